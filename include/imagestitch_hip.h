@@ -1,0 +1,197 @@
+/*
+ * imagestitch_hip.h — C-ABI of the MI355X (gfx950) warp + multi-band blend hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one call the
+ * reference makes on cv::detail::RotationWarper / cv::detail::Blender (or their in-tree
+ * restatements).  Reference files, cited as alias:line (raw-file line numbers):
+ *   W = /root/reference/圆柱面投影变换/圆柱面投影变换/圆柱面投影.cpp   (cylindrical warper demo)
+ *   B = /root/reference/图像融合/图像融合/图像融合.cpp                 (blend demo)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
+ *   - every function returns an isx_status (0 = OK); isx_last_error() returns a thread-local
+ *     human-readable message for the last failure (the analogue of cv::Exception::what()).
+ *   - isx_mat mirrors cv::Mat{data,rows,cols,type(),step}; `type` uses OpenCV's numeric type
+ *     codes so an adapter can pass mat.type() through unchanged.  `device` = -1 means `data`
+ *     is a host pointer (the library stages it through HBM, PCIe-inclusive), >= 0 means
+ *     `data` is a HIP device pointer on that device (zero-copy; the measured path).
+ *   - output mats are caller-allocated (replaces OutputArray::create, W:128-129,150); the
+ *     *_roi / *_result_size queries give the sizes.
+ *   - all work is enqueued on the handle's HIP stream (isx_*_set_stream); calls that return
+ *     host values (ROI, corner) synchronise that stream, the others are asynchronous when all
+ *     mats are device mats.
+ */
+#ifndef IMAGESTITCH_HIP_H
+#define IMAGESTITCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (CV_Assert / CV_Error analogue, W:94-96) ------------------------------ */
+typedef enum {
+    ISX_OK = 0,
+    ISX_ERR_INVALID = 1,     /* bad argument (null pointer, bad enum, bad size)                 */
+    ISX_ERR_TYPE = 2,        /* wrong isx_mat type for this call (CV_Assert(type()==...))       */
+    ISX_ERR_STATE = 3,       /* call order violated (feed before prepare, blend twice, ...)     */
+    ISX_ERR_HIP = 4,         /* a HIP runtime call failed; message carries hipGetErrorString    */
+    ISX_ERR_NOMEM = 5,       /* hipMalloc failed                                                */
+    ISX_ERR_UNSUPPORTED = 6, /* valid in OpenCV, not implemented on this path                   */
+    ISX_ERR_SIZE = 7,        /* caller-allocated output has the wrong rows/cols                 */
+    ISX_ERR_PLAN = 8         /* a planned (sync-free) run saw geometry that differs from plan   */
+} isx_status;
+
+/* ---- cv::Mat type codes: depth + ((cn-1)<<3), same numbers as OpenCV -------------------- */
+enum {
+    ISX_8UC1 = 0,   /* CV_8UC1  : masks (W:213-214,232)                                       */
+    ISX_8UC3 = 16,  /* CV_8UC3  : source and warped images (W:166-169,229)                    */
+    ISX_16SC3 = 19, /* CV_16SC3 : Blender::feed input / blend output (W:294,302,313)          */
+    ISX_32FC1 = 5,  /* CV_32FC1 : xmap / ymap (W:128-129)                                     */
+    ISX_32FC3 = 21  /* CV_32FC3 : float images (W:261; B:143-145)                             */
+};
+
+/* cv::InterpolationFlags / cv::BorderTypes values used by W:229,232 */
+enum { ISX_INTER_NEAREST = 0, ISX_INTER_LINEAR = 1 };
+enum { ISX_BORDER_CONSTANT = 0, ISX_BORDER_REPLICATE = 1, ISX_BORDER_REFLECT = 2,
+       ISX_BORDER_WRAP = 3, ISX_BORDER_REFLECT_101 = 4 };
+
+/* warper kinds: cv::CylindricalWarper (W:219) / cv::SphericalWarper (B:93, commented) */
+enum { ISX_WARP_CYLINDRICAL = 0, ISX_WARP_SPHERICAL = 1 };
+
+/* cv::detail::Blender::{NO, FEATHER, MULTI_BAND} (W:271,276,278) */
+enum { ISX_BLEND_NO = 0, ISX_BLEND_FEATHER = 1, ISX_BLEND_MULTI_BAND = 2 };
+
+/* pyramid precision of the multi-band blender */
+enum {
+    ISX_PREC_I16 = 0,      /* OpenCV's arithmetic: int16 Laplacian pyramid, fp32 weights       */
+    ISX_PREC_F32 = 1,      /* everything fp32, same order of operations, no short casts        */
+    ISX_PREC_F16ACC32 = 2  /* Gaussian levels stored fp16, arithmetic + accumulators fp32      */
+};
+
+typedef struct isx_mat {
+    void*  data;    /* first byte of row 0                                                     */
+    int    rows;
+    int    cols;
+    int    type;    /* ISX_8UC1 ...                                                            */
+    size_t step;    /* bytes between consecutive rows (cv::Mat::step)                          */
+    int    device;  /* -1: host pointer; >=0: HIP device pointer on that device                */
+} isx_mat;
+
+typedef struct isx_warper  isx_warper;
+typedef struct isx_blender isx_blender;
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char* isx_last_error(void);            /* thread-local message of the last failure      */
+const char* isx_version(void);
+int         isx_device_count(int* count);    /* hipGetDeviceCount; ISX_ERR_HIP if no runtime  */
+
+/* ---- warper: replaces warper_creator->create(scale) + RotationWarper (W:217-233) -------- */
+/* replaces Ptr<RotationWarper> w = warper_creator->create(float scale)  (W:217-222; the
+ * in-tree twin hard-codes `float scale = 2707.47f`, W:30).  `device` is the HIP device.      */
+int isx_warper_create(int kind, float scale, int device, isx_warper** out);
+int isx_warper_destroy(isx_warper* w);
+int isx_warper_set_stream(isx_warper* w, void* hip_stream /* hipStream_t, NULL = default */);
+
+/* setCameraParams (W:90-120): K, R are 3x3 row-major CV_32F.  Writes r_kinv = R*K^-1 (W:108)
+ * and k_rinv = K*R^T (W:113) as the library computes them (for inspection / parity tests).   */
+int isx_warper_camera(isx_warper* w, const float K[9], const float R[9],
+                      float r_kinv[9], float k_rinv[9]);
+
+/* detectResultRoi (W:64-88): full forward scan of every source pixel on the GPU.
+ * roi = {tl.x, tl.y, br.x, br.y} (inclusive br, trunc-toward-zero casts, W:83-86).
+ * minmax (optional, may be NULL) receives the four float extrema {min u, min v, max u, max v}. */
+int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9],
+                   int roi[4], float minmax[4]);
+
+/* buildMaps (W:122-144): xmap,ymap are caller-allocated CV_32FC1 of
+ * (roi[3]-roi[1]+1) rows x (roi[2]-roi[0]+1) cols (W:128-129).                               */
+int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9],
+                          isx_mat* xmap, isx_mat* ymap, int roi[4]);
+
+/* Point warp(src,K,R,interp,border,dst) (W:145-161; stock call sites B:105,109): buildMaps +
+ * cv::remap (W:157) fused into one gather kernel; the maps are never written to HBM.
+ * src: CV_8UC3 / CV_8UC1 (fixed-point bilinear) or CV_32FC3 / CV_32FC1 (float bilinear).
+ * dst: caller-allocated, same type, (roi.h+1) x (roi.w+1) (W:150).  corner = roi.tl() (W:160). */
+int isx_warper_warp(isx_warper* w, const isx_mat* src, const float K[9], const float R[9],
+                    int interp, int border, isx_mat* dst, int corner[2]);
+
+/* The two calls of W:229 + W:232 on one tile fused: image LINEAR/REFLECT and mask
+ * NEAREST/CONSTANT in one pass over the destination.  src_mask may be NULL = all 255
+ * (W:213-214).  dst_img may be CV_8UC3 or CV_16SC3 (= warp + convertTo(CV_16S), W:294).      */
+int isx_warper_warp_with_mask(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask,
+                              const float K[9], const float R[9],
+                              isx_mat* dst_img, isx_mat* dst_mask, int corner[2]);
+
+/* Sync-free variant for captured / batched runs: the caller supplies the ROI it planned with
+ * isx_warper_roi; the ROI scan still runs on the GPU and is compared with `planned_roi` on
+ * the device; a mismatch raises the sticky flag read by isx_warper_plan_status.               */
+int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img,
+                                      const isx_mat* src_mask, const float K[9],
+                                      const float R[9], const int planned_roi[4],
+                                      isx_mat* dst_img, isx_mat* dst_mask);
+int isx_warper_plan_status(isx_warper* w, int* mismatches /* synchronises the stream */);
+
+/* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
+/* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
+ * type must be ISX_BLEND_MULTI_BAND; num_bands default in OpenCV is 5.                        */
+int isx_blender_create(int type, int num_bands, int precision, int device, isx_blender** out);
+int isx_blender_destroy(isx_blender* b);
+int isx_blender_set_stream(isx_blender* b, void* hip_stream);
+int isx_blender_set_num_bands(isx_blender* b, int num_bands);   /* mb->setNumBands(n), W:273 */
+int isx_blender_num_bands(isx_blender* b, int* num_bands);      /* after prepare: the clamped */
+
+/* blender->prepare(corners, sizes) (W:281): corners_xy = {x0,y0,x1,y1,...}, sizes_wh likewise */
+int isx_blender_prepare(isx_blender* b, int n, const int* corners_xy, const int* sizes_wh);
+/* MultiBandBlender::prepare(Rect dst_roi) */
+int isx_blender_prepare_roi(isx_blender* b, int x, int y, int width, int height);
+
+/* blender->feed(img [CV_16SC3], mask [CV_8U], tl) (W:302).  img may also be CV_32FC3 in
+ * the F32 / F16ACC32 precisions.  CV_8UC3 is rejected with ISX_ERR_UNSUPPORTED (OpenCV runs a
+ * different, 8-bit pyramid for it that the reference never uses) — see isx_blender_feed_u8.   */
+int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y);
+/* images_warped.convertTo(CV_16S) (W:261,294) fused into feed: img is CV_8UC3 and is widened
+ * to int16 on load; results are identical to converting first and calling isx_blender_feed.   */
+int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y);
+
+/* size of the result of blend(): dst_roi_final_ (unpadded union of the fed tiles)             */
+int isx_blender_result_size(isx_blender* b, int* width, int* height);
+/* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast
+ * round-half-even) or CV_32FC3 (F32/F16ACC32 only); dst_mask: CV_8UC1.  Releases the pyramids:
+ * prepare must be called again before the next feed (as in OpenCV).                           */
+int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask);
+
+/* introspection for parity tests: copy destination pyramid level `level` (after feeds, before
+ * blend) to host buffers.  lap: rows*cols*3 of int16 (I16) or float (F32/F16ACC32); weight:
+ * rows*cols float.  Either may be NULL.  rows/cols are always written.                        */
+int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
+                            int* rows, int* cols);
+
+/* ---- the reference's in-tree single-band seam-ramp blend (B:141-717) --------------------- */
+/* images1/images2: CV_32FC3 warped tiles (B:143-145), tl1/tl2 their corners (B:148-149),
+ * pano: caller-allocated CV_32FC3 of isx_blend_pair_linear_size().  seam_x (optional, may be
+ * NULL) receives the greedy seam's x per row (B:268-307), panoHe_ entries.                    */
+int isx_blend_pair_linear_size(int rows1, int cols1, int rows2, int cols2,
+                               int tl1_x, int tl1_y, int tl2_x, int tl2_y,
+                               int* pano_rows, int* pano_cols);
+int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2,
+                          int tl1_x, int tl1_y, int tl2_x, int tl2_y,
+                          isx_mat* pano, int* seam_x, int device, void* hip_stream);
+
+/* ---- per-kernel HIP-event timing (feeds bench.py's roofline object) ----------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on its own stream.               */
+int isx_profile_enable(int on);
+int isx_profile_reset(void);
+/* number of distinct kernel names seen; then name / launches / total milliseconds by index.
+ * isx_profile_collect() synchronises the device and folds pending events into the totals.     */
+int isx_profile_collect(void);
+int isx_profile_count(int* n);
+int isx_profile_entry(int index, const char** name, long long* launches, double* total_ms,
+                      double* alg_bytes /* algorithmic bytes summed over launches */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGESTITCH_HIP_H */
