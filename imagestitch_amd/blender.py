@@ -1,0 +1,107 @@
+"""Host-side mirror of cv::detail::Blender / MultiBandBlender as the reference calls it
+(W:271-273, 281, 302, 313; S:1244-1280).
+
+    blender = Blender.createDefault(Blender.MULTI_BAND, False)      # W:271
+    blender.setNumBands(4)                                          # W:273
+    blender.prepare(corners, sizes)                                 # W:281
+    blender.feed(img_s16, mask, corner)                             # W:302
+    result, result_mask = blender.blend()                           # W:313
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BLEND_MULTI_BAND, PREC_F16ACC32, PREC_F32, PREC_I16, IsxError, as_mat, check  # noqa: F401
+from .warper import _empty_like_kind, _is_tensor
+
+
+class MultiBandBlender:
+    def __init__(self, try_gpu=False, num_bands=5, precision=PREC_I16, device=0, stream=None):
+        del try_gpu  # the reference passes false everywhere (W:276,278); this IS the accelerator path
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.isx_blender_create(BLEND_MULTI_BAND, int(num_bands), int(precision), int(device), C.byref(self._h)))
+        self.precision = precision
+        self._like = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.isx_blender_destroy(h)
+            self._h = None
+
+    def set_stream(self, stream):
+        ptr = getattr(stream, "cuda_stream", stream)
+        check(self._lib.isx_blender_set_stream(self._h, C.c_void_p(ptr or 0)))
+
+    def setNumBands(self, n):
+        check(self._lib.isx_blender_set_num_bands(self._h, int(n)))
+
+    def numBands(self):
+        n = C.c_int()
+        check(self._lib.isx_blender_num_bands(self._h, C.byref(n)))
+        return n.value
+
+    def prepare(self, corners, sizes=None):
+        """prepare(corners, sizes) (W:281) or prepare((x, y, w, h)) = MultiBandBlender::prepare(Rect)."""
+        if sizes is None:
+            x, y, w, h = [int(v) for v in corners]
+            check(self._lib.isx_blender_prepare_roi(self._h, x, y, w, h))
+            return
+        c = np.ascontiguousarray(np.asarray(corners, np.int32).reshape(-1))
+        s = np.ascontiguousarray(np.asarray(sizes, np.int32).reshape(-1))
+        if c.size != s.size or c.size % 2:
+            raise IsxError(1, "prepare: corners and sizes must both hold n (x, y) pairs")
+        check(self._lib.isx_blender_prepare(self._h, c.size // 2, c.ctypes.data_as(_lib._IP), s.ctypes.data_as(_lib._IP)))
+
+    def feed(self, img, mask, tl):
+        """feed(img CV_16SC3 [or CV_32FC3 in the float precisions], mask CV_8U, tl) (W:302)."""
+        mi, mm = as_mat(img), as_mat(mask)
+        self._like = img
+        check(self._lib.isx_blender_feed(self._h, C.byref(mi), C.byref(mm), int(tl[0]), int(tl[1])))
+
+    def feed_u8(self, img, mask, tl):
+        """convertTo(CV_16S) (W:294) fused into feed: img is CV_8UC3."""
+        mi, mm = as_mat(img), as_mat(mask)
+        self._like = img
+        check(self._lib.isx_blender_feed_u8(self._h, C.byref(mi), C.byref(mm), int(tl[0]), int(tl[1])))
+
+    def result_size(self):
+        w, h = C.c_int(), C.c_int()
+        check(self._lib.isx_blender_result_size(self._h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def level(self, i):
+        """Accumulated destination pyramid level i (parity tests): (laplacian HxWx3, weight HxW)."""
+        r, c = C.c_int(), C.c_int()
+        check(self._lib.isx_blender_debug_level(self._h, int(i), None, None, C.byref(r), C.byref(c)))
+        lap = np.empty((r.value, c.value, 3), np.int16 if self.precision == PREC_I16 else np.float32)
+        w = np.empty((r.value, c.value), np.float32)
+        check(self._lib.isx_blender_debug_level(self._h, int(i), lap.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), C.byref(r), C.byref(c)))
+        return lap, w
+
+    def blend(self, dst=None, dst_mask=None, out_f32=False):
+        """blend(result, result_mask) (W:313) -> (result, result_mask)."""
+        w, h = self.result_size()
+        like = self._like if (self._like is not None and _is_tensor(self._like)) else np.empty(0)
+        if dst is None:
+            dst = _empty_like_kind(like, (h, w, 3), np.float32 if out_f32 else np.int16)
+        if dst_mask is None:
+            dst_mask = _empty_like_kind(like, (h, w), np.uint8)
+        md, mm = as_mat(dst), as_mat(dst_mask)
+        check(self._lib.isx_blender_blend(self._h, C.byref(md), C.byref(mm)))
+        return dst, dst_mask
+
+
+class Blender:
+    """cv::detail::Blender factory (W:271,276,278)."""
+    NO, FEATHER, MULTI_BAND = 0, 1, 2
+
+    @staticmethod
+    def createDefault(blend_type, try_gpu=False, **kw):
+        if blend_type != Blender.MULTI_BAND:
+            raise IsxError(6, "Blender::createDefault: only MULTI_BAND is implemented on this path (got %d)" % blend_type)
+        return MultiBandBlender(try_gpu, **kw)

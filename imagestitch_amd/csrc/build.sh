@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# Builds imagestitch_amd/csrc/libimagestitch_hip.so for gfx950 (MI355X) with hipcc.
+#   -ffp-contract=off : the fp32 kernels must evaluate a*b+c as two rounded operations, exactly
+#                       like the (non-FMA) CPU reference code they are bit-compared against.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+mkdir -p build
+pids=()
+for f in isx_core.cpp warp.hip blend.hip linear_blend.hip; do
+    [ -f "$f" ] || continue
+    o=build/${f%.*}.o
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ isx_internal.hpp -nt "$o" ] || [ isx_device.hpp -nt "$o" ] || [ ../../include/imagestitch_hip.h -nt "$o" ]; then
+        $HIPCC $FLAGS -x hip -c "$f" -o "$o" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libimagestitch_hip.so build/*.o -Wl,-rpath,/opt/rocm/lib
+echo "built $(pwd)/libimagestitch_hip.so"

@@ -1,0 +1,188 @@
+// isx_core.cpp — error strings, buffers, host<->device mat staging, per-kernel profiler.
+#include "isx_internal.hpp"
+
+#include <map>
+#include <mutex>
+
+namespace isx {
+
+static thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+void clear_error() { g_err.clear(); }
+
+const char* type_name(int type) {
+    switch (type) {
+        case ISX_8UC1: return "CV_8UC1";
+        case ISX_8UC3: return "CV_8UC3";
+        case ISX_16SC3: return "CV_16SC3";
+        case ISX_32FC1: return "CV_32FC1";
+        case ISX_32FC3: return "CV_32FC3";
+        default: return "unsupported type";
+    }
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return ISX_OK;
+    if (p) { ISX_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    // round up so that small geometry changes do not reallocate
+    size_t want = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    ISX_HIP(hipMalloc(&p, want));
+    cap = want;
+    return ISX_OK;
+}
+void DevBuf::release() {
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+}
+
+int check_mat(const isx_mat* m, const char* what) {
+    ISX_CHECK_ARG(m != nullptr, ISX_ERR_INVALID, "%s: null isx_mat", what);
+    ISX_CHECK_ARG(m->data != nullptr, ISX_ERR_INVALID, "%s: null data pointer", what);
+    ISX_CHECK_ARG(m->rows > 0 && m->cols > 0, ISX_ERR_INVALID, "%s: empty mat (%d x %d)", what, m->rows, m->cols);
+    ISX_CHECK_ARG(m->step >= (size_t)m->cols * mat_elem_size(m->type), ISX_ERR_INVALID,
+                  "%s: step %zu smaller than a row (%d cols of %s)", what, m->step, m->cols, type_name(m->type));
+    return ISX_OK;
+}
+
+int MatStage::use_in(const isx_mat* m, hipStream_t s, const char* what) {
+    ISX_TRY(check_mat(m, what));
+    host = nullptr;
+    if (m->device >= 0) { d = *m; return ISX_OK; }
+    size_t row = (size_t)m->cols * mat_elem_size(m->type);
+    ISX_TRY(buf.reserve(row * m->rows));
+    d = *m; d.data = buf.p; d.step = row; d.device = 0;
+    ISX_HIP(hipMemcpy2DAsync(buf.p, row, m->data, m->step, row, m->rows, hipMemcpyHostToDevice, s));
+    return ISX_OK;
+}
+int MatStage::use_out(isx_mat* m, hipStream_t s, const char* what) {
+    (void)s;
+    ISX_TRY(check_mat(m, what));
+    host = nullptr;
+    if (m->device >= 0) { d = *m; return ISX_OK; }
+    size_t row = (size_t)m->cols * mat_elem_size(m->type);
+    ISX_TRY(buf.reserve(row * m->rows));
+    d = *m; d.data = buf.p; d.step = row; d.device = 0;
+    host = m;
+    return ISX_OK;
+}
+int MatStage::finish_out(hipStream_t s) {
+    if (!host) return ISX_OK;
+    size_t row = (size_t)host->cols * mat_elem_size(host->type);
+    ISX_HIP(hipMemcpy2DAsync(host->data, host->step, d.data, d.step, row, host->rows, hipMemcpyDeviceToHost, s));
+    ISX_HIP(hipStreamSynchronize(s));
+    return ISX_OK;
+}
+
+// ---- profiler ---------------------------------------------------------------------------------
+struct ProfEntry {
+    std::string name;
+    long long launches = 0;
+    double ms = 0.0;
+    double bytes = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static std::mutex g_pm;
+static bool g_prof = false;
+static std::vector<ProfEntry> g_entries;
+static std::map<std::string, int> g_index;
+static std::vector<hipEvent_t> g_pool;
+
+bool profiling_enabled() { return g_prof; }
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(const char* name, hipStream_t s, double alg_bytes) : stream(s) {
+    if (!g_prof) return;
+    std::lock_guard<std::mutex> lk(g_pm);
+    auto it = g_index.find(name);
+    if (it == g_index.end()) {
+        g_entries.emplace_back();
+        g_entries.back().name = name;
+        slot = (int)g_entries.size() - 1;
+        g_index[name] = slot;
+    } else slot = it->second;
+    ProfEntry& e = g_entries[slot];
+    e.launches++;
+    e.bytes += alg_bytes;
+    hipEvent_t a = get_event(), b = get_event();
+    e.pending.emplace_back(a, b);
+    (void)hipEventRecord(a, s);
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_pm);
+    (void)hipEventRecord(g_entries[slot].pending.back().second, stream);
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+extern "C" {
+
+const char* isx_last_error(void) { return g_err.c_str(); }
+const char* isx_version(void) { return "imagestitch_hip 0.1 (gfx950)"; }
+
+int isx_device_count(int* count) {
+    ISX_CHECK_ARG(count != nullptr, ISX_ERR_INVALID, "isx_device_count: null pointer");
+    ISX_HIP(hipGetDeviceCount(count));
+    return ISX_OK;
+}
+
+int isx_profile_enable(int on) { g_prof = on != 0; return ISX_OK; }
+
+int isx_profile_collect(void) {
+    ISX_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_pm);
+    for (auto& e : g_entries) {
+        for (auto& pr : e.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) e.ms += ms;
+            g_pool.push_back(pr.first);
+            g_pool.push_back(pr.second);
+        }
+        e.pending.clear();
+    }
+    return ISX_OK;
+}
+
+int isx_profile_reset(void) {
+    ISX_TRY(isx_profile_collect());
+    std::lock_guard<std::mutex> lk(g_pm);
+    g_entries.clear();
+    g_index.clear();
+    return ISX_OK;
+}
+
+int isx_profile_count(int* n) {
+    ISX_CHECK_ARG(n != nullptr, ISX_ERR_INVALID, "isx_profile_count: null pointer");
+    std::lock_guard<std::mutex> lk(g_pm);
+    *n = (int)g_entries.size();
+    return ISX_OK;
+}
+
+int isx_profile_entry(int index, const char** name, long long* launches, double* total_ms, double* alg_bytes) {
+    std::lock_guard<std::mutex> lk(g_pm);
+    ISX_CHECK_ARG(index >= 0 && index < (int)g_entries.size(), ISX_ERR_INVALID, "isx_profile_entry: index %d out of range", index);
+    const ProfEntry& e = g_entries[index];
+    if (name) *name = e.name.c_str();
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.ms;
+    if (alg_bytes) *alg_bytes = e.bytes;
+    return ISX_OK;
+}
+
+}  // extern "C"

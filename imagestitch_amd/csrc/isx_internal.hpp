@@ -1,0 +1,94 @@
+// isx_internal.hpp — shared host-side plumbing of libimagestitch_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/imagestitch_hip.h"
+
+namespace isx {
+
+// ---- errors: thread-local message + status code, no exceptions across the C boundary ----------
+int fail(int code, const char* fmt, ...);
+void clear_error();
+
+#define ISX_CHECK_ARG(cond, code, ...)                   \
+    do {                                                 \
+        if (!(cond)) return ::isx::fail(code, __VA_ARGS__); \
+    } while (0)
+
+#define ISX_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return ::isx::fail(e__ == hipErrorOutOfMemory ? ISX_ERR_NOMEM : ISX_ERR_HIP,       \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define ISX_TRY(expr)                \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != ISX_OK) return rc__; \
+    } while (0)
+
+// ---- cv::Mat type helpers --------------------------------------------------------------------
+inline int mat_depth(int type) { return type & 7; }
+inline int mat_cn(int type) { return (type >> 3) + 1; }
+inline int mat_elem_size(int type) {
+    static const int dsz[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+    return dsz[mat_depth(type)] * mat_cn(type);
+}
+const char* type_name(int type);
+
+// ---- device buffer that only ever grows (no hipMalloc in the steady state) -------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // grows if needed (synchronous hipFree/hipMalloc), keeps contents undefined
+    void release();
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// Stages a host isx_mat through HBM (device == -1) or passes a device mat through.
+// After use_in() `d` is a device mat with the same geometry; finish_out() copies results back.
+struct MatStage {
+    DevBuf buf;
+    isx_mat d{};        // device view
+    const isx_mat* host = nullptr;
+    int use_in(const isx_mat* m, hipStream_t s, const char* what);   // H2D if needed
+    int use_out(isx_mat* m, hipStream_t s, const char* what);        // allocate staging if needed
+    int finish_out(hipStream_t s);                                   // D2H if needed (async)
+};
+
+int check_mat(const isx_mat* m, const char* what);
+
+// ---- per-kernel profiler (hipEvents on the launch stream) ------------------------------------
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s, double alg_bytes);
+    ~ProfScope();
+    int slot = -1;
+    hipStream_t stream;
+};
+bool profiling_enabled();
+
+// Launch wrapper: records events when profiling, checks the launch error.
+#define ISX_LAUNCH(name, alg_bytes, stream, kernel, grid, block, shmem, ...)                   \
+    do {                                                                                       \
+        ::isx::ProfScope ps__(name, stream, (double)(alg_bytes));                              \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                   \
+        hipError_t le__ = hipGetLastError();                                                   \
+        if (le__ != hipSuccess)                                                                \
+            return ::isx::fail(ISX_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(le__)); \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace isx

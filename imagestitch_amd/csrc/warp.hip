@@ -1,0 +1,624 @@
+// warp.hip — cylindrical / spherical rotation warper for MI355X (gfx950).
+// Replaces the reference's in-tree warper (W:30-161: mapForward, mapBackward, detectResultRoi,
+// setCameraParams, buildMaps, warp) and the cv::remap call it ends in (W:157; arithmetic spec:
+// SURVEY.md §8(a) A8).  buildMaps + remap are fused: the back-projection is evaluated per
+// destination pixel in registers and the maps are never written to HBM (isx_warper_build_maps
+// exists for API parity only).
+//
+// Transcendentals: mapBackward's sinf/cosf depend only on the destination COLUMN (u) and, for the
+// spherical projector, on the destination ROW (v), so the host evaluates them once per column /
+// row with the same libm the reference code would call and the kernels read them from two small
+// tables — the per-pixel work is the 3x3 transform, two IEEE divisions and the sampler, all of
+// which the GPU reproduces bit-for-bit (no FMA contraction, correctly rounded div / sqrt).
+#include "isx_device.hpp"
+#include "isx_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <new>
+
+using namespace isx;
+using namespace isxd;
+
+namespace {
+
+constexpr float PI_F = (float)3.1415926535897932384626433832795;
+
+struct Proj {
+    float r_kinv[9], k_rinv[9];
+    float scale;
+    int kind;
+};
+
+struct MapTabs {            // device tables of the separable part of mapBackward
+    const float* col_s;     // sinf(u / scale)            per destination column
+    const float* col_c;     // cosf(u / scale)
+    const float* row_a;     // cyl: v / scale             sph: sinf(pi - v / scale)
+    const float* row_b;     // cyl: unused                sph: cosf(pi - v / scale)
+};
+
+// mapBackward (W:46-63) with the transcendental part tabulated
+__device__ __forceinline__ void map_backward(const Proj& p, const MapTabs& t, int dx, int dy, float& x, float& y) {
+    float x_, y_, z_;
+    if (p.kind == ISX_WARP_CYLINDRICAL) {
+        x_ = t.col_s[dx]; y_ = t.row_a[dy]; z_ = t.col_c[dx];             // W:51-53
+    } else {
+        float sinv = t.row_a[dy];
+        x_ = sinv * t.col_s[dx]; y_ = t.row_b[dy]; z_ = sinv * t.col_c[dx];
+    }
+    float z;
+    x = p.k_rinv[0] * x_ + p.k_rinv[1] * y_ + p.k_rinv[2] * z_;            // W:56
+    y = p.k_rinv[3] * x_ + p.k_rinv[4] * y_ + p.k_rinv[5] * z_;            // W:57
+    z = p.k_rinv[6] * x_ + p.k_rinv[7] * y_ + p.k_rinv[8] * z_;            // W:58
+    if (z > 0) { x /= z; y /= z; }                                        // W:60
+    else x = y = -1;                                                       // W:61
+}
+
+struct SrcView {
+    const unsigned char* data;
+    size_t step;
+    int rows, cols;
+};
+
+__device__ __forceinline__ int clamp_short(int v) { return min(max(v, -32768), 32767); }
+
+// cv::remap, INTER_NEAREST on a u8 / f32 image of CN channels
+template <class T, int CN>
+__device__ __forceinline__ void sample_nearest(const SrcView& s, float mx, float my, int border, T* out) {
+    int sx = clamp_short(cvround_x86(mx)), sy = clamp_short(cvround_x86(my));
+    if (!((unsigned)sx < (unsigned)s.cols && (unsigned)sy < (unsigned)s.rows)) {
+        if (border == ISX_BORDER_CONSTANT) {
+#pragma unroll
+            for (int c = 0; c < CN; ++c) out[c] = 0;
+            return;
+        }
+        sx = border_index(sx, s.cols, border); sy = border_index(sy, s.rows, border);
+    }
+    const T* q = (const T*)(s.data + (size_t)sy * s.step) + (size_t)sx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) out[c] = q[c];
+}
+
+// cv::remap, INTER_LINEAR: coordinates quantised to 1/32 px (cvRound(x*32)), taps through
+// borderInterpolate; u8 uses the 15-bit fixed-point table, f32 the float table.
+template <class T, int CN>
+__device__ __forceinline__ void sample_linear(const SrcView& s, float mx, float my, int border, T* out) {
+    int isx = cvround_x86(mx * 32.f), isy = cvround_x86(my * 32.f);
+    int fx = isx & 31, fy = isy & 31;
+    int sx = clamp_short(isx >> 5), sy = clamp_short(isy >> 5);
+    if (border == ISX_BORDER_CONSTANT && (sx >= s.cols || sx + 1 < 0 || sy >= s.rows || sy + 1 < 0)) {
+#pragma unroll
+        for (int c = 0; c < CN; ++c) out[c] = 0;
+        return;
+    }
+    int sx0 = border_index(sx, s.cols, border), sx1 = border_index(sx + 1, s.cols, border);
+    int sy0 = border_index(sy, s.rows, border), sy1 = border_index(sy + 1, s.rows, border);
+    const bool ok00 = sx0 >= 0 && sy0 >= 0, ok01 = sx1 >= 0 && sy0 >= 0, ok10 = sx0 >= 0 && sy1 >= 0, ok11 = sx1 >= 0 && sy1 >= 0;
+    const T* r0 = (const T*)(s.data + (size_t)max(sy0, 0) * s.step);
+    const T* r1 = (const T*)(s.data + (size_t)max(sy1, 0) * s.step);
+    const int o0 = max(sx0, 0) * CN, o1 = max(sx1, 0) * CN;
+    if constexpr (sizeof(T) == 1) {
+        // BilinearTab_i: (32-fx)(32-fy)*32 ... ; entry (0,0) saturates to {32767,0,0,1}
+        int w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+        if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            int v0 = ok00 ? r0[o0 + c] : 0, v1 = ok01 ? r0[o1 + c] : 0, v2 = ok10 ? r1[o0 + c] : 0, v3 = ok11 ? r1[o1 + c] : 0;
+            out[c] = (T)sat_u8((v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15);
+        }
+    } else {
+        float ax1 = fx * (1.f / 32.f), ax0 = 1.f - ax1, ay1 = fy * (1.f / 32.f), ay0 = 1.f - ay1;
+        float w0 = ay0 * ax0, w1 = ay0 * ax1, w2 = ay1 * ax0, w3 = ay1 * ax1;
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            float v0 = ok00 ? r0[o0 + c] : 0.f, v1 = ok01 ? r0[o1 + c] : 0.f, v2 = ok10 ? r1[o0 + c] : 0.f, v3 = ok11 ? r1[o1 + c] : 0.f;
+            out[c] = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+        }
+    }
+}
+
+// generic warp: one destination pixel per thread, 64 x 4 pixels per block
+template <class T, int CN>
+__global__ __launch_bounds__(256) void k_warp(Proj p, MapTabs t, SrcView src, unsigned char* dst, size_t dstep,
+                                              int dw, int dh, int interp, int border) {
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    float mx, my;
+    map_backward(p, t, dx, dy, mx, my);
+    T o[CN];
+    if (interp == ISX_INTER_NEAREST) sample_nearest<T, CN>(src, mx, my, border, o);
+    else sample_linear<T, CN>(src, mx, my, border, o);
+    T* q = (T*)(dst + (size_t)dy * dstep) + (size_t)dx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) q[c] = o[c];
+}
+
+// W:229 + W:232 fused: image LINEAR / REFLECT and mask NEAREST / CONSTANT from one map evaluation.
+// OUT16: write the image as CV_16SC3 (the convertTo(CV_16S) of W:294 folded in; u8 -> s16 is exact).
+template <bool OUT16>
+__global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcView img, SrcView msk, int has_mask,
+                                                       unsigned char* dimg, size_t dimg_step, unsigned char* dmask,
+                                                       size_t dmask_step, int dw, int dh) {
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    float mx, my;
+    map_backward(p, t, dx, dy, mx, my);
+    unsigned char o[3];
+    sample_linear<unsigned char, 3>(img, mx, my, ISX_BORDER_REFLECT, o);
+    if constexpr (OUT16) {
+        short* q = (short*)(dimg + (size_t)dy * dimg_step) + (size_t)dx * 3;
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    } else {
+        unsigned char* q = dimg + (size_t)dy * dimg_step + (size_t)dx * 3;
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    }
+    unsigned char m;
+    if (has_mask) sample_nearest<unsigned char, 1>(msk, mx, my, ISX_BORDER_CONSTANT, &m);
+    else {  // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT
+        int sx = clamp_short(cvround_x86(mx)), sy = clamp_short(cvround_x86(my));
+        m = ((unsigned)sx < (unsigned)img.cols && (unsigned)sy < (unsigned)img.rows) ? 255 : 0;
+    }
+    dmask[(size_t)dy * dmask_step + dx] = m;
+}
+
+// buildMaps (W:133-141), API parity only
+__global__ __launch_bounds__(256) void k_build_maps(Proj p, MapTabs t, float* xmap, size_t xstep, float* ymap, size_t ystep, int dw, int dh) {
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    float mx, my;
+    map_backward(p, t, dx, dy, mx, my);
+    ((float*)((char*)xmap + (size_t)dy * xstep))[dx] = mx;
+    ((float*)((char*)ymap + (size_t)dy * ystep))[dx] = my;
+}
+
+// ---- detectResultRoi (W:64-88): full forward scan, min / max reduction ----------------------------
+// order-preserving float <-> uint key for atomicMin / atomicMax
+__device__ __forceinline__ unsigned fkey(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float fkey_inv(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(b);
+#else
+    memcpy(&f, &b, 4);
+#endif
+    return f;
+}
+
+// mapForward (W:36-45).  v is bit-exact (IEEE mul/add/sqrt/div).  u goes through atan2: evaluated
+// in fp64 and rounded once, i.e. the correctly rounded atan2f; host libms differ from that by
+// <= 1 ulp, which the host-side candidate refinement (refine_u) removes.
+__device__ __forceinline__ void map_forward_cyl(const Proj& p, float x, float y, float& u, float& v) {
+    float x_ = p.r_kinv[0] * x + p.r_kinv[1] * y + p.r_kinv[2];
+    float y_ = p.r_kinv[3] * x + p.r_kinv[4] * y + p.r_kinv[5];
+    float z_ = p.r_kinv[6] * x + p.r_kinv[7] * y + p.r_kinv[8];
+    u = p.scale * (float)atan2((double)x_, (double)z_);
+    v = p.scale * y_ / sqrtf(x_ * x_ + z_ * z_);
+}
+
+// keys[0..3] = min u, min v, max u, max v (as fkey)
+__global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsigned* keys) {
+    float tl_u = 3.402823466e+38f, tl_v = 3.402823466e+38f, br_u = -3.402823466e+38f, br_v = -3.402823466e+38f;
+    const int y = blockIdx.y;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
+        float u, v;
+        map_forward_cyl(p, (float)x, (float)y, u, v);
+        tl_u = (u < tl_u) ? u : tl_u; tl_v = (v < tl_v) ? v : tl_v;     // (std::min)(tl, u): NaN never wins
+        br_u = (br_u < u) ? u : br_u; br_v = (br_v < v) ? v : br_v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        tl_u = fminf(tl_u, __shfl_xor(tl_u, o)); tl_v = fminf(tl_v, __shfl_xor(tl_v, o));
+        br_u = fmaxf(br_u, __shfl_xor(br_u, o)); br_v = fmaxf(br_v, __shfl_xor(br_v, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&keys[0], fkey(tl_u)); atomicMin(&keys[1], fkey(tl_v));
+        atomicMax(&keys[2], fkey(br_u)); atomicMax(&keys[3], fkey(br_v));
+    }
+}
+
+// second pass: collect every source pixel whose u is within `tol` of an extremum, so the host can
+// re-evaluate exactly those with its own atan2f (what the reference code would have computed)
+__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, float tol,
+                                                        int* cand_xy, int cap, int* count) {
+    const float umin = fkey_inv(keys[0]), umax = fkey_inv(keys[2]);
+    const int y = blockIdx.y;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
+        float u, v;
+        map_forward_cyl(p, (float)x, (float)y, u, v);
+        bool lo = u <= umin + tol, hi = u >= umax - tol;
+        if (lo || hi) {
+            int i = atomicAdd(count, 1);
+            if (i < cap) { cand_xy[2 * i] = x; cand_xy[2 * i + 1] = y | (lo ? 0 : 0x40000000) | ((lo && hi) ? 0x20000000 : 0); }
+        }
+    }
+}
+
+// planned (sync-free) runs: compare the scanned ROI with the planned one on the device
+__global__ void k_roi_check(const unsigned* keys, int4 planned, int* mismatches) {
+    int tlx = f2i_x86(fkey_inv(keys[0])), tly = f2i_x86(fkey_inv(keys[1]));
+    int brx = f2i_x86(fkey_inv(keys[2])), bry = f2i_x86(fkey_inv(keys[3]));
+    if (tlx != planned.x || tly != planned.y || brx != planned.z || bry != planned.w) atomicAdd(mismatches, 1);
+}
+
+// ---- host-side scalar restatements used for parameter set-up only (O(W+H) work) -----------------
+// K.inv() on 3x3 CV_32F: closed form in double, rounded once (OpenCV cv::invert, n == 3);
+// Mat products of CV_32F: double accumulation, rounded once (cv::gemm GEMMSingleMul<float,double>).
+void mat3_mul(const float a[9], const float b[9], float c[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += (double)a[i * 3 + k] * (double)b[k * 3 + j];
+            c[i * 3 + j] = (float)s;
+        }
+}
+bool mat3_inv(const float s[9], float d[9]) {
+    auto S = [&](int i, int j) { return (double)s[i * 3 + j]; };
+    double det = S(0, 0) * (S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) - S(0, 1) * (S(1, 0) * S(2, 2) - S(1, 2) * S(2, 0)) +
+                 S(0, 2) * (S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0));
+    if (det == 0.0) { for (int i = 0; i < 9; ++i) d[i] = 0.f; return false; }
+    double id = 1.0 / det;
+    d[0] = (float)((S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) * id);
+    d[1] = (float)((S(0, 2) * S(2, 1) - S(0, 1) * S(2, 2)) * id);
+    d[2] = (float)((S(0, 1) * S(1, 2) - S(0, 2) * S(1, 1)) * id);
+    d[3] = (float)((S(1, 2) * S(2, 0) - S(1, 0) * S(2, 2)) * id);
+    d[4] = (float)((S(0, 0) * S(2, 2) - S(0, 2) * S(2, 0)) * id);
+    d[5] = (float)((S(0, 2) * S(1, 0) - S(0, 0) * S(1, 2)) * id);
+    d[6] = (float)((S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0)) * id);
+    d[7] = (float)((S(0, 1) * S(2, 0) - S(0, 0) * S(2, 1)) * id);
+    d[8] = (float)((S(0, 0) * S(1, 1) - S(0, 1) * S(1, 0)) * id);
+    return true;
+}
+
+inline int f2i_host(float v) { return (std::fabs(v) < 2147483648.0f) ? (int)v : INT_MIN; }
+
+// mapForward on the host (W:36-45 / SphericalProjector): used on O(W+H) points only — the spherical
+// border scan and the cylindrical extremum candidates
+void map_forward_host(const Proj& p, float x, float y, float& u, float& v) {
+    float x_ = p.r_kinv[0] * x + p.r_kinv[1] * y + p.r_kinv[2];
+    float y_ = p.r_kinv[3] * x + p.r_kinv[4] * y + p.r_kinv[5];
+    float z_ = p.r_kinv[6] * x + p.r_kinv[7] * y + p.r_kinv[8];
+    u = p.scale * atan2f(x_, z_);
+    if (p.kind == ISX_WARP_CYLINDRICAL) v = p.scale * y_ / sqrtf(x_ * x_ + z_ * z_);
+    else {
+        float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
+        v = p.scale * (PI_F - acosf(w == w ? w : 0));
+    }
+}
+
+}  // namespace
+
+struct isx_warper {
+    int kind = 0, device = 0;
+    float scale = 1.f;
+    hipStream_t stream = nullptr;
+    // device scratch
+    DevBuf tabs, scan;       // tables; {keys[4], count, mismatches, cand...}
+    MatStage st_src, st_mask, st_dst, st_dmask, st_x, st_y;
+    // table cache key
+    int tab_kind = -1, tab_roi[4] = {0, 0, 0, 0};
+    float tab_scale = 0.f;
+    std::vector<float> host_tabs;
+    std::vector<int> host_cand;
+    float k[9], rinv[9];
+    Proj proj;
+};
+
+namespace {
+
+constexpr int CAND_CAP = 1 << 16;
+
+int set_camera(isx_warper* w, const float K[9], const float R[9]) {
+    ISX_CHECK_ARG(K != nullptr && R != nullptr, ISX_ERR_INVALID, "setCameraParams: K and R must be 3x3 CV_32F (got null)");  // W:94-95
+    for (int i = 0; i < 9; ++i) {
+        ISX_CHECK_ARG(std::isfinite(K[i]) && std::isfinite(R[i]), ISX_ERR_INVALID, "setCameraParams: K / R contain non-finite values");
+        w->k[i] = K[i];                                                     // W:98-101
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) w->rinv[i * 3 + j] = R[j * 3 + i];   // W:103
+    float kinv[9];
+    mat3_inv(K, kinv);
+    mat3_mul(R, kinv, w->proj.r_kinv);                                      // W:108
+    mat3_mul(K, w->rinv, w->proj.k_rinv);                                   // W:113
+    w->proj.scale = w->scale;
+    w->proj.kind = w->kind;
+    return ISX_OK;
+}
+
+// detectResultRoi.  Cylindrical: full scan on the GPU (W:72-81) + host refinement of u.
+// Spherical: OpenCV's detectResultRoiByBorder + pole tests — O(W+H) points, evaluated on the host.
+int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync_free, const int* planned) {
+    hipStream_t st = w->stream;
+    size_t need = 64 + (size_t)CAND_CAP * 8;
+    if (!w->scan.p) {
+        ISX_TRY(w->scan.reserve(need));
+        ISX_HIP(hipMemsetAsync(w->scan.p, 0, 64, st));
+    }
+    unsigned* keys = (unsigned*)w->scan.p;
+    int* count = (int*)(keys + 4);
+    int* mism = (int*)(keys + 5);
+    int* cand = (int*)((char*)w->scan.p + 64);
+    if (w->kind == ISX_WARP_SPHERICAL) {
+        ISX_CHECK_ARG(!sync_free, ISX_ERR_UNSUPPORTED, "planned warp: spherical ROI is computed on the host; use isx_warper_warp_with_mask");
+        float tl_u = std::numeric_limits<float>::max(), tl_v = tl_u, br_u = -tl_u, br_v = -tl_u, u, v;
+        auto upd = [&](float x, float y) {
+            map_forward_host(w->proj, x, y, u, v);
+            tl_u = (std::min)(tl_u, u); tl_v = (std::min)(tl_v, v); br_u = (std::max)(br_u, u); br_v = (std::max)(br_v, v);
+        };
+        for (int i = 0; i < sw; ++i) { upd((float)i, 0.f); upd((float)i, (float)(sh - 1)); }
+        for (int i = 0; i < sh; ++i) { upd(0.f, (float)i); upd((float)(sw - 1), (float)i); }
+        tl_u = (float)f2i_host(tl_u); tl_v = (float)f2i_host(tl_v); br_u = (float)f2i_host(br_u); br_v = (float)f2i_host(br_v);
+        const float* k = w->k; const float* rinv = w->rinv;
+        float x = rinv[1], y = rinv[4], z = rinv[7];
+        if (y > 0.f) {
+            float x_ = (k[0] * x + k[1] * y) / z + k[2], y_ = k[4] * y / z + k[5];
+            if (x_ > 0.f && x_ < sw && y_ > 0.f && y_ < sh) {
+                float pv = (float)(3.1415926535897932384626433832795 * w->scale);
+                tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, pv); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, pv);
+            }
+        }
+        x = rinv[1]; y = -rinv[4]; z = rinv[7];
+        if (y > 0.f) {
+            float x_ = (k[0] * x + k[1] * y) / z + k[2], y_ = k[4] * y / z + k[5];
+            if (x_ > 0.f && x_ < sw && y_ > 0.f && y_ < sh) {
+                tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, 0.f); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, 0.f);
+            }
+        }
+        if (mm) { mm[0] = tl_u; mm[1] = tl_v; mm[2] = br_u; mm[3] = br_v; }
+        roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
+        return ISX_OK;
+    }
+    // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0; the
+    // mismatch counter keys[5] is sticky (zeroed when the scratch buffer is created)
+    ISX_HIP(hipMemsetAsync(keys, 0xff, 2 * sizeof(unsigned), st));
+    ISX_HIP(hipMemsetAsync(keys + 2, 0, 3 * sizeof(unsigned), st));
+    dim3 grid(std::min(cdiv(sw, 256), 8), sh);
+    double px = (double)sw * sh;
+    ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
+    if (sync_free) {
+        ISX_LAUNCH("roi_check", 0.0, st, k_roi_check, dim3(1), dim3(1), 0, keys, make_int4(planned[0], planned[1], planned[2], planned[3]), mism);
+        return ISX_OK;
+    }
+    // candidate pass: tolerance of 16 ulp of the largest |u| covers the GPU's correctly rounded
+    // atan2 vs any faithful host atan2f (<= 2 ulp) with a wide margin
+    unsigned hk[4];
+    ISX_HIP(hipMemcpyAsync(hk, keys, sizeof(hk), hipMemcpyDeviceToHost, st));
+    ISX_HIP(hipStreamSynchronize(st));
+    float umin = fkey_inv(hk[0]), vmin = fkey_inv(hk[1]), umax = fkey_inv(hk[2]), vmax = fkey_inv(hk[3]);
+    float amax = std::max(std::fabs(umin), std::fabs(umax));
+    float tol = 16.f * (std::nextafter(amax, std::numeric_limits<float>::infinity()) - amax);
+    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, grid, dim3(256), 0, w->proj, sw, sh, keys, tol, cand, CAND_CAP, count);
+    int n = 0;
+    ISX_HIP(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, st));
+    ISX_HIP(hipStreamSynchronize(st));
+    ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
+    w->host_cand.resize((size_t)std::max(n, 1) * 2);
+    if (n > 0) ISX_HIP(hipMemcpy(w->host_cand.data(), cand, (size_t)n * 8, hipMemcpyDeviceToHost));
+    float hu_min = std::numeric_limits<float>::max(), hu_max = -hu_min;
+    for (int i = 0; i < n; ++i) {
+        int x = w->host_cand[2 * i], y = w->host_cand[2 * i + 1] & 0x1fffffff;
+        float u, v;
+        map_forward_host(w->proj, (float)x, (float)y, u, v);
+        hu_min = (std::min)(hu_min, u); hu_max = (std::max)(hu_max, u);
+    }
+    if (n == 0) { hu_min = umin; hu_max = umax; }   // all-NaN scan: keep the sentinels
+    if (mm) { mm[0] = hu_min; mm[1] = vmin; mm[2] = hu_max; mm[3] = vmax; }
+    roi[0] = f2i_host(hu_min); roi[1] = f2i_host(vmin); roi[2] = f2i_host(hu_max); roi[3] = f2i_host(vmax);   // W:83-86
+    return ISX_OK;
+}
+
+// per-column / per-row tables of mapBackward's transcendental part, cached per (kind, scale, roi)
+int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
+    int mw = roi[2] - roi[0] + 1, mh = roi[3] - roi[1] + 1;
+    size_t n = (size_t)2 * mw + 2 * mh;
+    bool hit = w->tab_kind == w->kind && w->tab_scale == w->scale && std::equal(roi, roi + 4, w->tab_roi) && w->tabs.p != nullptr;
+    if (!hit) {
+        w->host_tabs.resize(n);
+        float* cs = w->host_tabs.data(); float* cc = cs + mw; float* ra = cc + mw; float* rb = ra + mh;
+        for (int i = 0; i < mw; ++i) {
+            float u = (float)(roi[0] + i);
+            u /= w->scale;                                 // W:48
+            cs[i] = sinf(u); cc[i] = cosf(u);              // W:51,53
+        }
+        for (int i = 0; i < mh; ++i) {
+            float v = (float)(roi[1] + i);
+            v /= w->scale;                                 // W:49
+            if (w->kind == ISX_WARP_CYLINDRICAL) { ra[i] = v; rb[i] = 0.f; }          // W:52
+            else { ra[i] = sinf(PI_F - v); rb[i] = cosf(PI_F - v); }
+        }
+        ISX_TRY(w->tabs.reserve(n * sizeof(float)));
+        ISX_HIP(hipMemcpyAsync(w->tabs.p, w->host_tabs.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
+        ISX_HIP(hipStreamSynchronize(w->stream));   // host_tabs may be rewritten by the next call
+        w->tab_kind = w->kind; w->tab_scale = w->scale; std::copy(roi, roi + 4, w->tab_roi);
+    }
+    const float* base = (const float*)w->tabs.p;
+    t->col_s = base; t->col_c = base + mw; t->row_a = base + 2 * mw; t->row_b = base + 2 * mw + mh;
+    return ISX_OK;
+}
+
+int check_roi_sane(const int roi[4]) {
+    ISX_CHECK_ARG(roi[2] >= roi[0] && roi[3] >= roi[1] && (long long)roi[2] - roi[0] < 65536 && (long long)roi[3] - roi[1] < 65536,
+                  ISX_ERR_INVALID, "detectResultRoi produced a degenerate ROI [%d,%d]-[%d,%d] (bad K / R / scale?)", roi[0], roi[1], roi[2], roi[3]);
+    return ISX_OK;
+}
+
+int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, const float K[9], const float R[9], int interp, int border,
+                isx_mat* dst, isx_mat* dst_mask, int corner[2], const int* planned, bool fused) {
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "warp: null warper");
+    ISX_TRY(check_mat(src, "warp: src"));
+    ISX_TRY(check_mat(dst, "warp: dst"));
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(set_camera(w, K, R));
+    int roi[4];
+    if (planned) {
+        ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, true, planned));
+        std::copy(planned, planned + 4, roi);
+    } else ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, false, nullptr));
+    ISX_TRY(check_roi_sane(roi));
+    const int dw = roi[2] - roi[0] + 1, dh = roi[3] - roi[1] + 1;   // dst.create(roi.height + 1, roi.width + 1)  W:150
+    ISX_CHECK_ARG(dst->rows == dh && dst->cols == dw, ISX_ERR_SIZE, "warp: dst is %dx%d, the warped tile is %dx%d (query isx_warper_roi first)",
+                  dst->cols, dst->rows, dw, dh);
+    MapTabs t;
+    ISX_TRY(make_tabs(w, roi, &t));
+    hipStream_t st = w->stream;
+    ISX_TRY(w->st_src.use_in(src, st, "warp: src"));
+    ISX_TRY(w->st_dst.use_out(dst, st, "warp: dst"));
+    SrcView sv{(const unsigned char*)w->st_src.d.data, w->st_src.d.step, src->rows, src->cols};
+    dim3 grid(cdiv(dw, 64), cdiv(dh, 4));
+    double spx = (double)src->rows * src->cols, dpx = (double)dw * dh;
+    if (fused) {
+        ISX_CHECK_ARG(src->type == ISX_8UC3, ISX_ERR_TYPE, "warp_with_mask: src_img must be CV_8UC3, got %s", type_name(src->type));
+        ISX_CHECK_ARG(dst->type == ISX_8UC3 || dst->type == ISX_16SC3, ISX_ERR_TYPE, "warp_with_mask: dst_img must be CV_8UC3 or CV_16SC3, got %s", type_name(dst->type));
+        ISX_TRY(check_mat(dst_mask, "warp_with_mask: dst_mask"));
+        ISX_CHECK_ARG(dst_mask->type == ISX_8UC1, ISX_ERR_TYPE, "warp_with_mask: dst_mask must be CV_8U, got %s", type_name(dst_mask->type));
+        ISX_CHECK_ARG(dst_mask->rows == dh && dst_mask->cols == dw, ISX_ERR_SIZE, "warp_with_mask: dst_mask is %dx%d, the warped tile is %dx%d",
+                      dst_mask->cols, dst_mask->rows, dw, dh);
+        SrcView mv{nullptr, 0, src->rows, src->cols};
+        if (src_mask) {
+            ISX_TRY(check_mat(src_mask, "warp_with_mask: src_mask"));
+            ISX_CHECK_ARG(src_mask->type == ISX_8UC1, ISX_ERR_TYPE, "warp_with_mask: src_mask must be CV_8U, got %s", type_name(src_mask->type));
+            ISX_CHECK_ARG(src_mask->rows == src->rows && src_mask->cols == src->cols, ISX_ERR_SIZE, "warp_with_mask: src_mask size differs from src_img");
+            ISX_TRY(w->st_mask.use_in(src_mask, st, "warp_with_mask: src_mask"));
+            mv.data = (const unsigned char*)w->st_mask.d.data; mv.step = w->st_mask.d.step;
+        }
+        ISX_TRY(w->st_dmask.use_out(dst_mask, st, "warp_with_mask: dst_mask"));
+        double bytes = spx * (src_mask ? 4.0 : 3.0) + dpx * (dst->type == ISX_16SC3 ? 7.0 : 4.0);
+        if (dst->type == ISX_16SC3)
+            ISX_LAUNCH("warp_img_mask", bytes, st, k_warp_img_mask<true>, grid, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0,
+                       (unsigned char*)w->st_dst.d.data, w->st_dst.d.step, (unsigned char*)w->st_dmask.d.data, w->st_dmask.d.step, dw, dh);
+        else
+            ISX_LAUNCH("warp_img_mask", bytes, st, k_warp_img_mask<false>, grid, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0,
+                       (unsigned char*)w->st_dst.d.data, w->st_dst.d.step, (unsigned char*)w->st_dmask.d.data, w->st_dmask.d.step, dw, dh);
+        ISX_TRY(w->st_dmask.finish_out(st));
+    } else {
+        ISX_CHECK_ARG(dst->type == src->type, ISX_ERR_TYPE, "warp: dst type %s differs from src type %s", type_name(dst->type), type_name(src->type));
+        ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR, ISX_ERR_UNSUPPORTED, "warp: interpolation %d (only NEAREST and LINEAR)", interp);
+        ISX_CHECK_ARG(border >= ISX_BORDER_CONSTANT && border <= ISX_BORDER_REFLECT_101, ISX_ERR_UNSUPPORTED, "warp: border mode %d", border);
+        double bytes = (spx + dpx) * mat_elem_size(src->type);
+        unsigned char* dp = (unsigned char*)w->st_dst.d.data;
+        size_t ds = w->st_dst.d.step;
+        switch (src->type) {
+            case ISX_8UC3: ISX_LAUNCH("warp", bytes, st, (k_warp<unsigned char, 3>), grid, dim3(256), 0, w->proj, t, sv, dp, ds, dw, dh, interp, border); break;
+            case ISX_8UC1: ISX_LAUNCH("warp", bytes, st, (k_warp<unsigned char, 1>), grid, dim3(256), 0, w->proj, t, sv, dp, ds, dw, dh, interp, border); break;
+            case ISX_32FC3: ISX_LAUNCH("warp", bytes, st, (k_warp<float, 3>), grid, dim3(256), 0, w->proj, t, sv, dp, ds, dw, dh, interp, border); break;
+            case ISX_32FC1: ISX_LAUNCH("warp", bytes, st, (k_warp<float, 1>), grid, dim3(256), 0, w->proj, t, sv, dp, ds, dw, dh, interp, border); break;
+            default: return fail(ISX_ERR_TYPE, "warp: src type %s is not supported (CV_8UC1/3, CV_32FC1/3)", type_name(src->type));
+        }
+    }
+    ISX_TRY(w->st_dst.finish_out(st));
+    if (corner) { corner[0] = roi[0]; corner[1] = roi[1]; }   // return dst_roi.tl()  W:160
+    return ISX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int isx_warper_create(int kind, float scale, int device, isx_warper** out) {
+    clear_error();
+    ISX_CHECK_ARG(out != nullptr, ISX_ERR_INVALID, "isx_warper_create: null out pointer");
+    *out = nullptr;
+    ISX_CHECK_ARG(kind == ISX_WARP_CYLINDRICAL || kind == ISX_WARP_SPHERICAL, ISX_ERR_INVALID, "isx_warper_create: unknown warper kind %d", kind);
+    ISX_CHECK_ARG(std::isfinite(scale) && scale > 0.f, ISX_ERR_INVALID, "isx_warper_create: scale must be positive, got %g", (double)scale);
+    int n = 0;
+    ISX_HIP(hipGetDeviceCount(&n));
+    ISX_CHECK_ARG(device >= 0 && device < n, ISX_ERR_INVALID, "isx_warper_create: device %d of %d", device, n);
+    isx_warper* w = new (std::nothrow) isx_warper();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_NOMEM, "isx_warper_create: out of host memory");
+    w->kind = kind; w->scale = scale; w->device = device;
+    *out = w;
+    return ISX_OK;
+}
+
+int isx_warper_destroy(isx_warper* w) {
+    if (!w) return ISX_OK;
+    (void)hipSetDevice(w->device);
+    (void)hipStreamSynchronize(w->stream);
+    delete w;
+    return ISX_OK;
+}
+
+int isx_warper_set_stream(isx_warper* w, void* hip_stream) {
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_stream: null warper");
+    w->stream = (hipStream_t)hip_stream;
+    return ISX_OK;
+}
+
+int isx_warper_camera(isx_warper* w, const float K[9], const float R[9], float r_kinv[9], float k_rinv[9]) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_camera: null warper");
+    ISX_TRY(set_camera(w, K, R));
+    if (r_kinv) std::copy(w->proj.r_kinv, w->proj.r_kinv + 9, r_kinv);
+    if (k_rinv) std::copy(w->proj.k_rinv, w->proj.k_rinv + 9, k_rinv);
+    return ISX_OK;
+}
+
+int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], int roi[4], float minmax[4]) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr && roi != nullptr, ISX_ERR_INVALID, "isx_warper_roi: null argument");
+    ISX_CHECK_ARG(src_w > 0 && src_h > 0, ISX_ERR_INVALID, "isx_warper_roi: empty source size %d x %d", src_w, src_h);
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(set_camera(w, K, R));
+    return detect_roi(w, src_w, src_h, roi, minmax, false, nullptr);
+}
+
+int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4]) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr && roi != nullptr, ISX_ERR_INVALID, "buildMaps: null argument");
+    ISX_TRY(check_mat(xmap, "buildMaps: xmap"));
+    ISX_TRY(check_mat(ymap, "buildMaps: ymap"));
+    ISX_CHECK_ARG(xmap->type == ISX_32FC1 && ymap->type == ISX_32FC1, ISX_ERR_TYPE, "buildMaps: maps must be CV_32FC1");
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(set_camera(w, K, R));
+    ISX_TRY(detect_roi(w, src_w, src_h, roi, nullptr, false, nullptr));
+    ISX_TRY(check_roi_sane(roi));
+    const int dw = roi[2] - roi[0] + 1, dh = roi[3] - roi[1] + 1;   // W:128-129
+    ISX_CHECK_ARG(xmap->rows == dh && xmap->cols == dw && ymap->rows == dh && ymap->cols == dw, ISX_ERR_SIZE,
+                  "buildMaps: maps must be %dx%d", dw, dh);
+    MapTabs t;
+    ISX_TRY(make_tabs(w, roi, &t));
+    hipStream_t st = w->stream;
+    ISX_TRY(w->st_x.use_out(xmap, st, "buildMaps: xmap"));
+    ISX_TRY(w->st_y.use_out(ymap, st, "buildMaps: ymap"));
+    dim3 grid(cdiv(dw, 64), cdiv(dh, 4));
+    ISX_LAUNCH("build_maps", (double)dw * dh * 8.0, st, k_build_maps, grid, dim3(256), 0, w->proj, t, (float*)w->st_x.d.data, w->st_x.d.step,
+               (float*)w->st_y.d.data, w->st_y.d.step, dw, dh);
+    ISX_TRY(w->st_x.finish_out(st));
+    ISX_TRY(w->st_y.finish_out(st));
+    return ISX_OK;
+}
+
+int isx_warper_warp(isx_warper* w, const isx_mat* src, const float K[9], const float R[9], int interp, int border, isx_mat* dst, int corner[2]) {
+    clear_error();
+    return warp_common(w, src, nullptr, K, R, interp, border, dst, nullptr, corner, nullptr, false);
+}
+
+int isx_warper_warp_with_mask(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9], const float R[9],
+                              isx_mat* dst_img, isx_mat* dst_mask, int corner[2]) {
+    clear_error();
+    return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, corner, nullptr, true);
+}
+
+int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9], const float R[9],
+                                      const int planned_roi[4], isx_mat* dst_img, isx_mat* dst_mask) {
+    clear_error();
+    ISX_CHECK_ARG(planned_roi != nullptr, ISX_ERR_INVALID, "planned warp: null planned_roi");
+    return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, planned_roi, true);
+}
+
+int isx_warper_plan_status(isx_warper* w, int* mismatches) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr && mismatches != nullptr, ISX_ERR_INVALID, "plan_status: null argument");
+    *mismatches = 0;
+    if (!w->scan.p) return ISX_OK;
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_HIP(hipStreamSynchronize(w->stream));
+    ISX_HIP(hipMemcpy(mismatches, (int*)w->scan.p + 5, sizeof(int), hipMemcpyDeviceToHost));
+    if (*mismatches) return fail(ISX_ERR_PLAN, "planned warp: %d run(s) produced a ROI that differs from the planned one", *mismatches);
+    return ISX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Synthetic workloads of SURVEY.md §8(d): camera pairs, noisy sinusoid tiles, sinusoidal seam masks.
+
+Used by bench.py, __graft_entry__.smoke() and the tests.  Pure numpy; no reference data involved.
+"""
+import numpy as np
+
+SEED0 = 0xC0FFEE
+
+
+def _rot(axis, a):
+    c, s = np.cos(a), np.sin(a)
+    if axis == "x":
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], np.float64)
+    if axis == "y":
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float64)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float64)
+
+
+def camera_pair(width, height, focal, yaw=0.36, pitch=0.010, roll=0.005):
+    """K = [f 0 w/2; 0 f h/2; 0 0 1], R_i = Ry(-/+yaw) Rx(pitch) Rz(roll) as CV_32F (W:183-188,225-226)."""
+    K = np.array([[focal, 0, width / 2.0], [0, focal, height / 2.0], [0, 0, 1]], np.float32)
+    Rs = [(_rot("y", s * yaw) @ _rot("x", pitch) @ _rot("z", roll)).astype(np.float32) for s in (-1.0, 1.0)]
+    return K, Rs
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def make_tile(height, width, tile_index=0, noise_only=False):
+    """u8 = clamp(128 + 64 sin(2 pi x / 257) cos(2 pi y / 193) + noise), noise in U{-32..31}; the three
+    channels are phase shifted.  noise_only: pure U{0..255} (worst case for rounding parity)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(height * width * 3, dtype=np.uint64).reshape(height, width, 3)
+        r = _splitmix64(idx + np.uint64(((SEED0 + tile_index) * 0x1000003) & 0xFFFFFFFFFFFF))
+    if noise_only:
+        return (r >> np.uint64(56)).astype(np.uint8)
+    noise = ((r >> np.uint64(58)).astype(np.int32)) - 32
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    out = np.empty((height, width, 3), np.uint8)
+    for c in range(3):
+        base = 128.0 + 64.0 * np.sin(2 * np.pi * x / 257.0 + c * 0.7) * np.cos(2 * np.pi * y / 193.0 + c * 0.4)
+        out[:, :, c] = np.clip(np.rint(base) + noise[:, :, c], 0, 255).astype(np.uint8)
+    return out
+
+
+def seam_masks(corners, warped_masks):
+    """Global seam x_s(y) = x_mid + round(40 sin(2 pi y / 512)) through the centre of the overlap of two
+    tiles; mask0 = warped0 & (X < x_s), mask1 = warped1 & (X >= x_s) (X, y in panorama coordinates)."""
+    (x0, y0), (x1, y1) = corners
+    m0, m1 = warped_masks
+    ov_l, ov_r = max(x0, x1), min(x0 + m0.shape[1], x1 + m1.shape[1])
+    x_mid = (ov_l + ov_r) // 2
+    out = []
+    for (cx, cy), m, left in (((x0, y0), m0, x0 <= x1), ((x1, y1), m1, x0 > x1)):
+        Y = cy + np.arange(m.shape[0])[:, None]
+        X = cx + np.arange(m.shape[1])[None, :]
+        xs = x_mid + np.rint(40.0 * np.sin(2 * np.pi * Y / 512.0)).astype(np.int64)
+        keep = (X < xs) if left else (X >= xs)
+        out.append(np.where(keep, m, 0).astype(np.uint8))
+    return out

@@ -1,0 +1,153 @@
+"""Host-side mirror of cv::detail::RotationWarper as the reference uses it (W:217-233, B:99-110).
+
+    warper = CylindricalWarper().create(scale)        # warper_creator->create(focal)   W:217-222
+    corner, warped = warper.warp(img, K, R, INTER_LINEAR, BORDER_REFLECT)       # W:229
+    _, mask_w      = warper.warp(mask, K, R, INTER_NEAREST, BORDER_CONSTANT)    # W:232
+
+All pixel work happens in the HIP library behind the C-ABI (imagestitch_amd/csrc); this module only
+marshals arguments.  numpy arrays are host mats (staged over PCIe), torch CUDA tensors are device
+mats (zero-copy).  Outputs have the kind of the input.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BORDER_CONSTANT, BORDER_REFLECT, INTER_LINEAR, INTER_NEAREST, WARP_CYLINDRICAL,  # noqa: F401
+                   WARP_SPHERICAL, IsxError, as_mat, check, f9)
+
+
+def _is_tensor(a):
+    try:
+        import torch
+        return isinstance(a, torch.Tensor)
+    except ImportError:  # pragma: no cover
+        return False
+
+
+def _empty_like_kind(src, shape, dtype):
+    if _is_tensor(src):
+        import torch
+        return torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name), device=src.device)
+    return np.empty(shape, dtype)
+
+
+class RotationWarper:
+    """cv::detail::RotationWarper: warp / buildMaps / warpRoi on one projector kind."""
+
+    def __init__(self, kind, scale, device=0, stream=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.isx_warper_create(kind, float(scale), int(device), C.byref(self._h)))
+        self.kind, self.scale, self.device = kind, float(scale), device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.isx_warper_destroy(h)
+            self._h = None
+
+    def set_stream(self, stream):
+        """stream: a torch.cuda.Stream, an int hipStream_t, or None for the default stream."""
+        ptr = getattr(stream, "cuda_stream", stream)
+        check(self._lib.isx_warper_set_stream(self._h, C.c_void_p(ptr or 0)))
+
+    def camera(self, K, R):
+        """setCameraParams (W:90-120) -> (r_kinv, k_rinv) as the library computes them."""
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        a, b = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        check(self._lib.isx_warper_camera(self._h, kp, rp, a.ctypes.data_as(_lib._F9), b.ctypes.data_as(_lib._F9)))
+        return a, b
+
+    def warpRoi(self, src_size, K, R, with_minmax=False):
+        """detectResultRoi (W:64-88).  src_size = (width, height).  Returns (tl.x, tl.y, br.x, br.y)."""
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        roi = (C.c_int * 4)()
+        mm = (C.c_float * 4)()
+        check(self._lib.isx_warper_roi(self._h, int(src_size[0]), int(src_size[1]), kp, rp, roi, mm))
+        if with_minmax:
+            return tuple(roi), np.array(list(mm), np.float32)
+        return tuple(roi)
+
+    def buildMaps(self, src_size, K, R, like=None):
+        """buildMaps (W:122-144) -> (roi, xmap, ymap)."""
+        roi = self.warpRoi(src_size, K, R)
+        shape = (roi[3] - roi[1] + 1, roi[2] - roi[0] + 1)
+        xm = _empty_like_kind(like, shape, np.float32) if like is not None else np.empty(shape, np.float32)
+        ym = _empty_like_kind(like, shape, np.float32) if like is not None else np.empty(shape, np.float32)
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        mx, my = as_mat(xm), as_mat(ym)
+        r2 = (C.c_int * 4)()
+        check(self._lib.isx_warper_build_maps(self._h, int(src_size[0]), int(src_size[1]), kp, rp, C.byref(mx), C.byref(my), r2))
+        return tuple(r2), xm, ym
+
+    def warp(self, src, K, R, interp_mode, border_mode, dst=None):
+        """Point warp(src, K, R, interp, border, dst) (W:145-161) -> (corner, dst)."""
+        ms = as_mat(src)
+        if dst is None:
+            roi = self.warpRoi((ms.cols, ms.rows), K, R)
+            shape = (roi[3] - roi[1] + 1, roi[2] - roi[0] + 1) + tuple(src.shape[2:])
+            dst = _empty_like_kind(src, shape, np.dtype(str(src.dtype).replace("torch.", "")))
+        md = as_mat(dst)
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        corner = (C.c_int * 2)()
+        check(self._lib.isx_warper_warp(self._h, C.byref(ms), kp, rp, int(interp_mode), int(border_mode), C.byref(md), corner))
+        return (corner[0], corner[1]), dst
+
+    def warp_with_mask(self, img, K, R, mask=None, out16=False, dst_img=None, dst_mask=None):
+        """W:229 + W:232 (+ W:294 when out16) in one pass -> (corner, warped_img, warped_mask)."""
+        mi = as_mat(img)
+        if dst_img is None or dst_mask is None:
+            roi = self.warpRoi((mi.cols, mi.rows), K, R)
+            h, w = roi[3] - roi[1] + 1, roi[2] - roi[0] + 1
+            dst_img = _empty_like_kind(img, (h, w, 3), np.int16 if out16 else np.uint8)
+            dst_mask = _empty_like_kind(img, (h, w), np.uint8)
+        mdi, mdm = as_mat(dst_img), as_mat(dst_mask)
+        mm = as_mat(mask) if mask is not None else None
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        corner = (C.c_int * 2)()
+        check(self._lib.isx_warper_warp_with_mask(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
+                                                  C.byref(mdi), C.byref(mdm), corner))
+        return (corner[0], corner[1]), dst_img, dst_mask
+
+    def warp_with_mask_planned(self, img, K, R, planned_roi, dst_img, dst_mask, mask=None):
+        """Sync-free variant: caller planned the ROI (warpRoi) and allocated the outputs."""
+        mi, mdi, mdm = as_mat(img), as_mat(dst_img), as_mat(dst_mask)
+        mm = as_mat(mask) if mask is not None else None
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        roi = (C.c_int * 4)(*[int(v) for v in planned_roi])
+        check(self._lib.isx_warper_warp_with_mask_planned(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
+                                                          roi, C.byref(mdi), C.byref(mdm)))
+
+    def plan_status(self):
+        n = C.c_int()
+        check(self._lib.isx_warper_plan_status(self._h, C.byref(n)))
+        return n.value
+
+
+class _Creator:
+    kind = WARP_CYLINDRICAL
+
+    def __init__(self, device=0, stream=None):
+        self.device, self.stream = device, stream
+
+    def create(self, scale):
+        return RotationWarper(self.kind, scale, self.device, self.stream)
+
+
+class CylindricalWarper(_Creator):
+    """cv::CylindricalWarper (W:219): warper_creator->create(scale)."""
+    kind = WARP_CYLINDRICAL
+
+
+class SphericalWarper(_Creator):
+    """cv::SphericalWarper (B:93, commented out in the reference)."""
+    kind = WARP_SPHERICAL
