@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — Mpix/s of warp + 5-band blend on 4K pairs (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = every rank pushes `--pairs` (default 1) 4K pairs (BASELINE config 2: 2 x 3840x2160 u8x3
+tiles, cylindrical warp, 5-band fp32 blend) through warp -> prepare -> feed x2 -> blend with inputs
+resident in HBM; with N > 1 the blended mosaics are assembled on every rank with ONE all-gather
+(RCCL over xGMI).  Weak scaling: per-GPU work is fixed.  Mpix = source-tile pixels processed.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(width, height, focal, bands, precision):
+    """The CPU oracle (plain C, 1 thread, -O2, no FMA) on ONE pair of the same workload: the
+    reference's call sequence W:229,232 (two warps per tile), W:294, W:281,302,313."""
+    import numpy as np
+    from oracle import capi as O
+    from imagestitch_amd import synth
+    K, Rs = synth.camera_pair(width, height, focal)
+    imgs = [synth.make_tile(height, width, i) for i in range(2)]
+    t0 = time.perf_counter()
+    corners, warped, wmasks = [], [], []
+    for i in range(2):
+        c, wi, _ = O.warp_u8(O.CYL, focal, K, Rs[i], imgs[i], O.LINEAR, O.BORDER_REFLECT)
+        _, wm, _ = O.warp_u8(O.CYL, focal, K, Rs[i], np.full((height, width), 255, np.uint8), O.NEAREST, O.BORDER_CONSTANT)
+        corners.append(c); warped.append(wi); wmasks.append(wm)
+    t1 = time.perf_counter()
+    seam = synth.seam_masks(corners, wmasks)   # seam finder stand-in: not timed
+    t2 = time.perf_counter()
+    mb = O.MultiBand(bands, precision)
+    mb.prepare(corners, [(w.shape[1], w.shape[0]) for w in warped])
+    for i in range(2):
+        mb.feed(warped[i].astype(np.int16), seam[i], corners[i])
+    mb.blend(False)
+    t3 = time.perf_counter()
+    sec = (t1 - t0) + (t3 - t2)
+    return {"value": round(2 * width * height / sec / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "1 pair of %dx%d tiles (oracle/oracle.c, warp %.2fs + blend %.2fs)" % (width, height, t1 - t0, t3 - t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=1, help="4K pairs per GPU per step")
+    ap.add_argument("--bands", type=int, default=5)
+    ap.add_argument("--precision", default="f32", choices=["i16", "f32", "f16acc32"])
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--focal", type=float, default=3000.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import imagestitch_amd
+    from imagestitch_amd import _lib, synth
+    from imagestitch_amd.pipeline import PairStitcher
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = imagestitch_amd.load()
+    prec = {"i16": _lib.PREC_I16, "f32": _lib.PREC_F32, "f16acc32": _lib.PREC_F16ACC32}[args.precision]
+
+    W, H, F = args.width, args.height, args.focal
+    K, Rs = synth.camera_pair(W, H, F)
+    gen = torch.Generator(device=dev)
+    pairs = []
+    for p in range(args.pairs):
+        gen.manual_seed(synth.SEED0 + 1000 * rank + p)
+        # same statistics as synth.make_tile (sinusoid + U{-32..31} noise), generated on the device
+        yy, xx = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+        imgs = []
+        for t in range(2):
+            chans = []
+            for c in range(3):
+                base = 128.0 + 64.0 * torch.sin(2 * np.pi * xx / 257.0 + c * 0.7 + t) * torch.cos(2 * np.pi * yy / 193.0 + c * 0.4)
+                noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
+                chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
+            imgs.append(torch.stack(chans, dim=2).contiguous())
+        pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "int16"))
+        del yy, xx
+    bm = pairs[0].bytes_model()
+
+    gather_buf = None
+    if world > 1:
+        n_out = sum(p.out.numel() for p in pairs)
+        gather_buf = torch.empty((world * n_out,), dtype=torch.int16, device=dev)
+        send = torch.empty((n_out,), dtype=torch.int16, device=dev)
+
+    def step():
+        for p in pairs:
+            p.step()
+        if world > 1:
+            off = 0
+            for p in pairs:
+                send[off:off + p.out.numel()].copy_(p.out.reshape(-1)); off += p.out.numel()
+            dist.all_gather_into_tensor(gather_buf, send)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # warm-up; the last warm-up step runs with every kernel bracketed to find the dominant one
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    fence()
+    lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_reset()
+    step()
+    ent = _lib.profile_entries()
+    per_kernel = {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "alg_MB": round(v["alg_bytes"] / 1e6, 2)} for k, v in ent.items()}
+    dominant = max(ent.items(), key=lambda kv: kv[1]["ms"])[0] if ent else None
+    lib.isx_profile_reset()
+    # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream)
+    lib.isx_profile_filter(dominant.encode() if dominant else None)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ent = _lib.profile_entries()
+    lib.isx_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        mpix_step = world * args.pairs * 2 * W * H / 1e6
+        roof = None
+        if dominant and ent.get(dominant, {}).get("launches", 0) > 0:
+            e = ent[dominant]
+            avg_ms = e["ms"] / e["launches"]
+            bytes_per_launch = e["alg_bytes"] / e["launches"]
+            ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                    "alg_bytes_per_launch": int(bytes_per_launch), "launches": e["launches"]}
+        pair_ms = dt / args.steps / args.pairs * 1e3
+        out = {
+            "metric": "Mpix/s warp+5-band-blend @4K pair", "value": round(mpix_step * args.steps / dt, 1), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "%d x (2 x %dx%d u8x3 tiles, cylindrical warp f=%g, %d-band %s blend) per GPU per step%s" % (
+                args.pairs, W, H, F, args.bands, args.precision, ", all-gather of the s16x3 mosaics" if world > 1 else ""),
+                "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision,
+                "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
+            "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
+                                  "achieved_GBs": round(bm["total"] / (pair_ms * 1e-3) / 1e9, 1), "frac": round(bm["total"] / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roof,
+            "kernels_ms_one_step": per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H, F, args.bands, prec)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,7 @@ _SIGS = {
     "isx_blend_pair_linear": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, _MP, _IP, C.c_int, C.c_void_p],
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],
+    "isx_profile_filter": [C.c_char_p],
     "isx_profile_collect": [],
     "isx_profile_count": [_IP],
     "isx_profile_entry": [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],

@@ -91,6 +91,7 @@ struct ProfEntry {
 };
 static std::mutex g_pm;
 static bool g_prof = false;
+static std::string g_filter;   // empty = every kernel
 static std::vector<ProfEntry> g_entries;
 static std::map<std::string, int> g_index;
 static std::vector<hipEvent_t> g_pool;
@@ -107,6 +108,7 @@ static hipEvent_t get_event() {
 ProfScope::ProfScope(const char* name, hipStream_t s, double alg_bytes) : stream(s) {
     if (!g_prof) return;
     std::lock_guard<std::mutex> lk(g_pm);
+    if (!g_filter.empty() && g_filter != name) return;
     auto it = g_index.find(name);
     if (it == g_index.end()) {
         g_entries.emplace_back();
@@ -143,6 +145,12 @@ int isx_device_count(int* count) {
 }
 
 int isx_profile_enable(int on) { g_prof = on != 0; return ISX_OK; }
+
+int isx_profile_filter(const char* kernel_name) {
+    std::lock_guard<std::mutex> lk(g_pm);
+    g_filter = kernel_name ? kernel_name : "";
+    return ISX_OK;
+}
 
 int isx_profile_collect(void) {
     ISX_HIP(hipDeviceSynchronize());

@@ -1,0 +1,115 @@
+"""The hot path as the reference's main() drives it (W:223-233, 281, 294-302, 313), for one pair of
+tiles on one GPU: warp(image) + warp(mask) per tile -> prepare -> feed x2 -> blend.
+
+PairStitcher owns the device buffers so that the steady state allocates nothing.  Seam masks (the
+output of the seam finder, which is out of scope: SURVEY §8(f) N1) are inputs: they are built
+once from the warped masks with synth.seam_masks and stay resident.
+"""
+import numpy as np
+
+from . import _lib, synth
+from .blender import MultiBandBlender
+from .warper import CylindricalWarper, SphericalWarper
+
+
+def feed_geometry(roi, num_bands, tl, size):
+    """Padded tile rectangle of MultiBandBlender::feed (A11) -> (width, height) of the tile pyramid base."""
+    rx, ry, rw, rh = roi
+    L, m = num_bands, 1 << num_bands
+    gap = 3 * m
+    tlx, tly = max(rx, tl[0] - gap), max(ry, tl[1] - gap)
+    brx, bry = min(rx + rw, tl[0] + size[0] + gap), min(ry + rh, tl[1] + size[1] + gap)
+    tlx = rx + (((tlx - rx) >> L) << L)
+    tly = ry + (((tly - ry) >> L) << L)
+    w, h = brx - tlx, bry - tly
+    w += (m - w % m) % m
+    h += (m - h % m) % m
+    return w, h
+
+
+def prepare_geometry(corners, sizes, num_bands):
+    """dst_roi_ of MultiBandBlender::prepare (A9) -> ((x, y, padded_w, padded_h), (final_w, final_h), L)."""
+    c = np.asarray(corners).reshape(-1, 2)
+    s = np.asarray(sizes).reshape(-1, 2)
+    tl, br = c.min(0), (c + s).max(0)
+    w, h = int(br[0] - tl[0]), int(br[1] - tl[1])
+    L = min(num_bands, int(np.ceil(np.log(float(max(w, h))) / np.log(2.0))))
+    m = 1 << L
+    return (int(tl[0]), int(tl[1]), w + (m - w % m) % m, h + (m - h % m) % m), (w, h), L
+
+
+def model_bytes(src_px, warped_px, tile_base_px, mosaic_px, precision, num_bands):
+    """ALGORITHMIC bytes of one pair: each pyramid level materialised once,
+    elementwise work fused into its stencil, level-0 inputs at native width (u8x3 image + u8 mask
+    into feed — the convertTo(CV_16S) of W:294 is fused), maps never materialised.
+    Returns a dict with warp / feed / blend / total bytes."""
+    g = {_lib.PREC_F32: 16.0, _lib.PREC_I16: 10.0, _lib.PREC_F16ACC32: 8.0}[precision]
+    g_rgb = 12.0 if precision == _lib.PREC_F32 else 6.0
+    d = 10.0 if precision == _lib.PREC_I16 else 16.0
+    d_rgb = 6.0 if precision == _lib.PREC_I16 else 12.0
+    L = num_bands
+    warp = sum(3.0 * s + 4.0 * n for s, n in zip(src_px, warped_px))
+    feed = 0.0
+    for p in tile_base_px:
+        lv = [p / 4.0 ** k for k in range(L + 1)]
+        for k in range(L):                      # pyrDown k -> k+1
+            feed += lv[k] * (4.0 if k == 0 else g) + lv[k + 1] * g
+        for k in range(L):                      # Laplacian + accumulate level k
+            feed += lv[k] * ((4.0 if k == 0 else g) + 2.0 * d) + lv[k + 1] * g_rgb
+        feed += lv[L] * ((4.0 if L == 0 else g) + 2.0 * d)
+    lv = [mosaic_px / 4.0 ** k for k in range(L + 1)]
+    blend = lv[L] * (d + d_rgb) if L > 0 else lv[0] * (d + 7.0)
+    for k in range(L, 0, -1):
+        blend += lv[k] * d_rgb + lv[k - 1] * (d + (7.0 if k == 1 else d_rgb))
+    return {"warp": warp, "feed": feed, "blend": blend, "total": warp + feed + blend}
+
+
+class PairStitcher:
+    """One pair of tiles -> one blended mosaic, buffers resident in HBM (torch CUDA tensors)."""
+
+    def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
+                 device=0, stream=None, out_dtype="int16"):
+        import torch
+        self.torch = torch
+        self.imgs, self.K, self.Rs = imgs, K, Rs
+        self.device = device
+        creator = CylindricalWarper if kind == "cylindrical" else SphericalWarper
+        self.warper = creator(device, stream).create(scale)
+        self.blender = MultiBandBlender(False, num_bands, precision, device, stream)
+        self.precision, self.num_bands = precision, num_bands
+        dev = torch.device("cuda", device)
+        # plan: ROI per tile (detectResultRoi), output buffers, seam masks
+        self.rois = [self.warper.warpRoi((im.shape[1], im.shape[0]), K, R) for im, R in zip(imgs, Rs)]
+        self.sizes = [(r[2] - r[0] + 1, r[3] - r[1] + 1) for r in self.rois]
+        self.corners = [(r[0], r[1]) for r in self.rois]
+        self.warped = [torch.empty((h, w, 3), dtype=torch.uint8, device=dev) for (w, h) in self.sizes]
+        self.wmasks = [torch.empty((h, w), dtype=torch.uint8, device=dev) for (w, h) in self.sizes]
+        for i in range(len(imgs)):
+            self.warper.warp_with_mask(imgs[i], K, Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
+        seam = synth.seam_masks(self.corners, [m.cpu().numpy() for m in self.wmasks])
+        self.seam = [torch.from_numpy(s).to(dev) for s in seam]
+        self.roi_pad, (fw, fh), self.L = prepare_geometry(self.corners, self.sizes, num_bands)
+        odt = {"int16": torch.int16, "float32": torch.float32}[out_dtype]
+        self.out = torch.empty((fh, fw, 3), dtype=odt, device=dev)
+        self.out_mask = torch.empty((fh, fw), dtype=torch.uint8, device=dev)
+
+    def step(self):
+        """Exactly the reference's call sequence; ROI scan included (the warper recomputes it per call)."""
+        cs = []
+        for i in range(len(self.imgs)):
+            c, _, _ = self.warper.warp_with_mask(self.imgs[i], self.K, self.Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
+            cs.append(c)
+        self.blender.prepare(cs, self.sizes)
+        for i in range(len(self.imgs)):
+            self.blender.feed_u8(self.warped[i], self.seam[i], cs[i])
+        self.blender.blend(self.out, self.out_mask)
+        return self.out, self.out_mask
+
+    def bytes_model(self):
+        src_px = [im.shape[0] * im.shape[1] for im in self.imgs]
+        warped_px = [w * h for (w, h) in self.sizes]
+        base = [np.prod(feed_geometry(self.roi_pad, self.L, c, s)) for c, s in zip(self.corners, self.sizes)]
+        mosaic = self.roi_pad[2] * self.roi_pad[3]
+        out = model_bytes(src_px, warped_px, [float(b) for b in base], float(mosaic), self.precision, self.L)
+        out.update({"src_px": src_px, "warped_px": warped_px, "tile_base_px": [int(b) for b in base], "mosaic_px": int(mosaic)})
+        return out

@@ -23,28 +23,20 @@ def camera_pair(width, height, focal, yaw=0.36, pitch=0.010, roll=0.005):
     return K, Rs
 
 
-def _splitmix64(x):
-    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
-    z = x
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    return z ^ (z >> np.uint64(31))
-
-
 def make_tile(height, width, tile_index=0, noise_only=False):
-    """u8 = clamp(128 + 64 sin(2 pi x / 257) cos(2 pi y / 193) + noise), noise in U{-32..31}; the three
-    channels are phase shifted.  noise_only: pure U{0..255} (worst case for rounding parity)."""
-    with np.errstate(over="ignore"):
-        idx = np.arange(height * width * 3, dtype=np.uint64).reshape(height, width, 3)
-        r = _splitmix64(idx + np.uint64(((SEED0 + tile_index) * 0x1000003) & 0xFFFFFFFFFFFF))
+    """u8 = clamp(128 + 64 sin(2 pi x / 257) cos(2 pi y / 193) + noise), noise in U{-32..31} from a
+    PCG64 stream seeded SEED0 + tile_index; the three channels are phase shifted.
+    noise_only: pure U{0..255} (worst case for rounding parity)."""
+    rng = np.random.Generator(np.random.PCG64(SEED0 + tile_index))
     if noise_only:
-        return (r >> np.uint64(56)).astype(np.uint8)
-    noise = ((r >> np.uint64(58)).astype(np.int32)) - 32
-    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+        return rng.integers(0, 256, (height, width, 3), dtype=np.uint8)
+    noise = rng.integers(-32, 32, (height, width, 3), dtype=np.int16)
+    y = np.arange(height, dtype=np.float32)[:, None]
+    x = np.arange(width, dtype=np.float32)[None, :]
     out = np.empty((height, width, 3), np.uint8)
     for c in range(3):
         base = 128.0 + 64.0 * np.sin(2 * np.pi * x / 257.0 + c * 0.7) * np.cos(2 * np.pi * y / 193.0 + c * 0.4)
-        out[:, :, c] = np.clip(np.rint(base) + noise[:, :, c], 0, 255).astype(np.uint8)
+        out[:, :, c] = np.clip(np.rint(base).astype(np.int16) + noise[:, :, c], 0, 255).astype(np.uint8)
     return out
 
 

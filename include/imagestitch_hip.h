@@ -184,6 +184,9 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2,
 /* When enabled every kernel launch is bracketed by hipEvents on its own stream.               */
 int isx_profile_enable(int on);
 int isx_profile_reset(void);
+/* restrict the bracketing to one kernel name (NULL / "" = all): lets bench.py time the dominant
+ * kernel inside the timed region without perturbing the other launches.                          */
+int isx_profile_filter(const char* kernel_name);
 /* number of distinct kernel names seen; then name / launches / total milliseconds by index.
  * isx_profile_collect() synchronises the device and folds pending events into the totals.     */
 int isx_profile_collect(void);

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Regenerates the committed fixtures under tests/golden/ (run in the BUILD container only, where
+/root/reference exists; the GPU box and the tests only read the .npz files).
+
+  cyl_maps.npz       inputs + outputs of the reference's OWN mapForward / mapBackward (W:30-63 compiled
+                     verbatim into oracle/_ref/libref_warp.so by oracle/build.sh).  This is the one
+                     part of the hot path the reference holds in compilable form; it pins
+                     oracle.c's projector bit-exactly.
+  ref_inputs.npz     data crops of the reference's committed artefacts (mask_seam[0,1].bmp,
+                     images_warped_f[0,1].bmp written by S:1195-1198): realistic warped tiles and real
+                     DP-seam masks used as blend INPUTS.  Data files, not source.
+  oracle_regress.npz seeded inputs -> outputs of oracle/liboracle.so for remap / pyramids /
+                     MultiBandBlender / linear blend.  NOT reference-derived (OpenCV 3.4.2 is absent:
+                     "parity unpinned"); it freezes the restatement so that drift is caught.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import capi as O  # noqa: E402
+from imagestitch_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def cyl_maps():
+    assert O.ref() is not None, "oracle/_ref/libref_warp.so missing: run oracle/build.sh in the build container"
+    rng = np.random.default_rng(20260928)
+    out = {}
+    cams = []
+    # the reference's own geometry: scale = 2707.47f (W:30), 1101 x 1101 source (src1.bmp), c = 550.5
+    f = np.float32(2707.47)
+    cams.append((f, np.array([[f, 0, 550.5], [0, f, 550.5], [0, 0, 1]], np.float32), np.eye(3, dtype=np.float32), 1101, 1101))
+    for (w, h, fo, yaw) in ((3840, 2160, 3000.0, 0.36), (1920, 1080, 1500.0, -0.3), (640, 480, 300.0, 0.9)):
+        K, Rs = synth.camera_pair(w, h, fo, yaw=abs(yaw))
+        cams.append((np.float32(fo), K, Rs[0] if yaw > 0 else Rs[1], w, h))
+    for i, (scale, K, R, w, h) in enumerate(cams):
+        k, rinv, r_kinv, k_rinv = O.camera(K, R)
+        O.ref_set(float(scale), r_kinv, k_rinv)
+        # forward: image corners, borders and random interior points (integer pixel coordinates, as W:76 casts)
+        xs = np.concatenate([[0, w - 1, 0, w - 1], rng.integers(0, w, 400), np.arange(0, w, max(w // 64, 1))]).astype(np.float32)
+        ys = np.concatenate([[0, 0, h - 1, h - 1], rng.integers(0, h, 400), np.zeros(len(np.arange(0, w, max(w // 64, 1))))]).astype(np.float32)
+        u, v = O.ref_map_forward_n(xs, ys)
+        # backward: integer (u, v) across and beyond the ROI (z <= 0 cases included for wide yaw)
+        uu = rng.integers(int(u.min()) - 50, int(u.max()) + 50, 600).astype(np.float32)
+        vv = rng.integers(int(v.min()) - 50, int(v.max()) + 50, 600).astype(np.float32)
+        uu[:4] = [scale * 1.7, -scale * 1.7, scale * 3.2, 0]     # beyond +-pi/2: z <= 0 -> (-1,-1)
+        x, y = O.ref_map_backward_n(uu, vv)
+        out.update({"scale%d" % i: np.float32(scale), "r_kinv%d" % i: r_kinv, "k_rinv%d" % i: k_rinv, "size%d" % i: np.array([w, h]),
+                    "fx%d" % i: xs, "fy%d" % i: ys, "fu%d" % i: u, "fv%d" % i: v, "bu%d" % i: uu, "bv%d" % i: vv, "bx%d" % i: x, "by%d" % i: y})
+    out["n"] = np.array(len(cams))
+    np.savez_compressed(os.path.join(HERE, "cyl_maps.npz"), **out)
+    print("cyl_maps.npz:", len(cams), "cameras")
+
+
+def ref_inputs():
+    from PIL import Image
+    d = os.path.join(REF, "动态规划法寻找最佳缝合线", "动态规划法寻找最佳缝合线")
+    m0 = np.array(Image.open(os.path.join(d, "mask_seam[0].bmp")).convert("L"))
+    m1 = np.array(Image.open(os.path.join(d, "mask_seam[1].bmp")).convert("L"))
+    i0 = np.array(Image.open(os.path.join(d, "images_warped_f[0].bmp")).convert("RGB"))[:, :, ::-1]  # BGR as imread gives
+    i1 = np.array(Image.open(os.path.join(d, "images_warped_f[1].bmp")).convert("RGB"))[:, :, ::-1]
+    print("reference artefact shapes:", m0.shape, m1.shape, i0.shape, i1.shape)
+    # corners are not recorded by the reference; pano.jpg's union 1895 x 1105 implies dx = 799, dy = 3
+    dx, dy = 799, 3
+    # crop a 448 x 320 window of each tile around the seam (panorama x in [760, 1208), y in [400, 720))
+    px0, py0, cw, ch = 760, 400, 448, 320
+    c0 = (slice(py0, py0 + ch), slice(px0, px0 + cw))
+    c1 = (slice(py0 - dy, py0 - dy + ch), slice(max(px0 - dx, 0), px0 - dx + cw))
+    np.savez_compressed(os.path.join(HERE, "ref_inputs.npz"),
+                        img0=np.ascontiguousarray(i0[c0]), img1=np.ascontiguousarray(i1[c1]),
+                        mask0=np.ascontiguousarray(m0[c0]), mask1=np.ascontiguousarray(m1[c1]),
+                        corner0=np.array([px0, py0]), corner1=np.array([max(px0, dx), py0]),
+                        full_shapes=np.array([m0.shape, m1.shape]))
+    print("ref_inputs.npz: crops", i0[c0].shape, i1[c1].shape)
+
+
+def oracle_regress():
+    rng = np.random.default_rng(7)
+    out = {}
+    src = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    xm = (rng.random((33, 47)) * 70 - 7).astype(np.float32)
+    ym = (rng.random((33, 47)) * 52 - 6).astype(np.float32)
+    out.update(remap_src=src, remap_x=xm, remap_y=ym)
+    for interp, border in ((1, 2), (0, 0), (1, 0), (1, 4)):
+        out["remap_%d_%d" % (interp, border)] = O.remap(src, xm, ym, interp, border)
+    a = rng.integers(-4000, 4000, (22, 30, 3)).astype(np.int16)
+    f = (rng.standard_normal((22, 30, 3)) * 90).astype(np.float32)
+    out.update(pyr_s16=a, pyr_f32=f, down_s16=O.pyr_down(a), up_s16=O.pyr_up(a), down_f32=O.pyr_down(f), up_f32=O.pyr_up(f))
+    corners, sizes = [(-5, 3), (40, -2)], [(70, 50), (64, 57)]
+    tiles = [(rng.integers(0, 256, (s[1], s[0], 3)).astype(np.int16), (rng.random((s[1], s[0])) > 0.3).astype(np.uint8) * 255) for s in sizes]
+    out.update(mb_corners=np.array(corners), mb_sizes=np.array(sizes), mb_img0=tiles[0][0], mb_mask0=tiles[0][1], mb_img1=tiles[1][0], mb_mask1=tiles[1][1])
+    for prec in (0, 1, 2):
+        mb = O.MultiBand(4, prec)
+        mb.prepare(corners, sizes)
+        for (img, mask), c in zip(tiles, corners):
+            mb.feed(img, mask, c)
+        d, m = mb.blend(prec != 0)
+        out["mb_dst%d" % prec] = d
+        out["mb_omask%d" % prec] = m
+    i1 = (rng.random((60, 90, 3)) * 255).astype(np.float32)
+    i2 = (rng.random((63, 80, 3)) * 255).astype(np.float32)
+    i1[:8, -12:] = 2.0
+    i2[-9:, :10] = 1.0
+    rc, pano, seam = O.blend_pair_linear(i1, i2, (5, 9), (5 + 50, 9 + 2))
+    assert rc == 0
+    out.update(lin_img1=i1, lin_img2=i2, lin_pano=pano, lin_seam=seam)
+    np.savez_compressed(os.path.join(HERE, "oracle_regress.npz"), **out)
+    print("oracle_regress.npz written")
+
+
+if __name__ == "__main__":
+    cyl_maps()
+    if os.path.isdir(REF):
+        ref_inputs()
+    oracle_regress()

@@ -161,3 +161,72 @@ def test_linear_pair_blend(gpu, oracle, dy):
                                          seam.ctypes.data_as(_lib._IP), 0, None))
     assert np.array_equal(seam, oseam)
     assert np.array_equal(pano, opano, equal_nan=True), np.argwhere(pano != opano)[:5]
+
+
+def test_blend_on_reference_artefact_crops(gpu, oracle):
+    """Inputs: crops of the reference's committed images_warped_f[*].bmp and its real DP-seam masks
+    mask_seam[*].bmp (S:1195-1198); blender configured as the reference does (setNumBands(4), W:273)."""
+    import os
+    D = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_inputs.npz"))
+    imgs = [D["img0"].astype(np.int16), D["img1"].astype(np.int16)]       # convertTo(CV_16S), W:294
+    masks = [D["mask0"], D["mask1"]]
+    corners = [tuple(int(v) for v in D["corner0"]), tuple(int(v) for v in D["corner1"])]
+    sizes = [(m.shape[1], m.shape[0]) for m in masks]
+    for prec in (I16, F32):
+        mb = gpu.MultiBandBlender(False, 5, prec)
+        mb.setNumBands(4)
+        ob = oracle.MultiBand(4, prec)
+        mb.prepare(corners, sizes)
+        ob.prepare(corners, sizes)
+        for i in range(2):
+            mb.feed(imgs[i], masks[i], corners[i])
+            ob.feed(imgs[i], masks[i], corners[i])
+        d, m = mb.blend()
+        od, om = ob.blend(False)
+        assert np.array_equal(m, om) and np.array_equal(d, od)
+        assert m.max() == 255 and 0 < (m == 255).mean() <= 1.0
+
+
+def test_full_size_4k_pair(gpu, oracle):
+    """BASELINE config 2 at full size: 2 x 3840x2160, cylindrical f=3000, 5 bands.
+    Warp: bit-exact vs the oracle.  Blend: bit-exact vs the oracle in I16 (OpenCV's arithmetic) and F32,
+    plus size-independent properties (mask = union of the fed masks, zero outside, tile returned when
+    both inputs are the same image)."""
+    import torch
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F = 3840, 2160, 3000.0
+    K, Rs = synth.camera_pair(W, H, F)
+    imgs = [synth.make_tile(H, W, i) for i in range(2)]
+    dev = torch.device("cuda:0")
+    for prec in (gpu.PREC_I16, gpu.PREC_F32):
+        ps = PairStitcher([torch.from_numpy(i).to(dev) for i in imgs], K, Rs, F, "cylindrical", 5, prec, 0, None, "int16")
+        out, omask = ps.step()
+        out, omask = out.cpu().numpy(), omask.cpu().numpy()
+        if prec == gpu.PREC_I16:
+            o_warp = []
+            for i in range(2):
+                c, wi, _ = oracle.warp_u8(oracle.CYL, F, K, Rs[i], imgs[i], 1, 2)
+                _, wm, _ = oracle.warp_u8(oracle.CYL, F, K, Rs[i], np.full((H, W), 255, np.uint8), 0, 0)
+                assert c == ps.corners[i]
+                assert np.array_equal(ps.warped[i].cpu().numpy(), wi), "4K warp differs"
+                assert np.array_equal(ps.wmasks[i].cpu().numpy(), wm), "4K warped mask differs"
+                o_warp.append(wi)
+        seam = [s.cpu().numpy() for s in ps.seam]
+        ob = oracle.MultiBand(5, prec)
+        ob.prepare(ps.corners, ps.sizes)
+        for i in range(2):
+            ob.feed(o_warp[i].astype(np.int16), seam[i], ps.corners[i])
+        od, om = ob.blend(False)
+        assert np.array_equal(omask, om)
+        assert np.array_equal(out, od), "4K blend differs (precision %d)" % prec
+        # properties
+        union = np.zeros_like(omask)
+        x0 = min(c[0] for c in ps.corners); y0 = min(c[1] for c in ps.corners)
+        for i in range(2):
+            cx, cy = ps.corners[i][0] - x0, ps.corners[i][1] - y0
+            h, w = seam[i].shape
+            union[cy:cy + h, cx:cx + w] |= seam[i]
+        assert np.array_equal(omask, union)
+        assert np.all(out[omask == 0] == 0)
+        del ps
+    torch.cuda.empty_cache()

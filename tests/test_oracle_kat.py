@@ -1,0 +1,166 @@
+"""Known-answer and property tests of the oracle + bit-exact agreement of the two
+independent restatements (oracle/oracle.c vs oracle/oracle_np.py)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as N
+
+
+def test_scalar_conversions(oracle):
+    L = oracle.lib()
+    assert [L.orc_cvround(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999)] == [0, 2, 2, 0, -2, 2]   # round-half-even
+    assert L.orc_cvround(float("nan")) == -2 ** 31 and L.orc_cvround(3e9) == -2 ** 31 and L.orc_cvround(-3e9) == -2 ** 31
+    assert [L.orc_f2i_trunc(v) for v in (-543.0966, 542.99, -0.9)] == [-543, 542, 0]                 # W:83-86
+    for p, n, exp101, exp in ((-1, 5, 1, 0), (-2, 5, 2, 1), (5, 5, 3, 4), (6, 5, 2, 3), (-7, 3, 1, 0)):
+        assert L.orc_border_interpolate(p, n, 4) == exp101 and L.orc_border_interpolate(p, n, 2) == exp
+    assert L.orc_border_interpolate(-3, 1, 2) == 0 and L.orc_border_interpolate(9, 7, 0) == -1
+    # f16 rounding incl. ties, subnormals, overflow
+    vals = np.array([1.0, 1.00048828125, 1.0009765625 + 2 ** -12, 65519.9, 65520.0, 6e-8, 2.98e-8, 3e-8, -2049.0, 0.1], np.float32)
+    assert np.array_equal(oracle.f16_round(vals), vals.astype(np.float16).astype(np.float32))
+    # weight of a set mask pixel is exactly 1.0f: 255 * (float)(1/255.)
+    assert np.float32(255) * np.float32(1. / 255.) == np.float32(1.0)
+
+
+def test_remap_known_answers(oracle):
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:9, 0:11].astype(np.float32)
+    assert np.array_equal(oracle.remap(src, xx, yy, 1, 2), src)                      # identity
+    sh = oracle.remap(src, xx - 2, yy + 1, 1, 2)                                      # integer shift + BORDER_REFLECT
+    assert np.array_equal(sh[0, 2:], src[1, :9]) and np.array_equal(sh[:, 1], oracle.remap(src, xx - 2, yy + 1, 0, 2)[:, 1])
+    assert np.array_equal(sh[0, 1], src[1, 0]) and np.array_equal(sh[0, 0], src[1, 1])   # fedcba|abc: -1 -> 0, -2 -> 1
+    assert np.array_equal(sh[8, 5], src[8, 3])                                        # row 9 reflects to row 8
+    half = oracle.remap(src, xx + 0.5, yy, 1, 2)                                      # half pixel: (a*16384 + b*16384 + 16384) >> 15
+    a, b = src[:, :-1].astype(int), src[:, 1:].astype(int)
+    assert np.array_equal(half[:, :-1], ((a * 16384 + b * 16384 + 16384) >> 15).astype(np.uint8))
+    # (-1,-1) sentinel of mapBackward (W:61) with BORDER_REFLECT samples pixel (0,0): no black fill
+    m1 = np.full((2, 2), -1, np.float32)
+    assert np.array_equal(oracle.remap(src, m1, m1, 1, 2)[0, 0], src[0, 0])
+    # masks: NEAREST + CONSTANT of an all-255 mask is {0,255} only, 0 outside
+    mask = np.full((9, 11), 255, np.uint8)
+    out = oracle.remap(mask, xx * 1.7 - 3, yy * 1.7 - 3, 0, 0)
+    assert set(np.unique(out)) == {0, 255} and out[0, 0] == 0
+    # rounding of .5 in NEAREST is half-even: x = 0.5 -> 0, 1.5 -> 2
+    line = np.arange(11, dtype=np.uint8)[None, :].repeat(3, 0)
+    near = oracle.remap(line, np.array([[0.5, 1.5, 2.5]], np.float32), np.zeros((1, 3), np.float32), 0, 0)
+    assert near.tolist() == [[0, 2, 2]]
+
+
+def test_pyramid_known_answers(oracle):
+    const = np.full((16, 24, 3), 1234, np.int16)
+    assert np.all(oracle.pyr_down(const) == 1234) and np.all(oracle.pyr_up(const) == 1234)    # weights sum to 256 / 64
+    cf = np.full((8, 8), 0.3, np.float32)
+    assert np.allclose(oracle.pyr_down(cf), 0.3, atol=1e-6) and np.allclose(oracle.pyr_up(cf), 0.3, atol=1e-6)
+    imp = np.zeros((17, 17), np.float32)
+    imp[8, 8] = 256.0
+    # impulse response of [1 4 6 4 1]^2 / 256 seen through the stride-2 decimation: taps 1 6 1 around the centre
+    assert np.array_equal(oracle.pyr_down(imp)[3:6, 3:6], np.outer([1, 6, 1], [1, 6, 1]).astype(np.float32))
+    assert oracle.pyr_down(imp).sum() == 64.0
+    upi = oracle.pyr_up(np.pad(np.array([[64.0]], np.float32), 2))     # pyrUp impulse: [1 4 6 4 1]^2 / 64
+    assert np.array_equal(upi[2:7, 2:7], np.outer([1, 4, 6, 4, 1], [1, 4, 6, 4, 1]).astype(np.float32))
+    row = np.array([[10, 20, 40, 80]], np.int16)                                      # REFLECT_101 at both edges
+    d = oracle.pyr_down(row)
+    # horizontal taps of x=0: 6*10 + 4*(20+20) + 40 + 40 = 300 ; vertical (1 row): 16 * 300 -> (4800+128)>>8 = 19
+    assert d[0, 0] == (16 * 300 + 128) >> 8
+    u = oracle.pyr_up(np.array([[64, 128]], np.int16))                                # pyrUp edge formulas
+    # row pass: [6*64+2*128, 4*(64+128), 64+7*128, 8*128] = [640, 768, 960, 1024]; 1 source row -> rows x8
+    assert u[0].tolist() == [(8 * v + 32) >> 6 for v in (640, 768, 960, 1024)]
+    one = oracle.pyr_up(np.array([[5]], np.int16))
+    assert one.tolist() == [[5, 5], [5, 5]]                                           # n == 1: s*8 both ways
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 3), (17, 23, 3), (8, 6), (2, 2, 3), (1, 5, 3), (4, 1, 3), (33, 64, 1)])
+def test_c_and_numpy_pyramids_agree(oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    a = rng.integers(-32768, 32768, shape).astype(np.int16)
+    f = (rng.standard_normal(shape) * 100).astype(np.float32)
+    for arr in (a, f):
+        assert np.array_equal(oracle.pyr_down(arr), N.pyr_down(arr))
+        assert np.array_equal(oracle.pyr_up(arr), N.pyr_up(arr))
+
+
+def test_c_and_numpy_remap_agree(oracle):
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    xm = (rng.random((40, 60)) * 70 - 8).astype(np.float32)
+    ym = (rng.random((40, 60)) * 50 - 6).astype(np.float32)
+    xm[0, 0] = ym[0, 0] = -1
+    xm[1, 1] = np.nan
+    xm[2, 2] = 1e12
+    ym[3, 3] = -1e12
+    xm[4, 4], ym[4, 4] = 52.5, 36.5
+    for interp in (0, 1):
+        for border in (0, 1, 2, 4):
+            for s in (src, src[:, :, 0].copy(), src.astype(np.float32)):
+                assert np.array_equal(oracle.remap(s, xm, ym, interp, border), N.remap(s, xm, ym, interp, border), equal_nan=True)
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("bands", [0, 1, 3, 5])
+def test_c_and_numpy_multiband_agree(oracle, prec, bands):
+    rng = np.random.default_rng(10 * prec + bands)
+    corners, sizes = [(-5, 3), (40, -2), (20, 30)], [(70, 50), (64, 57), (33, 41)]
+    mo, mn = oracle.MultiBand(bands, prec), N.MultiBand(bands, prec)
+    mo.prepare(corners, sizes)
+    mn.prepare(corners, sizes)
+    assert mo.num_bands == mn.L
+    for c, s in zip(corners, sizes):
+        img = rng.integers(-300, 600, (s[1], s[0], 3)).astype(np.int16)
+        mask = (rng.random((s[1], s[0])) > 0.3).astype(np.uint8) * 255
+        mo.feed(img, mask, c)
+        mn.feed(img, mask, c)
+    for i in range(mo.num_bands + 1):
+        lap, w = mo.level(i)
+        assert np.array_equal(lap, mn.lap[i]) and np.array_equal(w, mn.wgt[i])
+    d, m = mo.blend(prec != 0)
+    d2, m2 = mn.blend(prec != 0)
+    assert np.array_equal(d, d2) and np.array_equal(m, m2)
+
+
+def test_multiband_properties(oracle):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (96, 128, 3)).astype(np.int16)
+    full = np.full((96, 128), 255, np.uint8)
+    # single image, full mask: F32 returns the image to a few ulp; I16 within the documented -1 truncation bias
+    mb = oracle.MultiBand(4, oracle.F32)
+    mb.prepare([(0, 0)], [(128, 96)])
+    mb.feed(img, full, (0, 0))
+    d, m = mb.blend(True)
+    assert np.all(m == 255) and np.abs(d - img).max() < 1e-2
+    mb = oracle.MultiBand(4, oracle.I16)
+    mb.prepare([(0, 0)], [(128, 96)])
+    mb.feed(img, full, (0, 0))
+    d, m = mb.blend(False)
+    assert np.abs(d.astype(int) - img).max() <= 8 and (d.astype(int) - img).mean() < 0      # biased low: 100/(1+1e-5) -> 99
+    assert oracle.lib().orc_f2i_trunc(np.float32(100) / (np.float32(1) + np.float32(1e-5))) == 99
+    # identical images, complementary masks -> the image again (F32)
+    left = full.copy(); left[:, 64:] = 0
+    right = full.copy(); right[:, :64] = 0
+    mb = oracle.MultiBand(3, oracle.F32)
+    mb.prepare([(0, 0), (0, 0)], [(128, 96), (128, 96)])
+    mb.feed(img, left, (0, 0)); mb.feed(img, right, (0, 0))
+    d, m = mb.blend(True)
+    assert np.all(m == 255) and np.abs(d - img).max() < 1e-2
+    # dst_mask is 255 exactly where a fed mask is set; padded sizes are multiples of 2^L; bands clamp
+    mb = oracle.MultiBand(5, oracle.I16)
+    mb.prepare([(3, 7)], [(100, 60)])
+    hole = full[:60, :100].copy(); hole[10:20, 30:50] = 0
+    mb.feed(img[:60, :100], hole, (3, 7))
+    lap0, w0 = mb.level(0)
+    assert lap0.shape[0] % 32 == 0 and lap0.shape[1] % 32 == 0 and lap0.shape[:2] == (64, 128)
+    d, m = mb.blend(False)
+    assert np.array_equal(m, hole) and np.all(d[m == 0] == 0)
+    mb = oracle.MultiBand(9, oracle.I16)
+    mb.prepare([(0, 0)], [(20, 9)])
+    assert mb.num_bands == 5                                                           # ceil(log2(20)) = 5
+
+
+def test_linear_blend_properties(oracle):
+    """A13: equal constant images -> identity in the overlap; m1 + m2 = 1 wherever both are valid."""
+    a = np.full((50, 80, 3), 100.0, np.float32)
+    b = np.full((50, 70, 3), 100.0, np.float32)
+    rc, pano, seam = oracle.blend_pair_linear(a, b, (0, 0), (45, 0))
+    assert rc == 0 and pano.shape == (50, 115, 3)
+    assert np.allclose(pano, 100.0, atol=1e-3)
+    rc, _, _ = oracle.blend_pair_linear(a, b, (0, 0), (200, 0))
+    assert rc == 1                                                                     # no overlap: B:182-183
