@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--focal", type=float, default=3000.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-roi", action="store_true", help="return every warp's corner to the host (one stream sync per tile) instead of the planned, device-checked ROI")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +114,7 @@ def main():
 
     def step():
         for p in pairs:
-            p.step()
+            p.step_sync() if args.sync_roi else p.step()
         if world > 1:
             off = 0
             for p in pairs:
@@ -146,6 +147,8 @@ def main():
     dt = time.perf_counter() - t0
     ent = _lib.profile_entries()
     lib.isx_profile_enable(0)
+    for p in pairs:
+        p.check_plan()   # raises if any planned step saw a ROI that differs from the plan
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -64,6 +64,25 @@ struct Src0 {
     int height, width;  // padded size = level-0 size of the tile pyramid
 };
 
+// Rectangles of one destination level that earlier feeds have already written.  prepare() does not
+// clear the destination pyramid (a 260 MB memset per 4K pair): a pixel outside every rectangle is
+// DEFINED to be zero — the first feed that touches it stores instead of accumulating, and blend()
+// reads zero for pixels no tile ever covered.  n < 0: the level has been cleared, always load.
+constexpr int MAX_COVER = 8;
+struct Cover {
+    int n;
+    int x[MAX_COVER], y[MAX_COVER], w[MAX_COVER], h[MAX_COVER];
+};
+// (x, y) are level-k coordinates; the rectangles are stored at level 0 when k > 0 is passed
+__device__ __forceinline__ bool covered(const Cover& c, int x, int y, int k = 0) {
+    if (c.n < 0) return true;
+    bool in = false;
+#pragma unroll
+    for (int i = 0; i < MAX_COVER; ++i)   // static indices: the struct stays in the kernel-argument segment
+        if (i < c.n) in = in || ((unsigned)(x - (c.x[i] >> k)) < (unsigned)(c.w[i] >> k) && (unsigned)(y - (c.y[i] >> k)) < (unsigned)(c.h[i] >> k));
+    return in;
+}
+
 template <int M, bool DST>
 __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
     size_t i = (size_t)y * L.cols + x;
@@ -146,48 +165,59 @@ template <class T>
 __device__ __forceinline__ T tap5(T c, T l1, T r1, T l2, T r2) { return c * 6 + (l1 + r1) * 4 + l2 + r2; }
 
 // ------------------------------------------------------------------------------------------------
-// k_pyr_down: one block = 64 x 16 outputs.  Each wave walks input rows; a lane loads the two
-// input pixels (2x, 2x+1) of its output column, the other three taps come from the neighbour
-// lanes by wavefront shuffle (lanes 0 / 63 fetch their missing neighbours themselves).  The
-// row-filtered tile (35 x 64 records, 2-row halo each side) is staged in LDS, then the column
-// filter runs out of LDS.
+// k_pyr_down: one block (8 waves) = 62 x 16 outputs.  Lane j of every wave owns output column
+// ox0 - 1 + j and loads the two input pixels (2x, 2x+1) of that column for each of its input rows;
+// the other three taps of the horizontal [1 4 6 4 1] come from the neighbour lanes by wavefront
+// shuffle.  Lanes 0 and 63 are halo lanes (they only feed their neighbours), so the wave needs no
+// divergent edge loads; every column / row index goes through REFLECT_101, which makes the shuffled
+// values correct at the image borders too.  All global loads of a wave are issued before the first
+// use (5 rows x 2 records in flight per lane).  The row-filtered tile (35 x 62 records, 2-row halo
+// above, 1 below... = 2*16+3 rows) is staged in LDS; the column filter runs out of LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int PD_TY = 16;
 constexpr int PD_NR = 2 * PD_TY + 3;
+constexpr int PD_OW = WAVE - 2;
+constexpr int PD_WAVES = 8;
+constexpr int PD_RPW = (PD_NR + PD_WAVES - 1) / PD_WAVES;
 
 template <int M, int SK>
-__global__ __launch_bounds__(256) void k_pyr_down(Src0 s0, LevelBuf src, LevelBuf dst) {
+__global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBuf dst) {
     using WT = typename WorkT<M>::t;
     __shared__ Px<M> hb[PD_NR][WAVE];
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
     const int sh = (SK == SK_LEVEL) ? src.rows : s0.height;
     const int dw = dst.cols, dh = dst.rows;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ox = blockIdx.x * WAVE + lane, oy0 = blockIdx.y * PD_TY;
-    const int oxc = min(ox, dw - 1);
-    const int cA = reflect101(2 * oxc, sw), cB = reflect101(2 * oxc + 1, sw);
-    const int cL2 = reflect101(2 * oxc - 2, sw), cL1 = reflect101(2 * oxc - 1, sw), cR = reflect101(2 * oxc + 2, sw);
-    for (int r = wv; r < PD_NR; r += 4) {
-        int iy = reflect101(2 * oy0 - 2 + r, sh);
-        Px<M> A = load_any<M, SK>(s0, src, cA, iy);
-        Px<M> B = load_any<M, SK>(s0, src, cB, iy);
-        Px<M> Am = shfl_up1<M>(A), Bm = shfl_up1<M>(B), Ap = shfl_down1<M>(A);
-        // a lane whose left/right neighbour is not the adjacent output column reloads those taps
-        // (lane 0, lane 63, and the clamped lanes past the right image edge)
-        if (lane == 0) { Am = load_any<M, SK>(s0, src, cL2, iy); Bm = load_any<M, SK>(s0, src, cL1, iy); }
-        if (lane == 63 || ox >= dw - 1) Ap = load_any<M, SK>(s0, src, cR, iy);
-        Px<M> h;
-        h.c0 = tap5<WT>(A.c0, Bm.c0, B.c0, Am.c0, Ap.c0);
-        h.c1 = tap5<WT>(A.c1, Bm.c1, B.c1, Am.c1, Ap.c1);
-        h.c2 = tap5<WT>(A.c2, Bm.c2, B.c2, Am.c2, Ap.c2);
-        h.w = tap5<float>(A.w, Bm.w, B.w, Am.w, Ap.w);
-        hb[r][lane] = h;
+    const int ox = blockIdx.x * PD_OW + lane - 1, oy0 = blockIdx.y * PD_TY;
+    const int cA = reflect101(2 * ox, sw), cB = reflect101(2 * ox + 1, sw);
+    Px<M> A[PD_RPW], B[PD_RPW];
+#pragma unroll
+    for (int i = 0; i < PD_RPW; ++i) {
+        int r = wv + PD_WAVES * i;
+        if (r < PD_NR) {
+            int iy = reflect101(2 * oy0 - 2 + r, sh);
+            A[i] = load_any<M, SK>(s0, src, cA, iy);
+            B[i] = load_any<M, SK>(s0, src, cB, iy);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PD_RPW; ++i) {
+        int r = wv + PD_WAVES * i;
+        if (r < PD_NR) {
+            Px<M> Am = shfl_up1<M>(A[i]), Bm = shfl_up1<M>(B[i]), Ap = shfl_down1<M>(A[i]);
+            Px<M> h;
+            h.c0 = tap5<WT>(A[i].c0, Bm.c0, B[i].c0, Am.c0, Ap.c0);
+            h.c1 = tap5<WT>(A[i].c1, Bm.c1, B[i].c1, Am.c1, Ap.c1);
+            h.c2 = tap5<WT>(A[i].c2, Bm.c2, B[i].c2, Am.c2, Ap.c2);
+            h.w = tap5<float>(A[i].w, Bm.w, B[i].w, Am.w, Ap.w);
+            hb[r][lane] = h;
+        }
     }
     __syncthreads();
-    if (ox >= dw) return;
+    if (lane == 0 || lane == 63 || ox >= dw) return;
 #pragma unroll
-    for (int i = 0; i < PD_TY / 4; ++i) {
-        int ty = wv + 4 * i, oy = oy0 + ty;
+    for (int i = 0; i < PD_TY / PD_WAVES; ++i) {
+        int ty = wv + PD_WAVES * i, oy = oy0 + ty;
         if (oy >= dh) break;
         Px<M> r0 = hb[2 * ty][lane], r1 = hb[2 * ty + 1][lane], r2 = hb[2 * ty + 2][lane], r3 = hb[2 * ty + 3][lane], r4 = hb[2 * ty + 4][lane];
         Px<M> o;
@@ -219,13 +249,25 @@ __device__ __forceinline__ int up_row_map(int y, int h) {
     return reflect101(2 * y, 2 * h) / 2;
 }
 
-template <int M, bool DST>
-__device__ __forceinline__ void stage_coarse(Px<M> (*ct)[WAVE + 2], const LevelBuf& coarse, int cx0, int cy0) {
+template <int M> __device__ __forceinline__ void normalise(Px<M>& d);
+
+// NORMC: the coarse level is the (not yet normalised) top level of the destination pyramid: apply
+// normalizeUsingWeightMap while staging (uncovered pixels are zero by definition, see Cover)
+template <int M, bool DST, bool NORMC = false>
+__device__ __forceinline__ void stage_coarse(Px<M> (*ct)[WAVE + 2], const LevelBuf& coarse, int cx0, int cy0, const Cover* ccov = nullptr) {
     for (int i = threadIdx.x; i < (UP_TY + 2) * (WAVE + 2); i += 256) {
         int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
         int gy = up_row_map<M>(cy0 - 1 + ry, coarse.rows);
         int gx = min(max(cx0 - 1 + rx, 0), coarse.cols - 1);
-        ct[ry][rx] = load_px<M, DST>(coarse, gx, gy);
+        if constexpr (NORMC) {
+            Px<M> d;
+            if (covered(*ccov, gx, gy)) d = load_px<M, DST>(coarse, gx, gy);
+            else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
+            normalise<M>(d);
+            ct[ry][rx] = d;
+        } else {
+            ct[ry][rx] = load_px<M, DST>(coarse, gx, gy);
+        }
     }
 }
 
@@ -264,8 +306,10 @@ __device__ __forceinline__ Up4<M> pyr_up_2x2(Px<M> (*ct)[WAVE + 2], int lane, in
 // dst += cast(lap * w), dstW += w   (MultiBandBlender::feed accumulate loop)
 template <int M>
 __device__ __forceinline__ void accumulate(const LevelBuf& dst, int x, int y, typename WorkT<M>::t l0,
-                                           typename WorkT<M>::t l1, typename WorkT<M>::t l2, float w) {
-    Px<M> d = load_px<M, true>(dst, x, y);
+                                           typename WorkT<M>::t l1, typename WorkT<M>::t l2, float w, bool have) {
+    Px<M> d;
+    if (have) d = load_px<M, true>(dst, x, y);
+    else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
     if constexpr (M == M_I16) {
         d.c0 = wrap_s16(d.c0 + f2s_x86((float)l0 * w));
         d.c1 = wrap_s16(d.c1 + f2s_x86((float)l1 * w));
@@ -278,15 +322,17 @@ __device__ __forceinline__ void accumulate(const LevelBuf& dst, int x, int y, ty
 }
 
 template <int M, int SK>
-__global__ __launch_bounds__(256) void k_lap_acc(Src0 s0, LevelBuf fine, LevelBuf coarse, LevelBuf dst, int x_tl, int y_tl) {
-    __shared__ Px<M> ct[UP_TY + 2][WAVE + 2];
+__device__ __forceinline__ void lap_acc_block(Px<M> (*ct)[WAVE + 2], const Src0& s0, const LevelBuf& fine, const LevelBuf& coarse,
+                                              const LevelBuf& dst, int x_tl, int y_tl, const Cover& cov, int bx, int by, int ck = 0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
+    const int cx0 = bx * WAVE, cy0 = by * UP_TY;
     stage_coarse<M, false>(ct, coarse, cx0, cy0);
     __syncthreads();
     const int cx = cx0 + lane, cy = cy0 + wv;
     if (cx >= coarse.cols || cy >= coarse.rows) return;
     Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse.cols);
+    // rectangle corners are even at every level below the top, so the 2x2 block is covered as a whole
+    const bool have = covered(cov, x_tl + 2 * cx, y_tl + 2 * cy, ck);
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -299,17 +345,60 @@ __global__ __launch_bounds__(256) void k_lap_acc(Src0 s0, LevelBuf fine, LevelBu
             } else {
                 l0 = g.c0 - u.v[dy][dx][0]; l1 = g.c1 - u.v[dy][dx][1]; l2 = g.c2 - u.v[dy][dx][2];
             }
-            accumulate<M>(dst, x_tl + fx, y_tl + fy, l0, l1, l2, g.w);
+            accumulate<M>(dst, x_tl + fx, y_tl + fy, l0, l1, l2, g.w, have);
         }
+}
+
+template <int M, int SK>
+__global__ __launch_bounds__(256) void k_lap_acc(Src0 s0, LevelBuf fine, LevelBuf coarse, LevelBuf dst, int x_tl, int y_tl, Cover cov) {
+    __shared__ Px<M> ct[UP_TY + 2][WAVE + 2];
+    lap_acc_block<M, SK>(ct, s0, fine, coarse, dst, x_tl, y_tl, cov, blockIdx.x, blockIdx.y);
+}
+
+// All levels of one feed in ONE launch: the per-level accumulations are independent of each other
+// once the Gaussian chain exists, so a 1-D grid is cut into per-level block ranges (level 0 first,
+// the small levels fill the tail of the launch instead of paying a kernel boundary each).
+constexpr int ACC_MAXL = 8;
+struct AccArgs {
+    Src0 s0;
+    LevelBuf g[ACC_MAXL + 1];
+    LevelBuf dst[ACC_MAXL + 1];
+    int blk_start[ACC_MAXL + 2];   // first block of level k; [L + 1] = grid size
+    int gw[ACC_MAXL + 1];          // blocks per row of level k
+    int L, x_tl, y_tl;
+    Cover cov0;                    // level-0 rectangles of the earlier feeds
+};
+
+template <int M, int SK>
+__global__ __launch_bounds__(256) void k_lap_acc_all(AccArgs a) {
+    __shared__ Px<M> ct[UP_TY + 2][WAVE + 2];
+    const int bid = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i <= ACC_MAXL; ++i) k += (i <= a.L && bid >= a.blk_start[i]) ? 1 : 0;
+    const int local = bid - a.blk_start[k];
+    const int by = local / a.gw[k], bx = local - by * a.gw[k];
+    const int xt = a.x_tl >> k, yt = a.y_tl >> k;
+    if (k == a.L) {   // top level: Laplacian == Gaussian
+        const int x = bx * 64 + (threadIdx.x & 63), y = by * 4 + (threadIdx.x >> 6);
+        if (x >= a.g[k].cols || y >= a.g[k].rows) return;
+        Px<M> g;
+        if (k == 0) g = load_any<M, SK>(a.s0, a.g[0], x, y); else g = load_px<M, false>(a.g[k], x, y);
+        accumulate<M>(a.dst[k], xt + x, yt + y, g.c0, g.c1, g.c2, g.w, covered(a.cov0, xt + x, yt + y, k));
+    } else if (k == 0) {
+        lap_acc_block<M, SK>(ct, a.s0, a.g[0], a.g[1], a.dst[0], xt, yt, a.cov0, bx, by, 0);
+    } else {
+        lap_acc_block<M, SK_LEVEL>(ct, a.s0, a.g[k], a.g[k + 1], a.dst[k], xt, yt, a.cov0, bx, by, k);
+    }
 }
 
 // top level: the Laplacian pyramid's last level is the Gaussian level itself
 template <int M, int SK>
-__global__ __launch_bounds__(256) void k_top_acc(Src0 s0, LevelBuf top, LevelBuf dst, int x_tl, int y_tl, int rows, int cols) {
+__global__ __launch_bounds__(256) void k_top_acc(Src0 s0, LevelBuf top, LevelBuf dst, int x_tl, int y_tl, int rows, int cols, Cover cov) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     Px<M> g = load_any<M, SK>(s0, top, x, y);
-    accumulate<M>(dst, x_tl + x, y_tl + y, g.c0, g.c1, g.c2, g.w);
+    accumulate<M>(dst, x_tl + x, y_tl + y, g.c0, g.c1, g.c2, g.w, covered(cov, x_tl + x, y_tl + y));
 }
 
 // normalizeUsingWeightMap for one pixel
@@ -351,33 +440,38 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
 
 // top level of blend(): normalise in place (or straight to the caller's mat when num_bands == 0)
 template <int M, bool FINAL>
-__global__ __launch_bounds__(256) void k_norm_top(LevelBuf lv, OutMat out) {
+__global__ __launch_bounds__(256) void k_norm_top(LevelBuf lv, OutMat out, Cover cov) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= lv.cols || y >= lv.rows) return;
-    Px<M> d = load_px<M, true>(lv, x, y);
+    Px<M> d;
+    if (covered(cov, x, y)) d = load_px<M, true>(lv, x, y);
+    else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
     normalise<M>(d);
     if constexpr (FINAL) write_final<M>(out, x, y, d);
     else store_px<M, true>(lv, x, y, d);
 }
 
 // out_{k-1} = sat(pyrUp(out_k) + normalise(dst_{k-1}))   (restoreImageFromLaplacePyr, fused normalise)
-template <int M, bool FINAL>
-__global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine, OutMat out) {
+template <int M, bool FINAL, bool NORMC>
+__global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine, OutMat out, Cover cov, Cover ccov) {
     __shared__ Px<M> ct[UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
-    stage_coarse<M, true>(ct, coarse, cx0, cy0);
+    stage_coarse<M, true, NORMC>(ct, coarse, cx0, cy0, &ccov);
     __syncthreads();
     const int cx = cx0 + lane, cy = cy0 + wv;
     if (cx >= coarse.cols || cy >= coarse.rows) return;
     Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse.cols);
+    const bool have = covered(cov, 2 * cx, 2 * cy);   // fine-level rectangles have even corners
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
             int fx = 2 * cx + dx, fy = 2 * cy + dy;
             if constexpr (FINAL) { if (fx >= out.cols || fy >= out.rows) continue; }
-            Px<M> d = load_px<M, true>(fine, fx, fy);
+            Px<M> d;
+            if (have) d = load_px<M, true>(fine, fx, fy);
+            else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
             normalise<M>(d);
             if constexpr (M == M_I16) {  // cv::add saturates
                 d.c0 = sat_s16(u.v[dy][dx][0] + d.c0); d.c1 = sat_s16(u.v[dy][dx][1] + d.c1); d.c2 = sat_s16(u.v[dy][dx][2] + d.c2);
@@ -389,6 +483,17 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
         }
 }
 
+// zero every pixel of a level that no fed tile covers (only needed when more than MAX_COVER tiles are
+// fed, and by the level-introspection entry point)
+template <int M>
+__global__ __launch_bounds__(256) void k_fill_uncovered(LevelBuf lv, Cover cov) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= lv.cols || y >= lv.rows || covered(cov, x, y)) return;
+    Px<M> z; z.c0 = 0; z.c1 = 0; z.c2 = 0; z.w = 0.f;
+    store_px<M, true>(lv, x, y, z);
+}
+
+// stage_coarse reads coarse pixels through the same definition (uncovered == 0)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -416,6 +521,10 @@ struct isx_blender {
     DevBuf dst_arena, tile_arena;
     MatStage st_img, st_mask, st_out, st_outmask;
     std::vector<unsigned char> host_tmp;
+    // level-0 rectangles (x, y, w, h in dst_roi_ coordinates) written by the feeds so far; `cleared`
+    // means every level has been zero-filled outside them (only when > MAX_COVER tiles are fed)
+    std::vector<int4> fed;
+    bool cleared = false;
 };
 
 namespace {
@@ -439,6 +548,30 @@ int layout_levels(LevelBuf* lv, int L, int rows, int cols, int prec, bool is_dst
     return ISX_OK;
 }
 
+Cover make_cover(const isx_blender* b, int level) {
+    Cover c;
+    memset(&c, 0, sizeof(c));
+    if (b->cleared) { c.n = -1; return c; }
+    c.n = (int)std::min<size_t>(b->fed.size(), MAX_COVER);
+    for (int i = 0; i < c.n; ++i) {
+        c.x[i] = b->fed[i].x >> level; c.y[i] = b->fed[i].y >> level;
+        c.w[i] = b->fed[i].z >> level; c.h[i] = b->fed[i].w >> level;
+    }
+    return c;
+}
+
+int fill_uncovered(isx_blender* b, int level) {
+    const LevelBuf& d = b->dst[level];
+    dim3 grid(cdiv(d.cols, 64), cdiv(d.rows, 4));
+    Cover c = make_cover(b, level);
+    switch (b->prec) {
+        case M_I16: ISX_LAUNCH("fill_uncovered", 0.0, b->stream, (k_fill_uncovered<M_I16>), grid, dim3(256), 0, d, c); break;
+        case M_F32: ISX_LAUNCH("fill_uncovered", 0.0, b->stream, (k_fill_uncovered<M_F32>), grid, dim3(256), 0, d, c); break;
+        default: ISX_LAUNCH("fill_uncovered", 0.0, b->stream, (k_fill_uncovered<M_F16>), grid, dim3(256), 0, d, c); break;
+    }
+    return ISX_OK;
+}
+
 int src_kind_of(int type) { return type == ISX_8UC3 ? SK_U8 : (type == ISX_16SC3 ? SK_S16 : SK_F32); }
 double src_px_bytes(int sk) { return sk == SK_U8 ? 3.0 : (sk == SK_S16 ? 6.0 : 12.0); }
 
@@ -448,28 +581,55 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
     const int prec = M;
     // Gaussian chain (image + weight): G_{k+1} = pyrDown(G_k)
     for (int k = 0; k < L; ++k) {
-        dim3 grid(cdiv(g[k + 1].cols, WAVE), cdiv(g[k + 1].rows, PD_TY));
+        dim3 grid(cdiv(g[k + 1].cols, PD_OW), cdiv(g[k + 1].rows, PD_TY));
         double in_px = (double)g[k].rows * g[k].cols, out_px = (double)g[k + 1].rows * g[k + 1].cols;
         double bytes = in_px * (k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + out_px * alg_g(prec);
-        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down<M, SK>), grid, dim3(256), 0, s0, g[0], g[1]);
-        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[k], g[k + 1]);
+        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down<M, SK>), grid, dim3(512), 0, s0, g[0], g[1]);
+        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down<M, SK_LEVEL>), grid, dim3(512), 0, s0, g[k], g[k + 1]);
     }
-    // Laplacian + weighted accumulate per level
+    // Laplacian + weighted accumulate: every level in one launch
+    if (L <= ACC_MAXL) {
+        AccArgs a;
+        memset(&a, 0, sizeof(a));
+        a.s0 = s0; a.L = L; a.x_tl = x_tl; a.y_tl = y_tl; a.cov0 = make_cover(b, 0);
+        double bytes = 0.0;
+        int nb = 0;
+        for (int k = 0; k <= L; ++k) {
+            a.g[k] = g[k]; a.dst[k] = b->dst[k];
+            a.blk_start[k] = nb;
+            double px = (double)g[k].rows * g[k].cols;
+            double gin = (k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec));
+            if (k < L) {
+                a.gw[k] = cdiv(g[k + 1].cols, WAVE);
+                nb += a.gw[k] * cdiv(g[k + 1].rows, UP_TY);
+                bytes += px * (gin + 2.0 * alg_d(prec)) + (double)g[k + 1].rows * g[k + 1].cols * alg_g_rgb(prec);
+            } else {
+                a.gw[k] = cdiv(g[k].cols, 64);
+                nb += a.gw[k] * cdiv(g[k].rows, 4);
+                bytes += px * (gin + 2.0 * alg_d(prec));
+            }
+        }
+        a.blk_start[L + 1] = nb;
+        ISX_LAUNCH("lap_acc_all", bytes, st, (k_lap_acc_all<M, SK>), dim3(nb), dim3(256), 0, a);
+        return ISX_OK;
+    }
     int xt = x_tl, yt = y_tl;
     for (int k = 0; k < L; ++k) {
         dim3 grid(cdiv(g[k + 1].cols, WAVE), cdiv(g[k + 1].rows, UP_TY));
         double fine_px = (double)g[k].rows * g[k].cols, coarse_px = (double)g[k + 1].rows * g[k + 1].cols;
         double bytes = fine_px * ((k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + 2.0 * alg_d(prec)) + coarse_px * alg_g_rgb(prec);
-        if (k == 0) ISX_LAUNCH("lap_acc_l0", bytes, st, (k_lap_acc<M, SK>), grid, dim3(256), 0, s0, g[0], g[1], b->dst[0], xt, yt);
-        else ISX_LAUNCH("lap_acc", bytes, st, (k_lap_acc<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[k], g[k + 1], b->dst[k], xt, yt);
+        Cover cov = make_cover(b, k);
+        if (k == 0) ISX_LAUNCH("lap_acc_l0", bytes, st, (k_lap_acc<M, SK>), grid, dim3(256), 0, s0, g[0], g[1], b->dst[0], xt, yt, cov);
+        else ISX_LAUNCH("lap_acc", bytes, st, (k_lap_acc<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[k], g[k + 1], b->dst[k], xt, yt, cov);
         xt /= 2; yt /= 2;
     }
     {
         dim3 grid(cdiv(g[L].cols, 64), cdiv(g[L].rows, 4));
         double px = (double)g[L].rows * g[L].cols;
         double bytes = px * ((L == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + 2.0 * alg_d(prec));
-        if (L == 0) ISX_LAUNCH("top_acc", bytes, st, (k_top_acc<M, SK>), grid, dim3(256), 0, s0, g[0], b->dst[0], xt, yt, g[0].rows, g[0].cols);
-        else ISX_LAUNCH("top_acc", bytes, st, (k_top_acc<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[L], b->dst[L], xt, yt, g[L].rows, g[L].cols);
+        Cover cov = make_cover(b, L);
+        if (L == 0) ISX_LAUNCH("top_acc", bytes, st, (k_top_acc<M, SK>), grid, dim3(256), 0, s0, g[0], b->dst[0], xt, yt, g[0].rows, g[0].cols, cov);
+        else ISX_LAUNCH("top_acc", bytes, st, (k_top_acc<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[L], b->dst[L], xt, yt, g[L].rows, g[L].cols, cov);
     }
     return ISX_OK;
 }
@@ -488,21 +648,27 @@ int run_blend(isx_blender* b, const OutMat& out) {
     hipStream_t st = b->stream;
     const int L = b->num_bands, prec = M;
     LevelBuf* d = b->dst;
-    {
-        dim3 grid(cdiv(d[L].cols, 64), cdiv(d[L].rows, 4));
-        double px = (double)d[L].rows * d[L].cols;
-        if (L == 0) ISX_LAUNCH("norm_top_final", px * alg_d(prec) + (double)out.rows * out.cols * (out.img_f32 ? 13.0 : 7.0), st, (k_norm_top<M, true>), grid, dim3(256), 0, d[L], out);
-        else ISX_LAUNCH("norm_top", px * (alg_d(prec) + alg_d_rgb(prec)), st, (k_norm_top<M, false>), grid, dim3(256), 0, d[L], out);
+    if (L == 0) {
+        dim3 grid(cdiv(d[0].cols, 64), cdiv(d[0].rows, 4));
+        double px = (double)d[0].rows * d[0].cols;
+        ISX_LAUNCH("norm_top_final", px * alg_d(prec) + (double)out.rows * out.cols * (out.img_f32 ? 13.0 : 7.0), st, (k_norm_top<M, true>), grid, dim3(256), 0, d[0], out, make_cover(b, 0));
+        return ISX_OK;
     }
+    // the top level is normalised while it is staged as the coarse tile of the first collapse step
     for (int k = L; k >= 1; --k) {
         dim3 grid(cdiv(d[k].cols, WAVE), cdiv(d[k].rows, UP_TY));
         double coarse_px = (double)d[k].rows * d[k].cols, fine_px = (double)d[k - 1].rows * d[k - 1].cols;
+        double cb = coarse_px * (k == L ? alg_d(prec) : alg_d_rgb(prec));
+        Cover cov = make_cover(b, k - 1), ccov = make_cover(b, k);
+        const bool normc = k == L;
         if (k == 1) {
-            double bytes = coarse_px * alg_d_rgb(prec) + (double)out.rows * out.cols * (alg_d(prec) + (out.img_f32 ? 13.0 : 7.0));
-            ISX_LAUNCH("collapse_final", bytes, st, (k_collapse<M, true>), grid, dim3(256), 0, d[1], d[0], out);
+            double bytes = cb + (double)out.rows * out.cols * (alg_d(prec) + (out.img_f32 ? 13.0 : 7.0));
+            if (normc) ISX_LAUNCH("collapse_final", bytes, st, (k_collapse<M, true, true>), grid, dim3(256), 0, d[1], d[0], out, cov, ccov);
+            else ISX_LAUNCH("collapse_final", bytes, st, (k_collapse<M, true, false>), grid, dim3(256), 0, d[1], d[0], out, cov, ccov);
         } else {
-            double bytes = coarse_px * alg_d_rgb(prec) + fine_px * (alg_d(prec) + alg_d_rgb(prec));
-            ISX_LAUNCH("collapse", bytes, st, (k_collapse<M, false>), grid, dim3(256), 0, d[k], d[k - 1], out);
+            double bytes = cb + fine_px * (alg_d(prec) + alg_d_rgb(prec));
+            if (normc) ISX_LAUNCH("collapse", bytes, st, (k_collapse<M, false, true>), grid, dim3(256), 0, d[k], d[k - 1], out, cov, ccov);
+            else ISX_LAUNCH("collapse", bytes, st, (k_collapse<M, false, false>), grid, dim3(256), 0, d[k], d[k - 1], out, cov, ccov);
         }
     }
     return ISX_OK;
@@ -524,7 +690,9 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     layout_levels(b->dst, L, height, width, b->prec, true, nullptr, &total);
     ISX_TRY(b->dst_arena.reserve(total));
     layout_levels(b->dst, L, height, width, b->prec, true, (char*)b->dst_arena.p, &total);
-    ISX_HIP(hipMemsetAsync(b->dst_arena.p, 0, total, b->stream));   // dst_.setTo(0), weights setTo(0)
+    // dst_.setTo(0) / weights setTo(0) are not executed: uncovered pixels are defined as zero (Cover)
+    b->fed.clear();
+    b->cleared = false;
     b->prepared = true;
     return ISX_OK;
 }
@@ -589,11 +757,19 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
 
     int x_tl = tlnx - b->rx, y_tl = tlny - b->ry;
     int sk = src_kind_of(img->type);
-    switch (b->prec) {
-        case M_I16: return run_feed_kind<M_I16>(b, sk, s0, g, L, x_tl, y_tl);
-        case M_F32: return run_feed_kind<M_F32>(b, sk, s0, g, L, x_tl, y_tl);
-        default: return run_feed_kind<M_F16>(b, sk, s0, g, L, x_tl, y_tl);
+    if (!b->cleared && b->fed.size() >= (size_t)MAX_COVER) {   // more tiles than a Cover holds: clear once, then plain RMW
+        for (int k = 0; k <= L; ++k) ISX_TRY(fill_uncovered(b, k));
+        b->cleared = true;
     }
+    int rc;
+    switch (b->prec) {
+        case M_I16: rc = run_feed_kind<M_I16>(b, sk, s0, g, L, x_tl, y_tl); break;
+        case M_F32: rc = run_feed_kind<M_F32>(b, sk, s0, g, L, x_tl, y_tl); break;
+        default: rc = run_feed_kind<M_F16>(b, sk, s0, g, L, x_tl, y_tl); break;
+    }
+    ISX_TRY(rc);
+    if (!b->cleared) b->fed.push_back(make_int4(x_tl, y_tl, width, height));
+    return ISX_OK;
 }
 
 }  // namespace
@@ -690,6 +866,7 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
     const LevelBuf& d = b->dst[level];
     *rows = d.rows; *cols = d.cols;
     size_t n = (size_t)d.rows * d.cols;
+    if (!b->cleared) ISX_TRY(fill_uncovered(b, level));   // materialise the "uncovered == 0" definition
     ISX_HIP(hipStreamSynchronize(b->stream));
     if (b->prec == M_I16) {
         if (lap) {

@@ -136,43 +136,14 @@ __global__ __launch_bounds__(256) void k_warp(Proj p, MapTabs t, SrcView src, un
 
 // W:229 + W:232 fused: image LINEAR / REFLECT and mask NEAREST / CONSTANT from one map evaluation.
 // OUT16: write the image as CV_16SC3 (the convertTo(CV_16S) of W:294 folded in; u8 -> s16 is exact).
-template <bool OUT16>
-__global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcView img, SrcView msk, int has_mask,
-                                                       unsigned char* dimg, size_t dimg_step, unsigned char* dmask,
-                                                       size_t dmask_step, int dw, int dh) {
-    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= dw || dy >= dh) return;
-    float mx, my;
-    map_backward(p, t, dx, dy, mx, my);
-    unsigned char o[3];
-    sample_linear<unsigned char, 3>(img, mx, my, ISX_BORDER_REFLECT, o);
-    if constexpr (OUT16) {
-        short* q = (short*)(dimg + (size_t)dy * dimg_step) + (size_t)dx * 3;
-        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
-    } else {
-        unsigned char* q = dimg + (size_t)dy * dimg_step + (size_t)dx * 3;
-        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
-    }
-    unsigned char m;
-    if (has_mask) sample_nearest<unsigned char, 1>(msk, mx, my, ISX_BORDER_CONSTANT, &m);
-    else {  // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT
-        int sx = clamp_short(cvround_x86(mx)), sy = clamp_short(cvround_x86(my));
-        m = ((unsigned)sx < (unsigned)img.cols && (unsigned)sy < (unsigned)img.rows) ? 255 : 0;
-    }
-    dmask[(size_t)dy * dmask_step + dx] = m;
-}
-
-// buildMaps (W:133-141), API parity only
-__global__ __launch_bounds__(256) void k_build_maps(Proj p, MapTabs t, float* xmap, size_t xstep, float* ymap, size_t ystep, int dw, int dh) {
-    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= dw || dy >= dh) return;
-    float mx, my;
-    map_backward(p, t, dx, dy, mx, my);
-    ((float*)((char*)xmap + (size_t)dy * xstep))[dx] = mx;
-    ((float*)((char*)ymap + (size_t)dy * ystep))[dx] = my;
-}
-
-// ---- detectResultRoi (W:64-88): full forward scan, min / max reduction ----------------------------
+//
+// One thread produces FOUR consecutive destination pixels.  The bilinear footprint of a pixel is two
+// runs of 6 contiguous bytes (p00|p01 and p10|p11); each run is fetched with ONE 12-byte load from the
+// enclosing 4-byte-aligned address and realigned with v_alignbyte, instead of six byte loads
+// (the byte-load version was bound by the texture-address unit: 18 memory instructions per pixel).
+// Pixels whose taps touch the image border (reflected, hence not adjacent) or the last bytes of the
+// buffer take the generic per-byte path.  When the destination rows are 4-byte aligned (VEC) the four
+// pixels are stored as dwords.
 // order-preserving float <-> uint key for atomicMin / atomicMax
 __device__ __forceinline__ unsigned fkey(float f) {
     unsigned b = __float_as_uint(f);
@@ -189,6 +160,156 @@ __host__ __device__ inline float fkey_inv(unsigned k) {
     return f;
 }
 
+struct U3 { unsigned x, y, z; };
+
+// border / buffer-end pixels of the fused kernel: generic per-byte sampler, kept out of line so that
+// the hot path stays small.  Returns b | g << 8 | r << 16.
+__device__ __noinline__ unsigned slow_bilinear_u8x3(const unsigned char* data, unsigned step, int rows, int cols, float mx, float my) {
+    SrcView s{data, step, rows, cols};
+    unsigned char o[3];
+    sample_linear<unsigned char, 3>(s, mx, my, ISX_BORDER_REFLECT, o);
+    return (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16);
+}
+__device__ __noinline__ unsigned slow_nearest_u8(const unsigned char* data, unsigned step, int rows, int cols, float mx, float my) {
+    SrcView s{data, step, rows, cols};
+    unsigned char m;
+    sample_nearest<unsigned char, 1>(s, mx, my, ISX_BORDER_CONSTANT, &m);
+    return m;
+}
+
+// (p00*w0 + p01*w1 + p10*w2 + p11*w3 + 2^14) >> 15 with 24-bit multiplies (bytes x 15-bit weights)
+__device__ __forceinline__ unsigned fix15(unsigned a, unsigned b, unsigned c, unsigned d, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+    return (__umul24(a, w0) + __umul24(b, w1) + __umul24(c, w2) + __umul24(d, w3) + (1u << 14)) >> 15;
+}
+
+template <bool OUT16, bool VEC>
+__global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcView img, SrcView msk, int has_mask,
+                                                       unsigned char* dimg, size_t dimg_step, unsigned char* dmask,
+                                                       size_t dmask_step, int dw, int dh,
+                                                       const unsigned* roi_keys, int4 planned, int* mismatches) {
+    // planned (sync-free) runs: the ROI scan that preceded this launch on the stream left its extrema in
+    // roi_keys; one thread compares them with the ROI the caller planned (detectResultRoi's int casts)
+    if (roi_keys != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        int tlx = f2i_x86(fkey_inv(roi_keys[0])), tly = f2i_x86(fkey_inv(roi_keys[1]));
+        int brx = f2i_x86(fkey_inv(roi_keys[2])), bry = f2i_x86(fkey_inv(roi_keys[3]));
+        if (tlx != planned.x || tly != planned.y || brx != planned.z || bry != planned.w) atomicAdd(mismatches, 1);
+    }
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx0 >= dw || dy >= dh) return;
+    const int n = min(4, dw - dx0);
+    // stage 1: the separable part of mapBackward for 4 columns (tables are padded to a multiple of 4)
+    const float4 cs4 = *(const float4*)(t.col_s + dx0), cc4 = *(const float4*)(t.col_c + dx0);
+    const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, cc[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+    const float ra = t.row_a[dy], rb = t.row_b[dy];
+    // stage 2: maps, fixed-point coordinates and the two 12-byte windows of every pixel.
+    // The host guarantees rows * step < 2^31, so byte offsets are 32-bit.
+    const unsigned char* base = img.data;
+    const unsigned step = (unsigned)img.step;
+    const unsigned mis = (unsigned)((uintptr_t)base & 3);                     // misalignment of the base pointer
+    const unsigned safe_end = (unsigned)(img.rows - 1) * step + (unsigned)img.cols * 3 + mis;
+    float mx[4], my[4];
+    unsigned wq[4];        // fx | fy << 8
+    unsigned o0[4], o1[4]; // byte offsets of the two rows relative to the ALIGNED base (base - mis)
+    bool fast[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x_, y_, z_;
+        if (p.kind == ISX_WARP_CYLINDRICAL) { x_ = cs[k]; y_ = ra; z_ = cc[k]; }          // W:51-53
+        else { x_ = ra * cs[k]; y_ = rb; z_ = ra * cc[k]; }
+        float x = p.k_rinv[0] * x_ + p.k_rinv[1] * y_ + p.k_rinv[2] * z_;                  // W:56
+        float y = p.k_rinv[3] * x_ + p.k_rinv[4] * y_ + p.k_rinv[5] * z_;                  // W:57
+        float z = p.k_rinv[6] * x_ + p.k_rinv[7] * y_ + p.k_rinv[8] * z_;                  // W:58
+        if (z > 0) { x /= z; y /= z; } else x = y = -1;                                   // W:60-61
+        mx[k] = x; my[k] = y;
+        const int isx = cvround_x86(x * 32.f), isy = cvround_x86(y * 32.f);
+        wq[k] = (unsigned)(isx & 31) | ((unsigned)(isy & 31) << 8);
+        const int sx = isx >> 5, sy = isy >> 5;   // no short saturation needed on the fast path (sx < cols <= 32767... checked below)
+        fast[k] = k < n && (unsigned)sx < (unsigned)(img.cols - 1) && (unsigned)sy < (unsigned)(img.rows - 1);
+        const unsigned a0 = (unsigned)sy * step + (unsigned)sx * 3 + mis;
+        // the aligned 12-byte window of row 1 must end inside the buffer
+        fast[k] = fast[k] && ((a0 + step) & ~3u) + 12 <= safe_end;
+        o0[k] = fast[k] ? a0 : 0;
+        o1[k] = fast[k] ? a0 + step : 0;
+    }
+    // stage 3: all eight loads in flight together
+    const unsigned char* abase = base - mis;
+    U3 v0[4], v1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v0[k] = *(const U3*)(abase + (o0[k] & ~3u));
+        v1[k] = *(const U3*)(abase + (o1[k] & ~3u));
+    }
+    // stage 4: realign + fixed-point bilinear (BilinearTab_i weights, (sum + 2^14) >> 15)
+    unsigned px[4];   // b | g << 8 | r << 16
+    unsigned m[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (fast[k]) {
+            const unsigned s0 = o0[k] & 3, s1 = o1[k] & 3;
+            const unsigned l0 = __builtin_amdgcn_alignbyte(v0[k].y, v0[k].x, s0), h0 = __builtin_amdgcn_alignbyte(v0[k].z, v0[k].y, s0);
+            const unsigned l1 = __builtin_amdgcn_alignbyte(v1[k].y, v1[k].x, s1), h1 = __builtin_amdgcn_alignbyte(v1[k].z, v1[k].y, s1);
+            const unsigned fx = wq[k] & 255, fy = wq[k] >> 8;
+            unsigned w0 = __umul24(32 - fx, 32 - fy) << 5, w1 = __umul24(fx, 32 - fy) << 5, w2 = __umul24(32 - fx, fy) << 5, w3 = __umul24(fx, fy) << 5;
+            if (wq[k] == 0) { w0 = 32767; w3 = 1; }   // BilinearTab_i entry (0,0) after saturate_cast<short> + fix-up
+            // p00 = l0 bytes 0..2, p01 = l0 byte 3, h0 bytes 0..1 (same for row 1)
+            const unsigned c0 = fix15(l0 & 255, l0 >> 24, l1 & 255, l1 >> 24, w0, w1, w2, w3);
+            const unsigned c1 = fix15((l0 >> 8) & 255, h0 & 255, (l1 >> 8) & 255, h1 & 255, w0, w1, w2, w3);
+            const unsigned c2 = fix15((l0 >> 16) & 255, (h0 >> 8) & 255, (l1 >> 16) & 255, (h1 >> 8) & 255, w0, w1, w2, w3);
+            px[k] = c0 | (c1 << 8) | (c2 << 16);   // each c <= 255: the weights sum to 2^15
+        } else if (k < n) {
+            px[k] = slow_bilinear_u8x3(base, step, img.rows, img.cols, mx[k], my[k]);
+        } else px[k] = 0;
+        if (k < n) {
+            if (has_mask) m[k] = slow_nearest_u8(msk.data, (unsigned)msk.step, msk.rows, msk.cols, mx[k], my[k]);
+            else {  // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT; short saturation cannot turn an outside index into an inside one
+                const int sx = cvround_x86(mx[k]), sy = cvround_x86(my[k]);
+                m[k] = ((unsigned)sx < (unsigned)img.cols && (unsigned)sy < (unsigned)img.rows) ? 255u : 0u;
+            }
+        } else m[k] = 0;
+    }
+    // stage 5: stores
+    if (VEC && n == 4) {
+        if constexpr (OUT16) {
+            unsigned* q = (unsigned*)(dimg + (size_t)dy * dimg_step + (size_t)dx0 * 6);
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {   // 2 pixels = 6 shorts = 3 dwords
+                const unsigned a = px[k], b2 = px[k + 1];
+                q[3 * (k / 2)] = (a & 255) | (((a >> 8) & 255) << 16);
+                q[3 * (k / 2) + 1] = ((a >> 16) & 255) | ((b2 & 255) << 16);
+                q[3 * (k / 2) + 2] = ((b2 >> 8) & 255) | (((b2 >> 16) & 255) << 16);
+            }
+        } else {
+            unsigned* q = (unsigned*)(dimg + (size_t)dy * dimg_step + (size_t)dx0 * 3);
+            q[0] = px[0] | (px[1] << 24);
+            q[1] = (px[1] >> 8) | (px[2] << 16);
+            q[2] = (px[2] >> 16) | (px[3] << 8);
+        }
+        *(unsigned*)(dmask + (size_t)dy * dmask_step + dx0) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+    } else {
+        for (int k = 0; k < n; ++k) {
+            if constexpr (OUT16) {
+                short* q = (short*)(dimg + (size_t)dy * dimg_step) + (size_t)(dx0 + k) * 3;
+                q[0] = (short)(px[k] & 255); q[1] = (short)((px[k] >> 8) & 255); q[2] = (short)((px[k] >> 16) & 255);
+            } else {
+                unsigned char* q = dimg + (size_t)dy * dimg_step + (size_t)(dx0 + k) * 3;
+                q[0] = (unsigned char)px[k]; q[1] = (unsigned char)(px[k] >> 8); q[2] = (unsigned char)(px[k] >> 16);
+            }
+            dmask[(size_t)dy * dmask_step + dx0 + k] = (unsigned char)m[k];
+        }
+    }
+}
+
+// buildMaps (W:133-141), API parity only
+__global__ __launch_bounds__(256) void k_build_maps(Proj p, MapTabs t, float* xmap, size_t xstep, float* ymap, size_t ystep, int dw, int dh) {
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    float mx, my;
+    map_backward(p, t, dx, dy, mx, my);
+    ((float*)((char*)xmap + (size_t)dy * xstep))[dx] = mx;
+    ((float*)((char*)ymap + (size_t)dy * ystep))[dx] = my;
+}
+
+// ---- detectResultRoi (W:64-88): full forward scan, min / max reduction ----------------------------
 // mapForward (W:36-45).  v is bit-exact (IEEE mul/add/sqrt/div).  u goes through atan2f, whose
 // device implementation differs from the host libm's by a few ulp: the scan only has to find the
 // extremum CANDIDATES, which the host then re-evaluates with its own atan2f (detect_roi).
@@ -251,13 +372,6 @@ __global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, 
                 if (i < cap) { cand_xy[2 * i] = x; cand_xy[2 * i + 1] = y; }
             }
         }
-}
-
-// planned (sync-free) runs: compare the scanned ROI with the planned one on the device
-__global__ void k_roi_check(const unsigned* keys, int4 planned, int* mismatches) {
-    int tlx = f2i_x86(fkey_inv(keys[0])), tly = f2i_x86(fkey_inv(keys[1]));
-    int brx = f2i_x86(fkey_inv(keys[2])), bry = f2i_x86(fkey_inv(keys[3]));
-    if (tlx != planned.x || tly != planned.y || brx != planned.z || bry != planned.w) atomicAdd(mismatches, 1);
 }
 
 // ---- host-side scalar restatements used for parameter set-up only (O(W+H) work) -----------------
@@ -354,7 +468,6 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     }
     unsigned* keys = (unsigned*)w->scan.p;
     int* count = (int*)(keys + 4);
-    int* mism = (int*)(keys + 5);
     int* cand = (int*)((char*)w->scan.p + 64);
     if (w->kind == ISX_WARP_SPHERICAL) {
         ISX_CHECK_ARG(!sync_free, ISX_ERR_UNSUPPORTED, "planned warp: spherical ROI is computed on the host; use isx_warper_warp_with_mask");
@@ -393,10 +506,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     dim3 grid(std::min(cdiv(sw, 256), 4), cdiv(sh, ROI_ROWS));
     double px = (double)sw * sh;
     ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
-    if (sync_free) {
-        ISX_LAUNCH("roi_check", 0.0, st, k_roi_check, dim3(1), dim3(1), 0, keys, make_int4(planned[0], planned[1], planned[2], planned[3]), mism);
-        return ISX_OK;
-    }
+    if (sync_free) return ISX_OK;   // the fused warp kernel compares keys with the plan (k_warp_img_mask)
     // candidate pass: a tolerance of 64 ulp of the largest |u| covers the device atan2f (<= 2 ulp)
     // vs any faithful host atan2f (<= 2 ulp) with a wide margin
     unsigned hk[4];
@@ -405,6 +515,14 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     float umin = fkey_inv(hk[0]), vmin = fkey_inv(hk[1]), umax = fkey_inv(hk[2]), vmax = fkey_inv(hk[3]);
     float amax = std::max(std::fabs(umin), std::fabs(umax));
     float tol = 64.f * (std::nextafter(amax, std::numeric_limits<float>::infinity()) - amax);
+    // The host's extrema lie within tol of the scanned ones.  When that interval cannot straddle an
+    // integer the ROI is already decided and the refinement pass is skipped (it always runs when the
+    // caller asked for the float extrema themselves).
+    if (!mm && f2i_host(umin - tol) == f2i_host(umin + tol) && f2i_host(umax - tol) == f2i_host(umax + tol) &&
+        std::isfinite(umin) && std::isfinite(umax)) {
+        roi[0] = f2i_host(umin); roi[1] = f2i_host(vmin); roi[2] = f2i_host(umax); roi[3] = f2i_host(vmax);
+        return ISX_OK;
+    }
     ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, grid, dim3(256), 0, w->proj, sw, sh, keys, tol, cand, CAND_CAP, count);
     int n = 0;
     ISX_HIP(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -428,11 +546,12 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
 // per-column / per-row tables of mapBackward's transcendental part, cached per (kind, scale, roi)
 int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
     int mw = roi[2] - roi[0] + 1, mh = roi[3] - roi[1] + 1;
-    size_t n = (size_t)2 * mw + 2 * mh;
+    const int mwp = (mw + 3) & ~3, mhp = (mh + 3) & ~3;   // segments padded to 16 bytes: the fused kernel loads float4
+    size_t n = (size_t)2 * mwp + 2 * mhp;
     bool hit = w->tab_kind == w->kind && w->tab_scale == w->scale && std::equal(roi, roi + 4, w->tab_roi) && w->tabs.p != nullptr;
     if (!hit) {
-        w->host_tabs.resize(n);
-        float* cs = w->host_tabs.data(); float* cc = cs + mw; float* ra = cc + mw; float* rb = ra + mh;
+        w->host_tabs.assign(n, 0.f);
+        float* cs = w->host_tabs.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
         for (int i = 0; i < mw; ++i) {
             float u = (float)(roi[0] + i);
             u /= w->scale;                                 // W:48
@@ -450,7 +569,7 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
         w->tab_kind = w->kind; w->tab_scale = w->scale; std::copy(roi, roi + 4, w->tab_roi);
     }
     const float* base = (const float*)w->tabs.p;
-    t->col_s = base; t->col_c = base + mw; t->row_a = base + 2 * mw; t->row_b = base + 2 * mw + mh;
+    t->col_s = base; t->col_c = base + mwp; t->row_a = base + 2 * mwp; t->row_b = base + 2 * mwp + mhp;
     return ISX_OK;
 }
 
@@ -486,6 +605,8 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
     double spx = (double)src->rows * src->cols, dpx = (double)dw * dh;
     if (fused) {
         ISX_CHECK_ARG(src->type == ISX_8UC3, ISX_ERR_TYPE, "warp_with_mask: src_img must be CV_8UC3, got %s", type_name(src->type));
+        ISX_CHECK_ARG((unsigned long long)w->st_src.d.step * src->rows < (1ull << 31) && src->cols <= 32767 && src->rows <= 32767, ISX_ERR_UNSUPPORTED,
+                      "warp_with_mask: source larger than 2 GiB or 32767 pixels per side");
         ISX_CHECK_ARG(dst->type == ISX_8UC3 || dst->type == ISX_16SC3, ISX_ERR_TYPE, "warp_with_mask: dst_img must be CV_8UC3 or CV_16SC3, got %s", type_name(dst->type));
         ISX_TRY(check_mat(dst_mask, "warp_with_mask: dst_mask"));
         ISX_CHECK_ARG(dst_mask->type == ISX_8UC1, ISX_ERR_TYPE, "warp_with_mask: dst_mask must be CV_8U, got %s", type_name(dst_mask->type));
@@ -501,12 +622,21 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         }
         ISX_TRY(w->st_dmask.use_out(dst_mask, st, "warp_with_mask: dst_mask"));
         double bytes = spx * (src_mask ? 4.0 : 3.0) + dpx * (dst->type == ISX_16SC3 ? 7.0 : 4.0);
-        if (dst->type == ISX_16SC3)
-            ISX_LAUNCH("warp_img_mask", bytes, st, k_warp_img_mask<true>, grid, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0,
-                       (unsigned char*)w->st_dst.d.data, w->st_dst.d.step, (unsigned char*)w->st_dmask.d.data, w->st_dmask.d.step, dw, dh);
-        else
-            ISX_LAUNCH("warp_img_mask", bytes, st, k_warp_img_mask<false>, grid, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0,
-                       (unsigned char*)w->st_dst.d.data, w->st_dst.d.step, (unsigned char*)w->st_dmask.d.data, w->st_dmask.d.step, dw, dh);
+        // dword stores need 4-byte aligned destination rows (pitch-aligned mats; a dense cv::Mat whose
+        // row length is not a multiple of 4 bytes takes the per-pixel store path)
+        const isx_mat& dd = w->st_dst.d;
+        const isx_mat& dm = w->st_dmask.d;
+        const bool vec = ((uintptr_t)dd.data % 4 == 0) && (dd.step % 4 == 0) && ((uintptr_t)dm.data % 4 == 0) && (dm.step % 4 == 0);
+        dim3 grid4(cdiv(dw, 256), cdiv(dh, 4));
+        const unsigned* plan_keys = planned ? (const unsigned*)w->scan.p : nullptr;
+        int* plan_mism = planned ? (int*)w->scan.p + 5 : nullptr;
+        const int4 plan4 = planned ? make_int4(planned[0], planned[1], planned[2], planned[3]) : make_int4(0, 0, 0, 0);
+#define ISX_WARP_FUSED(O16, V)                                                                                                   \
+        ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_img_mask<O16, V>), grid4, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0, \
+                   (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
+        if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_FUSED(true, true); else ISX_WARP_FUSED(true, false); }
+        else { if (vec) ISX_WARP_FUSED(false, true); else ISX_WARP_FUSED(false, false); }
+#undef ISX_WARP_FUSED
         ISX_TRY(w->st_dmask.finish_out(st));
     } else {
         ISX_CHECK_ARG(dst->type == src->type, ISX_ERR_TYPE, "warp: dst type %s differs from src type %s", type_name(dst->type), type_name(src->type));

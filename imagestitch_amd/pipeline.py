@@ -82,8 +82,12 @@ class PairStitcher:
         self.rois = [self.warper.warpRoi((im.shape[1], im.shape[0]), K, R) for im, R in zip(imgs, Rs)]
         self.sizes = [(r[2] - r[0] + 1, r[3] - r[1] + 1) for r in self.rois]
         self.corners = [(r[0], r[1]) for r in self.rois]
-        self.warped = [torch.empty((h, w, 3), dtype=torch.uint8, device=dev) for (w, h) in self.sizes]
-        self.wmasks = [torch.empty((h, w), dtype=torch.uint8, device=dev) for (w, h) in self.sizes]
+        # cv::Mat-style pitched buffers (row pitch a multiple of 64 B) so that the warp kernel can store dwords
+        def pitched(h, row_bytes, shape, strides):
+            pitch = (row_bytes + 63) // 64 * 64
+            return torch.empty((h * pitch,), dtype=torch.uint8, device=dev).as_strided(shape, (pitch,) + strides)
+        self.warped = [pitched(h, w * 3, (h, w, 3), (3, 1)) for (w, h) in self.sizes]
+        self.wmasks = [pitched(h, w, (h, w), (1,)) for (w, h) in self.sizes]
         for i in range(len(imgs)):
             self.warper.warp_with_mask(imgs[i], K, Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
         seam = synth.seam_masks(self.corners, [m.cpu().numpy() for m in self.wmasks])
@@ -94,7 +98,25 @@ class PairStitcher:
         self.out_mask = torch.empty((fh, fw), dtype=torch.uint8, device=dev)
 
     def step(self):
-        """Exactly the reference's call sequence; ROI scan included (the warper recomputes it per call)."""
+        """Steady-state step without host round trips: the ROI scan (detectResultRoi) still runs on the
+        GPU for every warp and is compared ON THE DEVICE with the ROI planned in __init__; a mismatch
+        raises the sticky flag read by check_plan().  Everything else is the reference's call sequence."""
+        n = len(self.imgs)
+        for i in range(n):
+            self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+        self.blender.prepare(self.corners, self.sizes)
+        for i in range(n):
+            self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+        self.blender.blend(self.out, self.out_mask)
+        return self.out, self.out_mask
+
+    def check_plan(self):
+        """Synchronises; raises IsxError(ISX_ERR_PLAN) if any planned step saw a different ROI."""
+        return self.warper.plan_status()
+
+    def step_sync(self):
+        """Exactly the reference's call sequence; the warper returns the corner to the host on every call
+        (one stream synchronisation per tile), as cv::detail::RotationWarper::warp does."""
         cs = []
         for i in range(len(self.imgs)):
             c, _, _ = self.warper.warp_with_mask(self.imgs[i], self.K, self.Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])

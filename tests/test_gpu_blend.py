@@ -230,3 +230,44 @@ def test_full_size_4k_pair(gpu, oracle):
         assert np.all(out[omask == 0] == 0)
         del ps
     torch.cuda.empty_cache()
+
+
+def test_more_tiles_than_cover_slots(gpu, oracle):
+    """11 tiles: after MAX_COVER (8) feeds the blender clears the uncovered area once and falls back to
+    plain read-modify-write; results must not change."""
+    rng = np.random.default_rng(21)
+    corners = [(37 * i, (i % 3) * 11 - 5) for i in range(11)]
+    sizes = [(64 + (i % 4) * 5, 48 + (i % 5) * 3) for i in range(11)]
+    tiles = _tiles(rng, sizes)
+    for prec in (I16, F32):
+        mb = gpu.MultiBandBlender(False, 3, prec)
+        ob = oracle.MultiBand(3, prec)
+        mb.prepare(corners, sizes)
+        ob.prepare(corners, sizes)
+        for (img, mask), c in zip(tiles, corners):
+            mb.feed(img, mask, c)
+            ob.feed(img, mask, c)
+        _compare_levels(mb, ob, prec)
+        d, m = mb.blend()
+        od, om = ob.blend(False)
+        assert np.array_equal(m, om) and np.array_equal(d, od)
+
+
+def test_planned_pipeline_matches_sync_pipeline(gpu):
+    import torch
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F = 960, 540, 700.0
+    K, Rs = synth.camera_pair(W, H, F)
+    dev = torch.device("cuda:0")
+    imgs = [torch.from_numpy(synth.make_tile(H, W, i)).to(dev) for i in range(2)]
+    ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16")
+    a, am = [t.clone() for t in ps.step_sync()]
+    b, bm = [t.clone() for t in ps.step()]
+    assert ps.check_plan() == 0
+    assert torch.equal(a, b) and torch.equal(am, bm)
+    # a wrong plan is detected on the device
+    ps.rois[0] = (ps.rois[0][0] + 1,) + tuple(ps.rois[0][1:])
+    ps.warper.warp_with_mask_planned(imgs[0], K, Rs[0], ps.rois[0], ps.warped[0][:, :-1], ps.wmasks[0][:, :-1])
+    with pytest.raises(gpu.IsxError) as e:
+        ps.check_plan()
+    assert e.value.code == 8

@@ -13,26 +13,10 @@ K, Rs = synth.camera_pair(W, H, F)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 imgs = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generator=g) for _ in range(2)]
-warper = I.CylindricalWarper().create(F)
-mb = I.MultiBandBlender(False, bands, prec)
-corners, wimgs, wmasks = [], [], []
-for i in range(2):
-    c, wi, wm = warper.warp_with_mask(imgs[i], K, Rs[i])
-    corners.append(c); wimgs.append(wi); wmasks.append(wm)
-sizes = [(m.shape[1], m.shape[0]) for m in wmasks]
-print("corners", corners, "sizes", sizes)
-seam = synth.seam_masks(corners, [m.cpu().numpy() for m in wmasks])
-seam = [torch.from_numpy(s).to(dev) for s in seam]
-
-def step():
-    cs = []
-    for i in range(2):
-        c, wi, wm = warper.warp_with_mask(imgs[i], K, Rs[i], dst_img=wimgs[i], dst_mask=wmasks[i])
-        cs.append(c)
-    mb.prepare(cs, sizes)
-    for i in range(2):
-        mb.feed_u8(wimgs[i], seam[i], cs[i])
-    return mb.blend(out_f32=(prec != 0))
+from imagestitch_amd.pipeline import PairStitcher
+ps = PairStitcher(imgs, K, Rs, F, "cylindrical", bands, prec, 0, None, "int16")
+print("corners", ps.corners, "sizes", ps.sizes)
+step = ps.step_sync if (len(sys.argv) > 3 and sys.argv[3] == "sync") else ps.step
 
 for _ in range(3): out = step()
 torch.cuda.synchronize()
