@@ -60,6 +60,9 @@ int MatStage::use_in(const isx_mat* m, hipStream_t s, const char* what) {
     ISX_TRY(buf.reserve(row * m->rows));
     d = *m; d.data = buf.p; d.step = row; d.device = 0;
     ISX_HIP(hipMemcpy2DAsync(buf.p, row, m->data, m->step, row, m->rows, hipMemcpyHostToDevice, s));
+    // cv::Mat semantics: the caller may free or overwrite a host mat as soon as the call returns
+    // (W:305-308 clears the fed images before blend()), so the copy must have consumed it by then
+    ISX_HIP(hipStreamSynchronize(s));
     return ISX_OK;
 }
 int MatStage::use_out(isx_mat* m, hipStream_t s, const char* what) {

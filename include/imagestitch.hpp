@@ -1,0 +1,173 @@
+// imagestitch.hpp — header-only C++ host-side mirror of the reference's call surface over the C-ABI.
+//
+// The reference is C++ on OpenCV (`cv::detail::RotationWarper`, `cv::detail::Blender`); this header gives
+// the same class / method names, argument meaning and error behaviour (exceptions) on top of
+// include/imagestitch_hip.h, so the pipeline code of W:217-233 / W:271-313 ports line by line:
+//
+//     isx::CylindricalWarper creator;                                   // W:219
+//     auto warper = creator.create(focal);                              // W:222
+//     isx::Point corner = warper->warp(img, K, R, isx::INTER_LINEAR, isx::BORDER_REFLECT, warped);   // W:229
+//     warper->warp(mask, K, R, isx::INTER_NEAREST, isx::BORDER_CONSTANT, mask_warped);               // W:232
+//     auto blender = isx::Blender::createDefault(isx::Blender::MULTI_BAND, false);                   // W:271
+//     static_cast<isx::MultiBandBlender*>(blender.get())->setNumBands(4);                            // W:273
+//     blender->prepare(corners, sizes);  blender->feed(img_s, mask, corner);  blender->blend(result, result_mask);
+//
+// With OpenCV available, define ISX_HAVE_OPENCV before including: isx::Mat then converts from / to cv::Mat
+// without copying (same data / rows / cols / type() / step).
+#pragma once
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "imagestitch_hip.h"
+#ifdef ISX_HAVE_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace isx {
+
+enum { INTER_NEAREST = ISX_INTER_NEAREST, INTER_LINEAR = ISX_INTER_LINEAR };
+enum { BORDER_CONSTANT = ISX_BORDER_CONSTANT, BORDER_REPLICATE = ISX_BORDER_REPLICATE, BORDER_REFLECT = ISX_BORDER_REFLECT,
+       BORDER_REFLECT_101 = ISX_BORDER_REFLECT_101 };
+
+struct Point { int x = 0, y = 0; Point() = default; Point(int x_, int y_) : x(x_), y(y_) {} };
+struct Size { int width = 0, height = 0; Size() = default; Size(int w, int h) : width(w), height(h) {} };
+struct Rect { int x = 0, y = 0, width = 0, height = 0; };
+
+// cv::Exception analogue: thrown for every non-zero status of the C-ABI
+class Exception : public std::runtime_error {
+public:
+    Exception(int code_, const std::string& msg) : std::runtime_error(msg), code(code_) {}
+    int code;
+};
+inline void check(int rc) { if (rc != ISX_OK) throw Exception(rc, isx_last_error()); }
+
+// cv::Mat-shaped matrix: owns a host buffer (create) or aliases foreign memory (host or HIP device).
+class Mat {
+public:
+    Mat() { std::memset(&m_, 0, sizeof(m_)); m_.device = -1; }
+    Mat(int rows, int cols, int type) : Mat() { create(rows, cols, type); }
+    Mat(int rows, int cols, int type, void* data, size_t step, int device = -1) : Mat() {
+        m_.data = data; m_.rows = rows; m_.cols = cols; m_.type = type; m_.step = step; m_.device = device;
+    }
+#ifdef ISX_HAVE_OPENCV
+    Mat(const cv::Mat& c) : Mat(c.rows, c.cols, c.type(), c.data, c.step, -1) {}   // zero-copy view
+    cv::Mat toCv() const { return cv::Mat(m_.rows, m_.cols, m_.type, m_.data, m_.step); }
+#endif
+    void create(int rows, int cols, int type) {   // OutputArray::create (W:128-129,150)
+        if (own_ && m_.rows == rows && m_.cols == cols && m_.type == type) return;
+        size_t es = elemSize(type);
+        own_ = std::shared_ptr<unsigned char>(new unsigned char[(size_t)rows * cols * es], std::default_delete<unsigned char[]>());
+        m_.data = own_.get(); m_.rows = rows; m_.cols = cols; m_.type = type; m_.step = (size_t)cols * es; m_.device = -1;
+    }
+    static size_t elemSize(int type) {
+        static const int d[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+        return (size_t)d[type & 7] * ((type >> 3) + 1);
+    }
+    bool empty() const { return m_.data == nullptr; }
+    int rows() const { return m_.rows; }
+    int cols() const { return m_.cols; }
+    int type() const { return m_.type; }
+    Size size() const { return Size(m_.cols, m_.rows); }
+    template <class T> T* ptr(int y) { return (T*)((unsigned char*)m_.data + (size_t)y * m_.step); }
+    template <class T> const T* ptr(int y) const { return (const T*)((const unsigned char*)m_.data + (size_t)y * m_.step); }
+    void setTo(unsigned char v) { for (int y = 0; y < m_.rows; ++y) std::memset(ptr<unsigned char>(y), v, (size_t)m_.cols * elemSize(m_.type)); }
+    isx_mat* c() { return &m_; }
+    const isx_mat* c() const { return &m_; }
+private:
+    isx_mat m_;
+    std::shared_ptr<unsigned char> own_;
+};
+
+// cv::detail::RotationWarper (W:122-161; stock call sites B:105,109)
+class RotationWarper {
+public:
+    RotationWarper(int kind, float scale, int device = 0) { check(isx_warper_create(kind, scale, device, &h_)); }
+    virtual ~RotationWarper() { isx_warper_destroy(h_); }
+    RotationWarper(const RotationWarper&) = delete;
+    RotationWarper& operator=(const RotationWarper&) = delete;
+    void setStream(void* hip_stream) { check(isx_warper_set_stream(h_, hip_stream)); }
+    // Rect buildMaps(Size src_size, K, R, xmap, ymap)  W:122
+    Rect buildMaps(Size src_size, const float K[9], const float R[9], Mat& xmap, Mat& ymap) {
+        int roi[4];
+        check(isx_warper_roi(h_, src_size.width, src_size.height, K, R, roi, nullptr));
+        xmap.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, ISX_32FC1);   // W:128
+        ymap.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, ISX_32FC1);   // W:129
+        check(isx_warper_build_maps(h_, src_size.width, src_size.height, K, R, xmap.c(), ymap.c(), roi));
+        Rect r; r.x = roi[0]; r.y = roi[1]; r.width = roi[2] - roi[0]; r.height = roi[3] - roi[1];   // Rect(tl, br)  W:143
+        return r;
+    }
+    // Point warp(src, K, R, interp_mode, border_mode, dst)  W:145
+    Point warp(const Mat& src, const float K[9], const float R[9], int interp_mode, int border_mode, Mat& dst) {
+        int roi[4];
+        check(isx_warper_roi(h_, src.cols(), src.rows(), K, R, roi, nullptr));
+        dst.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, src.type());   // dst.create(roi.height + 1, roi.width + 1)  W:150
+        int corner[2];
+        check(isx_warper_warp(h_, src.c(), K, R, interp_mode, border_mode, dst.c(), corner));
+        return Point(corner[0], corner[1]);   // dst_roi.tl()  W:160
+    }
+    Rect warpRoi(Size src_size, const float K[9], const float R[9]) {
+        int roi[4];
+        check(isx_warper_roi(h_, src_size.width, src_size.height, K, R, roi, nullptr));
+        Rect r; r.x = roi[0]; r.y = roi[1]; r.width = roi[2] - roi[0] + 1; r.height = roi[3] - roi[1] + 1;
+        return r;
+    }
+    isx_warper* handle() { return h_; }
+private:
+    isx_warper* h_ = nullptr;
+};
+
+struct WarperCreator { virtual ~WarperCreator() {} virtual std::shared_ptr<RotationWarper> create(float scale) const = 0; };
+struct CylindricalWarper : WarperCreator {   // cv::CylindricalWarper  W:219
+    std::shared_ptr<RotationWarper> create(float scale) const override { return std::make_shared<RotationWarper>(ISX_WARP_CYLINDRICAL, scale); }
+};
+struct SphericalWarper : WarperCreator {     // cv::SphericalWarper  B:93 (commented out in the reference)
+    std::shared_ptr<RotationWarper> create(float scale) const override { return std::make_shared<RotationWarper>(ISX_WARP_SPHERICAL, scale); }
+};
+
+// cv::detail::Blender / MultiBandBlender (W:271-281,302,313)
+class Blender {
+public:
+    enum { NO = ISX_BLEND_NO, FEATHER = ISX_BLEND_FEATHER, MULTI_BAND = ISX_BLEND_MULTI_BAND };
+    virtual ~Blender() { isx_blender_destroy(h_); }
+    static std::shared_ptr<Blender> createDefault(int type, bool try_gpu = false, int precision = ISX_PREC_I16);
+    void prepare(const std::vector<Point>& corners, const std::vector<Size>& sizes) {   // W:281
+        if (corners.size() != sizes.size()) throw Exception(ISX_ERR_INVALID, "prepare: corners.size() != sizes.size()");
+        std::vector<int> c, s;
+        for (size_t i = 0; i < corners.size(); ++i) { c.push_back(corners[i].x); c.push_back(corners[i].y); s.push_back(sizes[i].width); s.push_back(sizes[i].height); }
+        check(isx_blender_prepare(h_, (int)corners.size(), c.data(), s.data()));
+    }
+    void prepare(Rect dst_roi) { check(isx_blender_prepare_roi(h_, dst_roi.x, dst_roi.y, dst_roi.width, dst_roi.height)); }
+    void feed(const Mat& img, const Mat& mask, Point tl) { check(isx_blender_feed(h_, img.c(), mask.c(), tl.x, tl.y)); }   // W:302
+    void blend(Mat& dst, Mat& dst_mask) {   // W:313
+        int w, h;
+        check(isx_blender_result_size(h_, &w, &h));
+        if (dst.empty() || dst.rows() != h || dst.cols() != w) dst.create(h, w, ISX_16SC3);
+        dst_mask.create(h, w, ISX_8UC1);
+        check(isx_blender_blend(h_, dst.c(), dst_mask.c()));
+    }
+    void setStream(void* hip_stream) { check(isx_blender_set_stream(h_, hip_stream)); }
+    isx_blender* handle() { return h_; }
+protected:
+    Blender() = default;
+    isx_blender* h_ = nullptr;
+};
+
+class MultiBandBlender : public Blender {
+public:
+    MultiBandBlender(int try_gpu = false, int num_bands = 5, int precision = ISX_PREC_I16, int device = 0) {
+        (void)try_gpu;   // the reference passes false everywhere (W:276,278); this library IS the accelerator path
+        check(isx_blender_create(ISX_BLEND_MULTI_BAND, num_bands, precision, device, &h_));
+    }
+    int numBands() { int n; check(isx_blender_num_bands(h_, &n)); return n; }
+    void setNumBands(int val) { check(isx_blender_set_num_bands(h_, val)); }   // W:273
+};
+
+inline std::shared_ptr<Blender> Blender::createDefault(int type, bool try_gpu, int precision) {
+    if (type != MULTI_BAND) throw Exception(ISX_ERR_UNSUPPORTED, "Blender::createDefault: only MULTI_BAND is implemented on this path");
+    return std::make_shared<MultiBandBlender>(try_gpu, 5, precision);
+}
+
+}  // namespace isx
