@@ -37,6 +37,10 @@ class MultiBandBlender:
         ptr = getattr(stream, "cuda_stream", stream)
         check(self._lib.isx_blender_set_stream(self._h, C.c_void_p(ptr or 0)))
 
+    def set_deferred_level0(self, on=True):
+        """Opt-in (see include/imagestitch_hip.h): fed device mats must then stay valid until blend() returns."""
+        check(self._lib.isx_blender_set_deferred_level0(self._h, int(bool(on))))
+
     def setNumBands(self, n):
         check(self._lib.isx_blender_set_num_bands(self._h, int(n)))
 

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <memory>
 #include <new>
 
 using namespace isx;
@@ -181,7 +182,7 @@ constexpr int PD_WAVES = 8;
 constexpr int PD_RPW = (PD_NR + PD_WAVES - 1) / PD_WAVES;
 
 template <int M, int SK>
-__global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBuf dst) {
+__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst) {
     using WT = typename WorkT<M>::t;
     __shared__ Px<M> hb[PD_NR][WAVE];
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
@@ -230,6 +231,11 @@ __global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBu
         o.w = aw * (1.f / 256.f);
         store_px<M, false>(dst, ox, oy, o);
     }
+}
+
+template <int M, int SK>
+__global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBuf dst) {
+    pyr_down_block<M, SK>(s0, src, dst);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,6 +489,127 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Deferred mode (opt-in, isx_blender_set_deferred_level0): feed() only records the tile; blend()
+//   1. builds every tile's Gaussian chain, all tiles of a level in one launch   (k_pyr_down_multi)
+//   2. gathers + normalises the top level                                       (k_top_gather)
+//   3. collapses: out_{k-1} = sat(pyrUp(out_k) + norm(SUM_t cast(lap_{k-1,t} * w_{k-1,t})))
+//      where the sum over the tiles covering a pixel runs IN REGISTERS, in feed order, from
+//      lap = G_{k-1,t} - pyrUp(G_{k,t})                                         (k_collapse_gather)
+// The destination Laplacian / weight pyramid (32 B/px of read-modify-write per feed + 16 B/px
+// read back by blend) never exists in HBM.  Operations and their order per pixel are those of the
+// eager path (0 + a == a exactly), so the results are identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int DEF_MAX = 8;
+struct TileSet {                 // per-tile views of one pyramid level pair, indexed by the (uniform) tile id
+    int n;
+    Src0 s0[DEF_MAX];            // level-0 view (used where the fine / source level is level 0)
+    LevelBuf fine[DEF_MAX];      // G_{k-1,t}  (unused when the fine level is level 0)
+    LevelBuf coarse[DEF_MAX];    // G_{k,t}
+    int x_tl[DEF_MAX], y_tl[DEF_MAX], w[DEF_MAX], h[DEF_MAX];   // tile rectangle at the FINE level, dst_roi_ coordinates
+};
+
+template <int M, int SK>
+__global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
+    // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
+    const int t = blockIdx.z;
+    const LevelBuf dst = ts.coarse[t];
+    if (blockIdx.x * PD_OW >= dst.cols || blockIdx.y * PD_TY >= dst.rows) return;
+    pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst);
+}
+
+// top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t}))
+template <int M>
+__global__ __launch_bounds__(256) void k_top_gather(TileSet ts, LevelBuf out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= out.cols || y >= out.rows) return;
+    Px<M> d; d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f;
+    for (int t = 0; t < ts.n; ++t) {
+        const int lx = x - ts.x_tl[t], ly = y - ts.y_tl[t];
+        if ((unsigned)lx < (unsigned)ts.w[t] && (unsigned)ly < (unsigned)ts.h[t]) {
+            Px<M> g = load_px<M, false>(ts.coarse[t], lx, ly);
+            if constexpr (M == M_I16) {
+                d.c0 = wrap_s16(d.c0 + f2s_x86((float)g.c0 * g.w)); d.c1 = wrap_s16(d.c1 + f2s_x86((float)g.c1 * g.w)); d.c2 = wrap_s16(d.c2 + f2s_x86((float)g.c2 * g.w));
+            } else { d.c0 = d.c0 + g.c0 * g.w; d.c1 = d.c1 + g.c1 * g.w; d.c2 = d.c2 + g.c2 * g.w; }
+            d.w = d.w + g.w;
+        }
+    }
+    normalise<M>(d);
+    store_px<M, true>(out, x, y, d);
+}
+
+// FINE0: the fine level is level 0 = the caller's tiles (read through the copyMakeBorder maps) and the
+// result goes to the caller's mats (crop, mask, zero fill); otherwise fine = G_{k-1,t} and the result is
+// stored as level k-1 of the collapsed pyramid.
+template <int M, int SK, bool FINE0>
+__global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+    using WT = typename WorkT<M>::t;
+    __shared__ Px<M> ct[UP_TY + 2][WAVE + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
+    WT acc[2][2][3];
+    float accw[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[i][j][0] = 0; acc[i][j][1] = 0; acc[i][j][2] = 0; accw[i][j] = 0.f; }
+    for (int t = 0; t < ts.n; ++t) {
+        // block-uniform: does the block's fine region touch the tile's rectangle?
+        const int tx = ts.x_tl[t], ty = ts.y_tl[t];
+        if (2 * cx0 >= tx + ts.w[t] || 2 * cx0 + 2 * WAVE <= tx || 2 * cy0 >= ty + ts.h[t] || 2 * cy0 + 2 * UP_TY <= ty) continue;
+        const int lx0 = cx0 - (tx >> 1), ly0 = cy0 - (ty >> 1);      // block origin in the tile's coarse coordinates
+        __syncthreads();
+        stage_coarse<M, false>(ct, ts.coarse[t], lx0, ly0);
+        __syncthreads();
+        const int lcx = lx0 + lane, lcy = ly0 + wv;
+        const int cw = ts.coarse[t].cols, ch = ts.coarse[t].rows;
+        if ((unsigned)lcx < (unsigned)cw && (unsigned)lcy < (unsigned)ch) {
+            Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, lcx, cw);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    Px<M> g;
+                    if constexpr (FINE0) g = load_src0<M, SK>(ts.s0[t], 2 * lcx + dx, 2 * lcy + dy);
+                    else g = load_px<M, false>(ts.fine[t], 2 * lcx + dx, 2 * lcy + dy);
+                    if constexpr (M == M_I16) {
+                        acc[dy][dx][0] = wrap_s16(acc[dy][dx][0] + f2s_x86((float)sat_s16(g.c0 - u.v[dy][dx][0]) * g.w));
+                        acc[dy][dx][1] = wrap_s16(acc[dy][dx][1] + f2s_x86((float)sat_s16(g.c1 - u.v[dy][dx][1]) * g.w));
+                        acc[dy][dx][2] = wrap_s16(acc[dy][dx][2] + f2s_x86((float)sat_s16(g.c2 - u.v[dy][dx][2]) * g.w));
+                    } else {
+                        acc[dy][dx][0] = acc[dy][dx][0] + (g.c0 - u.v[dy][dx][0]) * g.w;
+                        acc[dy][dx][1] = acc[dy][dx][1] + (g.c1 - u.v[dy][dx][1]) * g.w;
+                        acc[dy][dx][2] = acc[dy][dx][2] + (g.c2 - u.v[dy][dx][2]) * g.w;
+                    }
+                    accw[dy][dx] = accw[dy][dx] + g.w;
+                }
+        }
+    }
+    __syncthreads();
+    stage_coarse<M, true>(ct, coarse_out, cx0, cy0);
+    __syncthreads();
+    const int cx = cx0 + lane, cy = cy0 + wv;
+    if (cx >= coarse_out.cols || cy >= coarse_out.rows) return;
+    Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse_out.cols);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int fx = 2 * cx + dx, fy = 2 * cy + dy;
+            if constexpr (FINE0) { if (fx >= out.cols || fy >= out.rows) continue; }
+            Px<M> d;
+            d.c0 = acc[dy][dx][0]; d.c1 = acc[dy][dx][1]; d.c2 = acc[dy][dx][2]; d.w = accw[dy][dx];
+            normalise<M>(d);
+            if constexpr (M == M_I16) {
+                d.c0 = sat_s16(u.v[dy][dx][0] + d.c0); d.c1 = sat_s16(u.v[dy][dx][1] + d.c1); d.c2 = sat_s16(u.v[dy][dx][2] + d.c2);
+            } else {
+                d.c0 = u.v[dy][dx][0] + d.c0; d.c1 = u.v[dy][dx][1] + d.c1; d.c2 = u.v[dy][dx][2] + d.c2;
+            }
+            if constexpr (FINE0) write_final<M>(out, fx, fy, d);
+            else store_px<M, true>(fine_out, fx, fy, d);
+        }
+}
+
 // zero every pixel of a level that no fed tile covers (only needed when more than MAX_COVER tiles are
 // fed, and by the level-introspection entry point)
 template <int M>
@@ -525,6 +652,13 @@ struct isx_blender {
     // means every level has been zero-filled outside them (only when > MAX_COVER tiles are fed)
     std::vector<int4> fed;
     bool cleared = false;
+    // deferred level 0: tiles recorded by feed(), consumed by blend()
+    struct TileRec { Src0 s0; int sk; LevelBuf g[MAX_LEVELS]; int x_tl, y_tl, width, height; };
+    bool deferred = false;          // requested by the caller
+    bool level0_pending = false;    // recorded tiles have not been accumulated into dst[0] yet
+    std::vector<TileRec> tiles;
+    std::vector<std::unique_ptr<DevBuf>> tile_arenas;      // one per recorded tile (their pyramids must outlive feed)
+    std::vector<std::unique_ptr<MatStage>> tile_img, tile_mask;   // staging of host mats, one per recorded tile
 };
 
 namespace {
@@ -576,7 +710,7 @@ int src_kind_of(int type) { return type == ISX_8UC3 ? SK_U8 : (type == ISX_16SC3
 double src_px_bytes(int sk) { return sk == SK_U8 ? 3.0 : (sk == SK_S16 ? 6.0 : 12.0); }
 
 template <int M, int SK>
-int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y_tl) {
+int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y_tl, bool skip_level0) {
     hipStream_t st = b->stream;
     const int prec = M;
     // Gaussian chain (image + weight): G_{k+1} = pyrDown(G_k)
@@ -599,7 +733,9 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
             a.blk_start[k] = nb;
             double px = (double)g[k].rows * g[k].cols;
             double gin = (k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec));
-            if (k < L) {
+            if (k == 0 && skip_level0) {
+                a.gw[k] = 1;   // deferred level 0: no blocks, blend() accumulates it in registers
+            } else if (k < L) {
                 a.gw[k] = cdiv(g[k + 1].cols, WAVE);
                 nb += a.gw[k] * cdiv(g[k + 1].rows, UP_TY);
                 bytes += px * (gin + 2.0 * alg_d(prec)) + (double)g[k + 1].rows * g[k + 1].cols * alg_g_rgb(prec);
@@ -635,11 +771,117 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
 }
 
 template <int M>
-int run_feed_kind(isx_blender* b, int sk, const Src0& s0, LevelBuf* g, int L, int x_tl, int y_tl) {
+int run_feed_kind(isx_blender* b, int sk, const Src0& s0, LevelBuf* g, int L, int x_tl, int y_tl, bool skip_level0) {
     switch (sk) {
-        case SK_U8: return run_feed<M, SK_U8>(b, s0, g, L, x_tl, y_tl);
-        case SK_S16: return run_feed<M, SK_S16>(b, s0, g, L, x_tl, y_tl);
-        default: return run_feed<M, SK_F32>(b, s0, g, L, x_tl, y_tl);
+        case SK_U8: return run_feed<M, SK_U8>(b, s0, g, L, x_tl, y_tl, skip_level0);
+        case SK_S16: return run_feed<M, SK_S16>(b, s0, g, L, x_tl, y_tl, skip_level0);
+        default: return run_feed<M, SK_F32>(b, s0, g, L, x_tl, y_tl, skip_level0);
+    }
+}
+
+Cover make_cover_n(const isx_blender* b, int level, int n) {
+    Cover c = make_cover(b, level);
+    if (c.n > n) c.n = n;
+    return c;
+}
+
+// Deferred tiles have had no kernel run for them.  When the cycle cannot stay deferred (level
+// introspection, a 9th tile, a tile of another type) they are replayed through the eager feed, in order.
+int flush_deferred(isx_blender* b) {
+    if (!b->level0_pending) return ISX_OK;
+    const int L = b->num_bands;
+    for (size_t t = 0; t < b->tiles.size(); ++t) {
+        isx_blender::TileRec& r = b->tiles[t];
+        int rc;
+        if (!b->cleared && b->fed.size() >= (size_t)MAX_COVER) {
+            for (int k = 0; k <= L; ++k) ISX_TRY(fill_uncovered(b, k));
+            b->cleared = true;
+        }
+        switch (b->prec) {
+            case M_I16: rc = run_feed_kind<M_I16>(b, r.sk, r.s0, r.g, L, r.x_tl, r.y_tl, false); break;
+            case M_F32: rc = run_feed_kind<M_F32>(b, r.sk, r.s0, r.g, L, r.x_tl, r.y_tl, false); break;
+            default: rc = run_feed_kind<M_F16>(b, r.sk, r.s0, r.g, L, r.x_tl, r.y_tl, false); break;
+        }
+        ISX_TRY(rc);
+        if (!b->cleared) b->fed.push_back(make_int4(r.x_tl, r.y_tl, r.width, r.height));
+    }
+    b->level0_pending = false;   // the tiles stay recorded (their buffers are in use); the cycle continues eagerly
+    return ISX_OK;
+}
+
+// blend() of a fully deferred cycle: Gaussian chains of all tiles, top gather, gathering collapse chain
+template <int M, int SK>
+int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
+    hipStream_t st = b->stream;
+    const int L = b->num_bands, prec = M, n = (int)b->tiles.size();
+    LevelBuf* d = b->dst;
+    auto base = [&](int k_fine) {   // tile rectangles at level k_fine
+        TileSet ts;
+        memset(&ts, 0, sizeof(ts));
+        ts.n = n;
+        for (int t = 0; t < n; ++t) {
+            const isx_blender::TileRec& r = b->tiles[t];
+            ts.s0[t] = r.s0;
+            ts.x_tl[t] = r.x_tl >> k_fine; ts.y_tl[t] = r.y_tl >> k_fine;
+            ts.w[t] = r.g[k_fine].cols; ts.h[t] = r.g[k_fine].rows;
+        }
+        return ts;
+    };
+    const double gin0 = src_px_bytes(SK) + 1.0;
+    // 1. Gaussian chains: one launch per level for all tiles
+    for (int k = 0; k < L; ++k) {
+        TileSet ts = base(k);
+        int maxc = 0, maxr = 0;
+        double bytes = 0.0;
+        for (int t = 0; t < n; ++t) {
+            const isx_blender::TileRec& r = b->tiles[t];
+            ts.fine[t] = r.g[k]; ts.coarse[t] = r.g[k + 1];
+            maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
+            bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
+        }
+        dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
+        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
+        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+    }
+    // 2. top level: gather + normalise into the collapsed pyramid's level L
+    {
+        TileSet ts = base(L);
+        double bytes = (double)d[L].rows * d[L].cols * (alg_d(prec) + alg_d_rgb(prec));
+        for (int t = 0; t < n; ++t) {
+            ts.coarse[t] = b->tiles[t].g[L];
+            bytes += (double)ts.w[t] * ts.h[t] * (alg_g(prec) + 2.0 * alg_d(prec));
+        }
+        dim3 grid(cdiv(d[L].cols, 64), cdiv(d[L].rows, 4));
+        ISX_LAUNCH("top_gather", bytes, st, (k_top_gather<M>), grid, dim3(256), 0, ts, d[L]);
+    }
+    // 3. collapse chain; each step gathers the tiles' Laplacians of its fine level in registers.
+    //    Algorithmic bytes = SURVEY-model bytes of the work the launch replaces: the accumulate of level
+    //    k-1 for every tile + the collapse step k -> k-1.
+    for (int k = L; k >= 1; --k) {
+        TileSet ts = base(k - 1);
+        double bytes = (double)d[k].rows * d[k].cols * alg_d_rgb(prec);
+        for (int t = 0; t < n; ++t) {
+            const isx_blender::TileRec& r = b->tiles[t];
+            ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
+            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * ((k == 1 ? gin0 : alg_g(prec)) + 2.0 * alg_d(prec)) + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);
+        }
+        dim3 grid(cdiv(d[k].cols, WAVE), cdiv(d[k].rows, UP_TY));
+        if (k == 1) {
+            bytes += (double)out.rows * out.cols * (alg_d(prec) + (out.img_f32 ? 13.0 : 7.0));
+            ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true>), grid, dim3(256), 0, ts, d[1], d[0], out);
+        } else {
+            bytes += (double)d[k - 1].rows * d[k - 1].cols * (alg_d(prec) + alg_d_rgb(prec));
+            ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
+        }
+    }
+    return ISX_OK;
+}
+template <int M>
+int run_blend_deferred(isx_blender* b, const OutMat& out) {
+    switch (b->tiles[0].sk) {
+        case SK_U8: return run_blend_deferred_t<M, SK_U8>(b, out);
+        case SK_S16: return run_blend_deferred_t<M, SK_S16>(b, out);
+        default: return run_blend_deferred_t<M, SK_F32>(b, out);
     }
 }
 
@@ -648,6 +890,7 @@ int run_blend(isx_blender* b, const OutMat& out) {
     hipStream_t st = b->stream;
     const int L = b->num_bands, prec = M;
     LevelBuf* d = b->dst;
+    if (b->level0_pending) return run_blend_deferred<M>(b, out);
     if (L == 0) {
         dim3 grid(cdiv(d[0].cols, 64), cdiv(d[0].rows, 4));
         double px = (double)d[0].rows * d[0].cols;
@@ -693,6 +936,8 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     // dst_.setTo(0) / weights setTo(0) are not executed: uncovered pixels are defined as zero (Cover)
     b->fed.clear();
     b->cleared = false;
+    b->tiles.clear();
+    b->level0_pending = false;
     b->prepared = true;
     return ISX_OK;
 }
@@ -713,10 +958,28 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     ISX_CHECK_ARG(mask->rows == img->rows && mask->cols == img->cols, ISX_ERR_SIZE, "feed: mask %dx%d does not match img %dx%d",
                   mask->cols, mask->rows, img->cols, img->rows);
     ISX_HIP(hipSetDevice(b->device));
-    ISX_TRY(b->st_img.use_in(img, b->stream, "feed: img"));
-    ISX_TRY(b->st_mask.use_in(mask, b->stream, "feed: mask"));
-    const isx_mat& di = b->st_img.d;
-    const isx_mat& dm = b->st_mask.d;
+    // deferred level 0: possible while every feed of this cycle has been deferred, at most DEF_MAX tiles,
+    // one source type.  A recorded tile's staging buffers and pyramid arena are its own (they must
+    // outlive this call); an eager feed uses the shared ones.
+    const int sk = src_kind_of(img->type);
+    const int L0 = b->num_bands;
+    const bool can_defer = b->deferred && L0 >= 1 && L0 <= ACC_MAXL && !b->cleared &&
+                           (b->tiles.empty() ? b->fed.empty() : b->level0_pending) && b->tiles.size() < (size_t)DEF_MAX &&
+                           (b->tiles.empty() || b->tiles[0].sk == sk);
+    if (!can_defer) ISX_TRY(flush_deferred(b));
+    const size_t slot = b->tiles.size();
+    if (can_defer && b->tile_arenas.size() <= slot) {
+        b->tile_arenas.emplace_back(new DevBuf());
+        b->tile_img.emplace_back(new MatStage());
+        b->tile_mask.emplace_back(new MatStage());
+    }
+    MatStage& st_img = can_defer ? *b->tile_img[slot] : b->st_img;
+    MatStage& st_mask = can_defer ? *b->tile_mask[slot] : b->st_mask;
+    DevBuf& arena = can_defer ? *b->tile_arenas[slot] : b->tile_arena;
+    ISX_TRY(st_img.use_in(img, b->stream, "feed: img"));
+    ISX_TRY(st_mask.use_in(mask, b->stream, "feed: mask"));
+    const isx_mat& di = st_img.d;
+    const isx_mat& dm = st_mask.d;
 
     // geometry of MultiBandBlender::feed
     const int L = b->num_bands, m = 1 << L, gap = 3 * m;
@@ -751,21 +1014,29 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
         skip = (n0 * g_px_bytes(b->prec) + 255) & ~(size_t)255;
         if (b->prec == M_I16) skip += (n0 * 4 + 255) & ~(size_t)255;
     }
-    ISX_TRY(b->tile_arena.reserve(total - skip + 256));
-    layout_levels(g, L, height, width, b->prec, false, (char*)b->tile_arena.p - skip, &total);
+    ISX_TRY(arena.reserve(total - skip + 256));
+    layout_levels(g, L, height, width, b->prec, false, (char*)arena.p - skip, &total);
     g[0].img = nullptr; g[0].wgt = nullptr;
 
     int x_tl = tlnx - b->rx, y_tl = tlny - b->ry;
-    int sk = src_kind_of(img->type);
+    if (can_defer) {   // record only: blend() does all the work
+        isx_blender::TileRec r;
+        r.s0 = s0; r.sk = sk; r.x_tl = x_tl; r.y_tl = y_tl; r.width = width; r.height = height;
+        for (int k = 0; k <= L; ++k) r.g[k] = g[k];
+        r.g[0].rows = height; r.g[0].cols = width;
+        b->tiles.push_back(r);
+        b->level0_pending = true;
+        return ISX_OK;
+    }
     if (!b->cleared && b->fed.size() >= (size_t)MAX_COVER) {   // more tiles than a Cover holds: clear once, then plain RMW
         for (int k = 0; k <= L; ++k) ISX_TRY(fill_uncovered(b, k));
         b->cleared = true;
     }
     int rc;
     switch (b->prec) {
-        case M_I16: rc = run_feed_kind<M_I16>(b, sk, s0, g, L, x_tl, y_tl); break;
-        case M_F32: rc = run_feed_kind<M_F32>(b, sk, s0, g, L, x_tl, y_tl); break;
-        default: rc = run_feed_kind<M_F16>(b, sk, s0, g, L, x_tl, y_tl); break;
+        case M_I16: rc = run_feed_kind<M_I16>(b, sk, s0, g, L, x_tl, y_tl, false); break;
+        case M_F32: rc = run_feed_kind<M_F32>(b, sk, s0, g, L, x_tl, y_tl, false); break;
+        default: rc = run_feed_kind<M_F16>(b, sk, s0, g, L, x_tl, y_tl, false); break;
     }
     ISX_TRY(rc);
     if (!b->cleared) b->fed.push_back(make_int4(x_tl, y_tl, width, height));
@@ -811,6 +1082,13 @@ int isx_blender_set_num_bands(isx_blender* b, int num_bands) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_num_bands: null blender");
     ISX_CHECK_ARG(num_bands >= 0 && num_bands < MAX_LEVELS - 1, ISX_ERR_INVALID, "setNumBands(%d) out of range", num_bands);
     b->actual_num_bands = num_bands;
+    return ISX_OK;
+}
+
+int isx_blender_set_deferred_level0(isx_blender* b, int on) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_deferred_level0: null blender");
+    ISX_CHECK_ARG(!b->prepared || b->fed.empty(), ISX_ERR_STATE, "isx_blender_set_deferred_level0: tiles have already been fed in this cycle");
+    b->deferred = on != 0;
     return ISX_OK;
 }
 
@@ -866,6 +1144,7 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
     const LevelBuf& d = b->dst[level];
     *rows = d.rows; *cols = d.cols;
     size_t n = (size_t)d.rows * d.cols;
+    ISX_TRY(flush_deferred(b));                           // deferred tiles: replay them through the eager feed now
     if (!b->cleared) ISX_TRY(fill_uncovered(b, level));   // materialise the "uncovered == 0" definition
     ISX_HIP(hipStreamSynchronize(b->stream));
     if (b->prec == M_I16) {
@@ -921,6 +1200,8 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     ISX_TRY(rc);
     ISX_TRY(b->st_out.finish_out(b->stream));
     if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
+    b->tiles.clear();
+    b->level0_pending = false;
     b->prepared = false;   // dst_pyr_laplace_.clear(); dst_band_weights_.clear()
     return ISX_OK;
 }

@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
         int tlx = f2i_x86(fkey_inv(roi_keys[0])), tly = f2i_x86(fkey_inv(roi_keys[1]));
         int brx = f2i_x86(fkey_inv(roi_keys[2])), bry = f2i_x86(fkey_inv(roi_keys[3]));
         if (tlx != planned.x || tly != planned.y || brx != planned.z || bry != planned.w) atomicAdd(mismatches, 1);
+        // re-arm the keys for the next scan on this stream (saves two memset launches per tile)
+        unsigned* k = const_cast<unsigned*>(roi_keys);
+        k[0] = 0xffffffffu; k[1] = 0xffffffffu; k[2] = 0u; k[3] = 0u; k[4] = 0u;
     }
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx0 >= dw || dy >= dh) return;
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, 
         }
 }
 
+__global__ void k_roi_rearm(unsigned* keys) {
+    keys[0] = 0xffffffffu; keys[1] = 0xffffffffu; keys[2] = 0u; keys[3] = 0u; keys[4] = 0u;
+}
+
 // ---- host-side scalar restatements used for parameter set-up only (O(W+H) work) -----------------
 // K.inv() on 3x3 CV_32F: closed form in double, rounded once (OpenCV cv::invert, n == 3);
 // Mat products of CV_32F: double accumulation, rounded once (cv::gemm GEMMSingleMul<float,double>).
@@ -462,9 +469,10 @@ int set_camera(isx_warper* w, const float K[9], const float R[9]) {
 int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync_free, const int* planned) {
     hipStream_t st = w->stream;
     size_t need = 64 + (size_t)CAND_CAP * 8;
-    if (!w->scan.p) {
+    if (!w->scan.p) {   // keys armed once here; every consumer re-arms them (k_warp_img_mask / k_roi_rearm)
         ISX_TRY(w->scan.reserve(need));
         ISX_HIP(hipMemsetAsync(w->scan.p, 0, 64, st));
+        ISX_HIP(hipMemsetAsync(w->scan.p, 0xff, 2 * sizeof(unsigned), st));
     }
     unsigned* keys = (unsigned*)w->scan.p;
     int* count = (int*)(keys + 4);
@@ -499,10 +507,8 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
         return ISX_OK;
     }
-    // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0; the
-    // mismatch counter keys[5] is sticky (zeroed when the scratch buffer is created)
-    ISX_HIP(hipMemsetAsync(keys, 0xff, 2 * sizeof(unsigned), st));
-    ISX_HIP(hipMemsetAsync(keys + 2, 0, 3 * sizeof(unsigned), st));
+    // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
+    // previous consumer); the mismatch counter keys[5] is sticky
     dim3 grid(std::min(cdiv(sw, 256), 4), cdiv(sh, ROI_ROWS));
     double px = (double)sw * sh;
     ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
@@ -521,12 +527,14 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     if (!mm && f2i_host(umin - tol) == f2i_host(umin + tol) && f2i_host(umax - tol) == f2i_host(umax + tol) &&
         std::isfinite(umin) && std::isfinite(umax)) {
         roi[0] = f2i_host(umin); roi[1] = f2i_host(vmin); roi[2] = f2i_host(umax); roi[3] = f2i_host(vmax);
+        ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
         return ISX_OK;
     }
     ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, grid, dim3(256), 0, w->proj, sw, sh, keys, tol, cand, CAND_CAP, count);
     int n = 0;
     ISX_HIP(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, st));
     ISX_HIP(hipStreamSynchronize(st));
+    ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
     ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
     w->host_cand.resize((size_t)std::max(n, 1) * 2);
     if (n > 0) ISX_HIP(hipMemcpy(w->host_cand.data(), cand, (size_t)n * 8, hipMemcpyDeviceToHost));

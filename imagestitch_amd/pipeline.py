@@ -68,7 +68,7 @@ class PairStitcher:
     """One pair of tiles -> one blended mosaic, buffers resident in HBM (torch CUDA tensors)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
-                 device=0, stream=None, out_dtype="int16"):
+                 device=0, stream=None, out_dtype="int16", deferred=True):
         import torch
         self.torch = torch
         self.imgs, self.K, self.Rs = imgs, K, Rs
@@ -76,6 +76,8 @@ class PairStitcher:
         creator = CylindricalWarper if kind == "cylindrical" else SphericalWarper
         self.warper = creator(device, stream).create(scale)
         self.blender = MultiBandBlender(False, num_bands, precision, device, stream)
+        # the warped tiles and seam masks below live as long as this object: the deferred level-0 contract holds
+        self.blender.set_deferred_level0(deferred)
         self.precision, self.num_bands = precision, num_bands
         dev = torch.device("cuda", device)
         # plan: ROI per tile (detectResultRoi), output buffers, seam masks

@@ -156,6 +156,18 @@ int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, in
  * to int16 on load; results are identical to converting first and calling isx_blender_feed.   */
 int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y);
 
+/* Opt-in: deferred mode.  feed() then only RECORDS the tile and blend() does all the work: the
+ * Gaussian chains of all tiles (one launch per level), then a collapse chain whose every step
+ * gathers the tiles' Laplacians in registers.  The destination Laplacian / weight pyramid
+ * (32 B/px of read-modify-write per feed, 16 B/px read back by blend) never touches HBM.
+ * Results are identical to the eager path.  THE CONTRACT THAT CHANGES: every DEVICE mat passed to
+ * feed()/feed_u8() must stay valid and unmodified until blend() returns (OpenCV's feed() consumes
+ * its inputs immediately — the reference clears the fed images before blend(), W:305-308 — so this
+ * is not the default).  Host mats are staged in per-tile device buffers owned by the blender:
+ * nothing changes for them.  At most 8 tiles of one type are deferred; beyond that, and when
+ * isx_blender_debug_level is called, the recorded tiles are replayed through the eager path.       */
+int isx_blender_set_deferred_level0(isx_blender* b, int on);
+
 /* size of the result of blend(): dst_roi_final_ (unpadded union of the fed tiles)             */
 int isx_blender_result_size(isx_blender* b, int* width, int* height);
 /* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast

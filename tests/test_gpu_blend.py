@@ -271,3 +271,46 @@ def test_planned_pipeline_matches_sync_pipeline(gpu):
     with pytest.raises(gpu.IsxError) as e:
         ps.check_plan()
     assert e.value.code == 8
+
+
+@pytest.mark.parametrize("prec", [I16, F32, F16])
+@pytest.mark.parametrize("ntiles", [1, 2, 3, 11])
+def test_deferred_level0_identical_to_eager(gpu, oracle, prec, ntiles):
+    """isx_blender_set_deferred_level0: same results as the eager path and as the oracle; host mats,
+    device mats, level introspection in the middle (forces the eager flush), > 8 tiles (falls back)."""
+    import torch
+    rng = np.random.default_rng(77 + ntiles)
+    corners = [(41 * i - 9, (i % 3) * 13 - 6) for i in range(ntiles)]
+    sizes = [(70 + (i % 4) * 9, 55 + (i % 5) * 4) for i in range(ntiles)]
+    tiles = _tiles(rng, sizes)
+    ob = oracle.MultiBand(4, prec)
+    ob.prepare(corners, sizes)
+    for (img, mask), c in zip(tiles, corners):
+        ob.feed(img, mask, c)
+    od, om = ob.blend(False)
+    for variant in ("host", "device", "peek"):
+        mb = gpu.MultiBandBlender(False, 4, prec)
+        mb.set_deferred_level0(True)
+        mb.prepare(corners, sizes)
+        keep = []
+        for k, ((img, mask), c) in enumerate(zip(tiles, corners)):
+            if variant == "host":
+                mb.feed(img.copy(), mask.copy(), c)         # temporaries: freed right after the call
+            else:
+                ti, tm = torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()
+                keep.append((ti, tm))
+                mb.feed(ti, tm, c)
+            if variant == "peek" and k == 0:
+                lap, w = mb.level(0)                          # flushes the deferred tile eagerly
+                assert lap.shape[2] == 3
+        d, m = mb.blend()
+        d = d.cpu().numpy() if hasattr(d, "cpu") else d
+        m = m.cpu().numpy() if hasattr(m, "cpu") else m
+        assert np.array_equal(m, om), variant
+        assert np.array_equal(d, od), (variant, np.argwhere(d != od)[:4])
+    # second cycle on the same blender object re-uses the per-tile arenas
+    mb.prepare(corners, sizes)
+    for (img, mask), c in zip(tiles, corners):
+        mb.feed(img, mask, c)
+    d, m = mb.blend()
+    assert np.array_equal(d, od) and np.array_equal(m, om)
