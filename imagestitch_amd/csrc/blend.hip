@@ -63,6 +63,11 @@ struct Src0 {
     int rows, cols;     // tile size
     int top, left;      // border offsets of copyMakeBorder
     int height, width;  // padded size = level-0 size of the tile pyramid
+    // fast path of load_src0_pair (CV_8UC3 tiles below 2 GiB): 4-byte aligned bases, the misalignment of
+    // the real base pointers and the end of the addressable bytes, all as 32-bit offsets (0 = disabled)
+    const unsigned char* img_al;
+    const unsigned char* mask_al;
+    unsigned imis, mmis, iend, mend;
 };
 
 // Rectangles of one destination level that earlier feeds have already written.  prepare() does not
@@ -86,7 +91,7 @@ __device__ __forceinline__ bool covered(const Cover& c, int x, int y, int k = 0)
 
 template <int M, bool DST>
 __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
-    size_t i = (size_t)y * L.cols + x;
+    const unsigned i = (unsigned)y * (unsigned)L.cols + (unsigned)x;   // levels hold < 2^31 records (checked by prepare)
     Px<M> p;
     if constexpr (M == M_I16) {
         short4 v = ((const short4*)L.img)[i];
@@ -104,7 +109,7 @@ __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
 
 template <int M, bool DST>
 __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const Px<M>& p) {
-    size_t i = (size_t)y * L.cols + x;
+    const unsigned i = (unsigned)y * (unsigned)L.cols + (unsigned)x;
     if constexpr (M == M_I16) {
         ((short4*)L.img)[i] = make_short4((short)p.c0, (short)p.c1, (short)p.c2, 0);
         L.wgt[i] = p.w;
@@ -140,6 +145,39 @@ __device__ __forceinline__ Px<M> load_src0(const Src0& s, int x, int y) {
     bool inside = (unsigned)yr < (unsigned)s.rows && (unsigned)xr < (unsigned)s.cols;
     p.w = inside ? (float)s.mask[(size_t)yr * s.mask_step + xr] * (float)(1. / 255.) : 0.f;
     return p;
+}
+
+// Two horizontally adjacent level-0 pixels (x, x + 1) of row y.  For CV_8UC3 tiles whose two pixels
+// lie inside the image (no reflected border in between) the 6 image bytes come from ONE 12-byte
+// window and the 2 mask bytes from ONE 8-byte window, realigned with v_alignbyte — instead of eight
+// byte loads (the level-0 kernels were bound by load-instruction issue, not by HBM).
+struct U3 { unsigned x, y, z; };
+struct U2 { unsigned x, y; };
+
+template <int M, int SK>
+__device__ __forceinline__ void load_src0_pair(const Src0& s, int x, int y, Px<M>& a, Px<M>& b) {
+    if constexpr (SK == SK_U8) {
+        const int yr = y - s.top, xr = x - s.left;
+        if ((unsigned)yr < (unsigned)s.rows && xr >= 0 && xr + 1 < s.cols) {
+            const unsigned io = (unsigned)yr * (unsigned)s.img_step + (unsigned)xr * 3u + s.imis;    // offset from img_al
+            const unsigned mo = (unsigned)yr * (unsigned)s.mask_step + (unsigned)xr + s.mmis;       // offset from mask_al
+            if ((io & ~3u) + 12u <= s.iend && (mo & ~3u) + 8u <= s.mend) {
+                const U3 v = *(const U3*)(s.img_al + (io & ~3u));
+                const U2 q = *(const U2*)(s.mask_al + (mo & ~3u));
+                const unsigned lo = __builtin_amdgcn_alignbyte(v.y, v.x, io & 3u), hi = __builtin_amdgcn_alignbyte(v.z, v.y, io & 3u);
+                const unsigned mk = __builtin_amdgcn_alignbyte(q.y, q.x, mo & 3u);
+                const float inv255 = (float)(1. / 255.);
+                const int a0 = lo & 255, a1 = (lo >> 8) & 255, a2 = (lo >> 16) & 255, b0 = lo >> 24, b1 = hi & 255, b2 = (hi >> 8) & 255;
+                if constexpr (M == M_I16) { a.c0 = a0; a.c1 = a1; a.c2 = a2; b.c0 = b0; b.c1 = b1; b.c2 = b2; }
+                else { a.c0 = (float)a0; a.c1 = (float)a1; a.c2 = (float)a2; b.c0 = (float)b0; b.c1 = (float)b1; b.c2 = (float)b2; }
+                a.w = (float)(mk & 255) * inv255;
+                b.w = (float)((mk >> 8) & 255) * inv255;
+                return;
+            }
+        }
+    }
+    a = load_src0<M, SK>(s, x, y);
+    b = load_src0<M, SK>(s, x + 1, y);
 }
 
 template <int M, int SK>
@@ -197,8 +235,13 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
         int r = wv + PD_WAVES * i;
         if (r < PD_NR) {
             int iy = reflect101(2 * oy0 - 2 + r, sh);
-            A[i] = load_any<M, SK>(s0, src, cA, iy);
-            B[i] = load_any<M, SK>(s0, src, cB, iy);
+            if constexpr (SK != SK_LEVEL) {
+                if (cB == cA + 1) load_src0_pair<M, SK>(s0, cA, iy, A[i], B[i]);
+                else { A[i] = load_src0<M, SK>(s0, cA, iy); B[i] = load_src0<M, SK>(s0, cB, iy); }
+            } else {
+                A[i] = load_px<M, false>(src, cA, iy);
+                B[i] = load_px<M, false>(src, cB, iy);
+            }
         }
     }
 #pragma unroll
@@ -251,8 +294,9 @@ struct Up4 { typename WorkT<M>::t v[2][2][3]; };  // [dy][dx][channel]
 
 template <int M>
 __device__ __forceinline__ int up_row_map(int y, int h) {
-    // borderInterpolate(2*y, 2*h, REFLECT_101) / 2
-    return reflect101(2 * y, 2 * h) / 2;
+    // borderInterpolate(2*y, 2*h, REFLECT_101) / 2 for y in [-1, h]: -1 -> 1 (0 when h == 1), h -> h - 1.
+    // Rows further out only feed threads that own no pixel: any valid row will do.
+    return y < 0 ? (h > 1 ? 1 : 0) : min(y, h - 1);
 }
 
 template <int M> __device__ __forceinline__ void normalise(Px<M>& d);
@@ -283,14 +327,22 @@ __device__ __forceinline__ Up4<M> pyr_up_2x2(Px<M> (*ct)[WAVE + 2], int lane, in
     WT t0[3][3], t1[3][3];  // [row][channel]
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
-        Px<M> sm = ct[wv + rr][lane], sc = ct[wv + rr][lane + 1], sp = ct[wv + rr][lane + 2];
-        WT m[3] = {sm.c0, sm.c1, sm.c2}, c[3] = {sc.c0, sc.c1, sc.c2}, p[3] = {sp.c0, sp.c1, sp.c2};
+        const Px<M> sm = ct[wv + rr][lane], sc = ct[wv + rr][lane + 1], sp = ct[wv + rr][lane + 2];
+        t0[rr][0] = sm.c0 + sc.c0 * 6 + sp.c0; t1[rr][0] = (sc.c0 + sp.c0) * 4;
+        t0[rr][1] = sm.c1 + sc.c1 * 6 + sp.c1; t1[rr][1] = (sc.c1 + sp.c1) * 4;
+        t0[rr][2] = sm.c2 + sc.c2 * 6 + sp.c2; t1[rr][2] = (sc.c2 + sp.c2) * 4;
+    }
+    if (cx == 0 || cx == cw - 1) {   // OpenCV's explicit edge formulas (a different fp32 association): two lanes per row
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (cw == 1) { t0[rr][k] = c[k] * 8; t1[rr][k] = c[k] * 8; }
-            else if (cx == 0) { t0[rr][k] = c[k] * 6 + p[k] * 2; t1[rr][k] = (c[k] + p[k]) * 4; }
-            else if (cx == cw - 1) { t0[rr][k] = m[k] + c[k] * 7; t1[rr][k] = c[k] * 8; }
-            else { t0[rr][k] = m[k] + c[k] * 6 + p[k]; t1[rr][k] = (c[k] + p[k]) * 4; }
+        for (int rr = 0; rr < 3; ++rr) {
+            const Px<M> sm = ct[wv + rr][lane], sc = ct[wv + rr][lane + 1], sp = ct[wv + rr][lane + 2];
+            const WT m[3] = {sm.c0, sm.c1, sm.c2}, c[3] = {sc.c0, sc.c1, sc.c2}, p[3] = {sp.c0, sp.c1, sp.c2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (cw == 1) { t0[rr][k] = c[k] * 8; t1[rr][k] = c[k] * 8; }
+                else if (cx == 0) { t0[rr][k] = c[k] * 6 + p[k] * 2; t1[rr][k] = (c[k] + p[k]) * 4; }
+                else { t0[rr][k] = m[k] + c[k] * 7; t1[rr][k] = c[k] * 8; }
+            }
         }
     }
     Up4<M> u;
@@ -339,12 +391,18 @@ __device__ __forceinline__ void lap_acc_block(Px<M> (*ct)[WAVE + 2], const Src0&
     Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse.cols);
     // rectangle corners are even at every level below the top, so the 2x2 block is covered as a whole
     const bool have = covered(cov, x_tl + 2 * cx, y_tl + 2 * cy, ck);
+    Px<M> gg[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        if constexpr (SK != SK_LEVEL) load_src0_pair<M, SK>(s0, 2 * cx, 2 * cy + dy, gg[dy][0], gg[dy][1]);
+        else { gg[dy][0] = load_px<M, false>(fine, 2 * cx, 2 * cy + dy); gg[dy][1] = load_px<M, false>(fine, 2 * cx + 1, 2 * cy + dy); }
+    }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
             int fx = 2 * cx + dx, fy = 2 * cy + dy;
-            Px<M> g = load_any<M, SK>(s0, fine, fx, fy);
+            const Px<M> g = gg[dy][dx];
             typename WorkT<M>::t l0, l1, l2;
             if constexpr (M == M_I16) {  // cv::subtract saturates
                 l0 = sat_s16(g.c0 - u.v[dy][dx][0]); l1 = sat_s16(g.c1 - u.v[dy][dx][1]); l2 = sat_s16(g.c2 - u.v[dy][dx][2]);
@@ -422,6 +480,7 @@ struct OutMat {  // the caller's blend() outputs
     unsigned char* img; size_t img_step; int img_f32;
     unsigned char* mask; size_t mask_step;
     int rows, cols;  // dst_roi_final_ size
+    int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
 };
 
 template <int M>
@@ -442,6 +501,32 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
             q[2] = on ? (short)sat_s16(cvround_x86(d.c2)) : 0;
         }
     }
+}
+
+// two horizontally adjacent result pixels (x even): CV_16SC3 = 12 contiguous bytes -> three dword
+// stores when the row is 4-byte aligned (OutMat::vec), mask = one 16-bit store
+template <int M>
+__device__ __forceinline__ void write_final_pair(const OutMat& o, int x, int y, const Px<M>& d0, const Px<M>& d1) {
+    if (!o.vec || o.img_f32 || x + 1 >= o.cols) {
+        write_final<M>(o, x, y, d0);
+        write_final<M>(o, x + 1, y, d1);
+        return;
+    }
+    if (y >= o.rows) return;
+    const bool on0 = d0.w > WEIGHT_EPS, on1 = d1.w > WEIGHT_EPS;
+    int v[6];
+    if constexpr (M == M_I16) { v[0] = d0.c0; v[1] = d0.c1; v[2] = d0.c2; v[3] = d1.c0; v[4] = d1.c1; v[5] = d1.c2; }
+    else {
+        v[0] = sat_s16(cvround_x86(d0.c0)); v[1] = sat_s16(cvround_x86(d0.c1)); v[2] = sat_s16(cvround_x86(d0.c2));
+        v[3] = sat_s16(cvround_x86(d1.c0)); v[4] = sat_s16(cvround_x86(d1.c1)); v[5] = sat_s16(cvround_x86(d1.c2));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { if (!on0) v[i] = 0; if (!on1) v[3 + i] = 0; }
+    unsigned* q = (unsigned*)(o.img + (size_t)y * o.img_step + (size_t)x * 6);
+    q[0] = (unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16);
+    q[1] = (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16);
+    q[2] = (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16);
+    if (o.mask) *(unsigned short*)(o.mask + (size_t)y * o.mask_step + x) = (unsigned short)((on0 ? 255u : 0u) | (on1 ? 0xff00u : 0u));
 }
 
 // top level of blend(): normalise in place (or straight to the caller's mat when num_bands == 0)
@@ -470,13 +555,15 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
     Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse.cols);
     const bool have = covered(cov, 2 * cx, 2 * cy);   // fine-level rectangles have even corners
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int dy = 0; dy < 2; ++dy) {
+        const int fy = 2 * cy + dy;
+        if constexpr (FINAL) { if (fy >= out.rows) continue; }
+        Px<M> dd[2];
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            int fx = 2 * cx + dx, fy = 2 * cy + dy;
-            if constexpr (FINAL) { if (fx >= out.cols || fy >= out.rows) continue; }
+            const int fx = 2 * cx + dx;
             Px<M> d;
-            if (have) d = load_px<M, true>(fine, fx, fy);
+            if (have && (!FINAL || fx < out.cols)) d = load_px<M, true>(fine, fx, fy);
             else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
             normalise<M>(d);
             if constexpr (M == M_I16) {  // cv::add saturates
@@ -484,9 +571,11 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
             } else {
                 d.c0 = u.v[dy][dx][0] + d.c0; d.c1 = u.v[dy][dx][1] + d.c1; d.c2 = u.v[dy][dx][2] + d.c2;
             }
-            if constexpr (FINAL) write_final<M>(out, fx, fy, d);
-            else store_px<M, true>(fine, fx, fy, d);
+            dd[dx] = d;
         }
+        if constexpr (FINAL) write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
+        else { store_px<M, true>(fine, 2 * cx, fy, dd[0]); store_px<M, true>(fine, 2 * cx + 1, fy, dd[1]); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,13 +654,17 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
         const int cw = ts.coarse[t].cols, ch = ts.coarse[t].rows;
         if ((unsigned)lcx < (unsigned)cw && (unsigned)lcy < (unsigned)ch) {
             Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, lcx, cw);
+            Px<M> gg[2][2];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                if constexpr (FINE0) load_src0_pair<M, SK>(ts.s0[t], 2 * lcx, 2 * lcy + dy, gg[dy][0], gg[dy][1]);
+                else { gg[dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
+            }
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    Px<M> g;
-                    if constexpr (FINE0) g = load_src0<M, SK>(ts.s0[t], 2 * lcx + dx, 2 * lcy + dy);
-                    else g = load_px<M, false>(ts.fine[t], 2 * lcx + dx, 2 * lcy + dy);
+                    const Px<M> g = gg[dy][dx];
                     if constexpr (M == M_I16) {
                         acc[dy][dx][0] = wrap_s16(acc[dy][dx][0] + f2s_x86((float)sat_s16(g.c0 - u.v[dy][dx][0]) * g.w));
                         acc[dy][dx][1] = wrap_s16(acc[dy][dx][1] + f2s_x86((float)sat_s16(g.c1 - u.v[dy][dx][1]) * g.w));
@@ -592,11 +685,11 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
     if (cx >= coarse_out.cols || cy >= coarse_out.rows) return;
     Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse_out.cols);
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int dy = 0; dy < 2; ++dy) {
+        const int fy = 2 * cy + dy;
+        Px<M> dd[2];
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            const int fx = 2 * cx + dx, fy = 2 * cy + dy;
-            if constexpr (FINE0) { if (fx >= out.cols || fy >= out.rows) continue; }
             Px<M> d;
             d.c0 = acc[dy][dx][0]; d.c1 = acc[dy][dx][1]; d.c2 = acc[dy][dx][2]; d.w = accw[dy][dx];
             normalise<M>(d);
@@ -605,9 +698,11 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
             } else {
                 d.c0 = u.v[dy][dx][0] + d.c0; d.c1 = u.v[dy][dx][1] + d.c1; d.c2 = u.v[dy][dx][2] + d.c2;
             }
-            if constexpr (FINE0) write_final<M>(out, fx, fy, d);
-            else store_px<M, true>(fine_out, fx, fy, d);
+            dd[dx] = d;
         }
+        if constexpr (FINE0) write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
+        else { store_px<M, true>(fine_out, 2 * cx, fy, dd[0]); store_px<M, true>(fine_out, 2 * cx + 1, fy, dd[1]); }
+    }
 }
 
 // zero every pixel of a level that no fed tile covers (only needed when more than MAX_COVER tiles are
@@ -828,7 +923,9 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         return ts;
     };
     const double gin0 = src_px_bytes(SK) + 1.0;
-    // 1. Gaussian chains: one launch per level for all tiles
+    // 1. Gaussian chains: one launch per level for all tiles.  (Per-tile chains on side streams, started
+    //    by feed() to overlap with the next tile's VALU-bound warp, were measured: no gain — a kernel that
+    //    fills every wave slot leaves nothing for a concurrent one — so the simpler form stays.)
     for (int k = 0; k < L; ++k) {
         TileSet ts = base(k);
         int maxc = 0, maxr = 0;
@@ -1003,6 +1100,13 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     s0.rows = img->rows; s0.cols = img->cols;
     s0.top = tl_y - tlny; s0.left = tl_x - tlnx;
     s0.height = height; s0.width = width;
+    s0.imis = (unsigned)((uintptr_t)s0.img & 3); s0.mmis = (unsigned)((uintptr_t)s0.mask & 3);
+    s0.img_al = s0.img - s0.imis; s0.mask_al = s0.mask - s0.mmis;
+    s0.iend = 0; s0.mend = 0;
+    if (img->type == ISX_8UC3 && (unsigned long long)di.step * img->rows < (1ull << 31) && (unsigned long long)dm.step * img->rows < (1ull << 31)) {
+        s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * 3) + s0.imis;
+        s0.mend = (unsigned)((size_t)(img->rows - 1) * dm.step + (size_t)img->cols) + s0.mmis;
+    }
 
     LevelBuf g[MAX_LEVELS];
     size_t total = 0;
@@ -1191,6 +1295,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
     o.rows = b->fh; o.cols = b->fw;
+    o.vec = ((uintptr_t)o.img % 4 == 0) && (o.img_step % 4 == 0) && (!o.mask || (((uintptr_t)o.mask % 2 == 0) && (o.mask_step % 2 == 0)));
     int rc;
     switch (b->prec) {
         case M_I16: rc = run_blend<M_I16>(b, o); break;

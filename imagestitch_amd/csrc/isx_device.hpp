@@ -15,23 +15,25 @@ constexpr int WAVE = 64;
 
 // cv::borderInterpolate, BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba) and BORDER_REFLECT
 // (fedcba|abcdefgh|hgfedcb).  Loop form: any p is legal, n == 1 returns 0.
-__device__ __forceinline__ int reflect101(int p, int n) {
-    if ((unsigned)p < (unsigned)n) return p;
+// One reflection is done branch-free (the common case: borders narrower than the image); the loop
+// for repeated reflections (tiny images) is kept out of line so that it does not bloat hot kernels.
+__device__ __noinline__ int reflect_loop(int p, int n, int delta) {
     if (n == 1) return 0;
     do {
-        if (p < 0) p = -p;
-        else p = 2 * n - 2 - p;
+        if (p < 0) p = -p - 1 + delta;
+        else p = 2 * n - 1 - p - delta;
     } while ((unsigned)p >= (unsigned)n);
     return p;
 }
+__device__ __forceinline__ int reflect101(int p, int n) {
+    int q = p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p);
+    if ((unsigned)q >= (unsigned)n) q = reflect_loop(p, n, 1);
+    return q;
+}
 __device__ __forceinline__ int reflect(int p, int n) {
-    if ((unsigned)p < (unsigned)n) return p;
-    if (n == 1) return 0;
-    do {
-        if (p < 0) p = -p - 1;
-        else p = 2 * n - 1 - p;
-    } while ((unsigned)p >= (unsigned)n);
-    return p;
+    int q = p < 0 ? -p - 1 : (p >= n ? 2 * n - 1 - p : p);
+    if ((unsigned)q >= (unsigned)n) q = reflect_loop(p, n, 0);
+    return q;
 }
 // generic border: returns -1 for BORDER_CONSTANT outside
 __device__ __forceinline__ int border_index(int p, int n, int border) {

@@ -377,6 +377,13 @@ __global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, 
         }
 }
 
+__global__ void k_roi_check_rearm(unsigned* keys, int4 planned, int* mismatches) {
+    int tlx = f2i_x86(fkey_inv(keys[0])), tly = f2i_x86(fkey_inv(keys[1]));
+    int brx = f2i_x86(fkey_inv(keys[2])), bry = f2i_x86(fkey_inv(keys[3]));
+    if (tlx != planned.x || tly != planned.y || brx != planned.z || bry != planned.w) atomicAdd(mismatches, 1);
+    keys[0] = 0xffffffffu; keys[1] = 0xffffffffu; keys[2] = 0u; keys[3] = 0u; keys[4] = 0u;
+}
+
 __global__ void k_roi_rearm(unsigned* keys) {
     keys[0] = 0xffffffffu; keys[1] = 0xffffffffu; keys[2] = 0u; keys[3] = 0u; keys[4] = 0u;
 }
@@ -434,6 +441,12 @@ struct isx_warper {
     hipStream_t stream = nullptr;
     // device scratch
     DevBuf tabs, scan;       // tables; {keys[4], count, mismatches, cand...}
+    // planned (sync-free) warps run their ROI scan + device-side check on a side stream: the scan is
+    // VALU-bound (atan2f / sqrt / div per source pixel) and overlaps with the memory-bound kernels of the
+    // main stream; nothing on the main stream depends on it (isx_warper_plan_status joins both).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_warp = nullptr;   // recorded on the main stream after a planned warp: its scan starts behind it
+    DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
     MatStage st_src, st_mask, st_dst, st_dmask, st_x, st_y;
     // table cache key
     int tab_kind = -1, tab_roi[4] = {0, 0, 0, 0};
@@ -507,12 +520,31 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
         return ISX_OK;
     }
+    if (sync_free) {
+        if (!w->side) {
+            ISX_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+            ISX_HIP(hipEventCreateWithFlags(&w->ev_warp, hipEventDisableTiming));
+        }
+        // the verification scan is VALU-bound like the warp kernel itself: start it behind this call's warp
+        // kernel so that it overlaps with the memory-bound pyramid kernels that follow on the main stream
+        ISX_HIP(hipEventRecord(w->ev_warp, st));
+        ISX_HIP(hipStreamWaitEvent(w->side, w->ev_warp, 0));
+        if (!w->scan_side.p) {
+            ISX_TRY(w->scan_side.reserve(64));
+            ISX_HIP(hipMemsetAsync(w->scan_side.p, 0, 64, w->side));
+            ISX_HIP(hipMemsetAsync(w->scan_side.p, 0xff, 2 * sizeof(unsigned), w->side));
+        }
+        unsigned* sk = (unsigned*)w->scan_side.p;
+        dim3 sgrid(std::min(cdiv(sw, 256), 4), cdiv(sh, ROI_ROWS));
+        ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, w->proj, sw, sh, sk);
+        ISX_LAUNCH("roi_check", 0.0, w->side, k_roi_check_rearm, dim3(1), dim3(1), 0, sk, make_int4(planned[0], planned[1], planned[2], planned[3]), (int*)(sk + 5));
+        return ISX_OK;
+    }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
     // previous consumer); the mismatch counter keys[5] is sticky
     dim3 grid(std::min(cdiv(sw, 256), 4), cdiv(sh, ROI_ROWS));
     double px = (double)sw * sh;
     ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
-    if (sync_free) return ISX_OK;   // the fused warp kernel compares keys with the plan (k_warp_img_mask)
     // candidate pass: a tolerance of 64 ulp of the largest |u| covers the device atan2f (<= 2 ulp)
     // vs any faithful host atan2f (<= 2 ulp) with a wide margin
     unsigned hk[4];
@@ -595,10 +627,10 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(set_camera(w, K, R));
     int roi[4];
-    if (planned) {
-        ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, true, planned));
-        std::copy(planned, planned + 4, roi);
-    } else ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, false, nullptr));
+    ISX_CHECK_ARG(!(planned && w->kind == ISX_WARP_SPHERICAL), ISX_ERR_UNSUPPORTED,
+                  "planned warp: the spherical ROI is computed on the host; use isx_warper_warp_with_mask");
+    if (planned) std::copy(planned, planned + 4, roi);   // the verifying scan is enqueued behind the warp kernel (below)
+    else ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, false, nullptr));
     ISX_TRY(check_roi_sane(roi));
     const int dw = roi[2] - roi[0] + 1, dh = roi[3] - roi[1] + 1;   // dst.create(roi.height + 1, roi.width + 1)  W:150
     ISX_CHECK_ARG(dst->rows == dh && dst->cols == dw, ISX_ERR_SIZE, "warp: dst is %dx%d, the warped tile is %dx%d (query isx_warper_roi first)",
@@ -636,9 +668,11 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         const isx_mat& dm = w->st_dmask.d;
         const bool vec = ((uintptr_t)dd.data % 4 == 0) && (dd.step % 4 == 0) && ((uintptr_t)dm.data % 4 == 0) && (dm.step % 4 == 0);
         dim3 grid4(cdiv(dw, 256), cdiv(dh, 4));
-        const unsigned* plan_keys = planned ? (const unsigned*)w->scan.p : nullptr;
-        int* plan_mism = planned ? (int*)w->scan.p + 5 : nullptr;
-        const int4 plan4 = planned ? make_int4(planned[0], planned[1], planned[2], planned[3]) : make_int4(0, 0, 0, 0);
+        // sync path: the scan ran on this stream and the host has consumed its keys; the kernel re-arms them.
+        // planned path: scan + check run on the side stream, nothing to do here.
+        const unsigned* plan_keys = nullptr;
+        int* plan_mism = nullptr;
+        const int4 plan4 = make_int4(0, 0, 0, 0);
 #define ISX_WARP_FUSED(O16, V)                                                                                                   \
         ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_img_mask<O16, V>), grid4, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0, \
                    (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
@@ -646,6 +680,10 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         else { if (vec) ISX_WARP_FUSED(false, true); else ISX_WARP_FUSED(false, false); }
 #undef ISX_WARP_FUSED
         ISX_TRY(w->st_dmask.finish_out(st));
+        if (planned) {
+            int scratch[4];
+            ISX_TRY(detect_roi(w, src->cols, src->rows, scratch, nullptr, true, planned));
+        }
     } else {
         ISX_CHECK_ARG(dst->type == src->type, ISX_ERR_TYPE, "warp: dst type %s differs from src type %s", type_name(dst->type), type_name(src->type));
         ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR, ISX_ERR_UNSUPPORTED, "warp: interpolation %d (only NEAREST and LINEAR)", interp);
@@ -690,6 +728,7 @@ int isx_warper_destroy(isx_warper* w) {
     if (!w) return ISX_OK;
     (void)hipSetDevice(w->device);
     (void)hipStreamSynchronize(w->stream);
+    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); (void)hipEventDestroy(w->ev_warp); }
     delete w;
     return ISX_OK;
 }
@@ -766,10 +805,11 @@ int isx_warper_plan_status(isx_warper* w, int* mismatches) {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && mismatches != nullptr, ISX_ERR_INVALID, "plan_status: null argument");
     *mismatches = 0;
-    if (!w->scan.p) return ISX_OK;
+    if (!w->scan_side.p) return ISX_OK;
     ISX_HIP(hipSetDevice(w->device));
+    ISX_HIP(hipStreamSynchronize(w->side));
     ISX_HIP(hipStreamSynchronize(w->stream));
-    ISX_HIP(hipMemcpy(mismatches, (int*)w->scan.p + 5, sizeof(int), hipMemcpyDeviceToHost));
+    ISX_HIP(hipMemcpy(mismatches, (int*)w->scan_side.p + 5, sizeof(int), hipMemcpyDeviceToHost));
     if (*mismatches) return fail(ISX_ERR_PLAN, "planned warp: %d run(s) produced a ROI that differs from the planned one", *mismatches);
     return ISX_OK;
 }

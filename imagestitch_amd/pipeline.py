@@ -96,8 +96,10 @@ class PairStitcher:
         self.seam = [torch.from_numpy(s).to(dev) for s in seam]
         self.roi_pad, (fw, fh), self.L = prepare_geometry(self.corners, self.sizes, num_bands)
         odt = {"int16": torch.int16, "float32": torch.float32}[out_dtype]
-        self.out = torch.empty((fh, fw, 3), dtype=odt, device=dev)
-        self.out_mask = torch.empty((fh, fw), dtype=torch.uint8, device=dev)
+        es = 2 if out_dtype == "int16" else 4
+        opitch = (fw * 3 * es + 63) // 64 * 64
+        self.out = torch.empty((fh * opitch // es,), dtype=odt, device=dev).as_strided((fh, fw, 3), (opitch // es, 3, 1))
+        self.out_mask = pitched(fh, fw, (fh, fw), (1,))
 
     def step(self):
         """Steady-state step without host round trips: the ROI scan (detectResultRoi) still runs on the
