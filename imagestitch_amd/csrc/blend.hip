@@ -941,33 +941,35 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
     }
     // 2. top level: gather + normalise into the collapsed pyramid's level L
+    //    (algorithmic bytes of the launches below = the traffic their own dataflow needs: every input
+    //    record read once, every output written once; the destination pyramid of the eager path and of
+    //    SURVEY's model does not exist here)
     {
         TileSet ts = base(L);
-        double bytes = (double)d[L].rows * d[L].cols * (alg_d(prec) + alg_d_rgb(prec));
+        double bytes = (double)d[L].rows * d[L].cols * alg_d_rgb(prec);
         for (int t = 0; t < n; ++t) {
             ts.coarse[t] = b->tiles[t].g[L];
-            bytes += (double)ts.w[t] * ts.h[t] * (alg_g(prec) + 2.0 * alg_d(prec));
+            bytes += (double)ts.w[t] * ts.h[t] * alg_g(prec);
         }
         dim3 grid(cdiv(d[L].cols, 64), cdiv(d[L].rows, 4));
         ISX_LAUNCH("top_gather", bytes, st, (k_top_gather<M>), grid, dim3(256), 0, ts, d[L]);
     }
-    // 3. collapse chain; each step gathers the tiles' Laplacians of its fine level in registers.
-    //    Algorithmic bytes = SURVEY-model bytes of the work the launch replaces: the accumulate of level
-    //    k-1 for every tile + the collapse step k -> k-1.
+    // 3. collapse chain; each step gathers the tiles' Laplacians of its fine level in registers
     for (int k = L; k >= 1; --k) {
         TileSet ts = base(k - 1);
-        double bytes = (double)d[k].rows * d[k].cols * alg_d_rgb(prec);
+        double bytes = (double)d[k].rows * d[k].cols * alg_d_rgb(prec);                      // out_k as pyrUp source
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
             ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
-            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * ((k == 1 ? gin0 : alg_g(prec)) + 2.0 * alg_d(prec)) + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);
+            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
+                   + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
         }
         dim3 grid(cdiv(d[k].cols, WAVE), cdiv(d[k].rows, UP_TY));
         if (k == 1) {
-            bytes += (double)out.rows * out.cols * (alg_d(prec) + (out.img_f32 ? 13.0 : 7.0));
+            bytes += (double)out.rows * out.cols * (out.img_f32 ? 13.0 : 7.0);                  // result + mask
             ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true>), grid, dim3(256), 0, ts, d[1], d[0], out);
         } else {
-            bytes += (double)d[k - 1].rows * d[k - 1].cols * (alg_d(prec) + alg_d_rgb(prec));
+            bytes += (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec);                   // out_{k-1}
             ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
         }
     }

@@ -313,32 +313,43 @@ __global__ __launch_bounds__(256) void k_build_maps(Proj p, MapTabs t, float* xm
 }
 
 // ---- detectResultRoi (W:64-88): full forward scan, min / max reduction ----------------------------
-// mapForward (W:36-45).  v is bit-exact (IEEE mul/add/sqrt/div).  u goes through atan2f, whose
-// device implementation differs from the host libm's by a few ulp: the scan only has to find the
-// extremum CANDIDATES, which the host then re-evaluates with its own atan2f (detect_roi).
-__device__ __forceinline__ void map_forward_cyl(const Proj& p, float x, float y, float& u, float& v) {
-    float x_ = p.r_kinv[0] * x + p.r_kinv[1] * y + p.r_kinv[2];
-    float y_ = p.r_kinv[3] * x + p.r_kinv[4] * y + p.r_kinv[5];
-    float z_ = p.r_kinv[6] * x + p.r_kinv[7] * y + p.r_kinv[8];
-    u = p.scale * atan2f(x_, z_);
-    v = p.scale * y_ / sqrtf(x_ * x_ + z_ * z_);
+// detectResultRoi scans EVERY source pixel through mapForward (W:72-81): 8.3 M atan2f + sqrtf + divisions
+// per 4K tile, VALU-bound.  Only the four extrema matter, so the scan ranks pixels by two cheap
+// strictly monotone stand-ins instead (about 40 VALU instructions per pixel instead of 90):
+//   u = scale * atan2f(x_, z_)         ~  d = "diamond angle" of (x_, z_) in (-2, 2]   (one v_rcp_f32)
+//   v = scale * y_ / sqrtf(x_^2+z_^2)  ~  q = y_ * rsq(x_^2 + z_^2)                     (one v_rsq_f32)
+// The extremal pixels found this way (plus every pixel within a tolerance that covers the stand-ins'
+// few-ulp error) are then evaluated EXACTLY: on the host with the host's own libm in the synchronous
+// path (= what the reference binary computes), or compared with proxy-space thresholds of the planned
+// ROI in the sync-free path.
+__device__ __forceinline__ void forward_proxy(const Proj& p, float x, float y, float& d, float& q) {
+    const float x_ = p.r_kinv[0] * x + p.r_kinv[1] * y + p.r_kinv[2];
+    const float y_ = p.r_kinv[3] * x + p.r_kinv[4] * y + p.r_kinv[5];
+    const float z_ = p.r_kinv[6] * x + p.r_kinv[7] * y + p.r_kinv[8];
+    const float ax = fabsf(x_), az = fabsf(z_);
+    const float t = ax * __builtin_amdgcn_rcpf(ax + az);      // |x_| / (|x_| + |z_|) in [0, 1]
+    d = copysignf(z_ >= 0.f ? t : 2.f - t, x_);
+    q = y_ * __builtin_amdgcn_rsqf(x_ * x_ + z_ * z_);
 }
 
-// keys[0..3] = min u, min v, max u, max v (as fkey).  One block scans a band of ROI_ROWS rows,
-// reduces through shuffles + LDS and touches the four global keys only when it improves them
-// (520 K contended atomics cost 3 ms on this part; a few hundred cost nothing).
-constexpr int ROI_ROWS = 8;
+// keys[0..3] = min d, min q, max d, max q (as fkey).  One block scans a band of ROI_ROWS rows, reduces
+// through shuffles + LDS and touches the four global keys only when it improves them (520 K contended
+// atomics cost 3 ms on this part; a few hundred cost nothing).
+constexpr int ROI_ROWS = 16;
 __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsigned* keys) {
     __shared__ float red[4][4];
     float tl_u = 3.402823466e+38f, tl_v = 3.402823466e+38f, br_u = -3.402823466e+38f, br_v = -3.402823466e+38f;
     const int y0 = blockIdx.y * ROI_ROWS, y1 = min(y0 + ROI_ROWS, sh);
-    for (int y = y0; y < y1; ++y)
-        for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x < sw) {
+#pragma unroll 4
+        for (int y = y0; y < y1; ++y) {
             float u, v;
-            map_forward_cyl(p, (float)x, (float)y, u, v);
-            tl_u = (u < tl_u) ? u : tl_u; tl_v = (v < tl_v) ? v : tl_v;     // (std::min)(tl, u): NaN never wins
+            forward_proxy(p, (float)x, (float)y, u, v);
+            tl_u = (u < tl_u) ? u : tl_u; tl_v = (v < tl_v) ? v : tl_v;     // NaN never wins, as with (std::min)(tl, u)
             br_u = (br_u < u) ? u : br_u; br_v = (br_v < v) ? v : br_v;
         }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         tl_u = fminf(tl_u, __shfl_xor(tl_u, o)); tl_v = fminf(tl_v, __shfl_xor(tl_v, o));
@@ -360,27 +371,33 @@ __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsign
     }
 }
 
-// second pass: collect every source pixel whose u is within `tol` of an extremum, so the host can
-// re-evaluate exactly those with its own atan2f (what the reference code would have computed)
-__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, float tol,
+// second pass of the synchronous path: every pixel whose stand-in is within the tolerance of one of the
+// four extrema; the host re-evaluates exactly those with mapForward and its own libm
+__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, float tol_d, float tol_q,
                                                         int* cand_xy, int cap, int* count) {
-    const float umin = fkey_inv(keys[0]), umax = fkey_inv(keys[2]);
+    const float dmin = fkey_inv(keys[0]), qmin = fkey_inv(keys[1]), dmax = fkey_inv(keys[2]), qmax = fkey_inv(keys[3]);
     const int y0 = blockIdx.y * ROI_ROWS, y1 = min(y0 + ROI_ROWS, sh);
     for (int y = y0; y < y1; ++y)
         for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
-            float u, v;
-            map_forward_cyl(p, (float)x, (float)y, u, v);
-            if (u <= umin + tol || u >= umax - tol) {
+            float d, q;
+            forward_proxy(p, (float)x, (float)y, d, q);
+            if (d <= dmin + tol_d || d >= dmax - tol_d || q <= qmin + tol_q || q >= qmax - tol_q) {
                 int i = atomicAdd(count, 1);
                 if (i < cap) { cand_xy[2 * i] = x; cand_xy[2 * i + 1] = y; }
             }
         }
 }
 
-__global__ void k_roi_check_rearm(unsigned* keys, int4 planned, int* mismatches) {
-    int tlx = f2i_x86(fkey_inv(keys[0])), tly = f2i_x86(fkey_inv(keys[1]));
-    int brx = f2i_x86(fkey_inv(keys[2])), bry = f2i_x86(fkey_inv(keys[3]));
-    if (tlx != planned.x || tly != planned.y || brx != planned.z || bry != planned.w) atomicAdd(mismatches, 1);
+// sync-free path: the scanned extrema must lie inside the stand-in intervals of the planned ROI
+// (lo/hi: min d, min q, max d, max q; margins already applied by the host)
+struct RoiBounds { float lo[4], hi[4]; };
+__global__ void k_roi_check_rearm(unsigned* keys, RoiBounds b, int* mismatches) {
+    bool ok = true;
+    for (int k = 0; k < 4; ++k) {
+        const float v = fkey_inv(keys[k]);
+        ok = ok && v >= b.lo[k] && v <= b.hi[k];
+    }
+    if (!ok) atomicAdd(mismatches, 1);
     keys[0] = 0xffffffffu; keys[1] = 0xffffffffu; keys[2] = 0u; keys[3] = 0u; keys[4] = 0u;
 }
 
@@ -431,6 +448,25 @@ void map_forward_host(const Proj& p, float x, float y, float& u, float& v) {
         float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
         v = p.scale * (PI_F - acosf(w == w ? w : 0));
     }
+}
+
+// the stand-ins of forward_proxy as functions of u and v (monotone increasing), in double
+double proxy_d_of_u(double u, double scale) {
+    double th = u / scale;
+    const double pi = 3.14159265358979323846;
+    th = std::max(-pi, std::min(pi, th));
+    double sx = std::sin(th), cz = std::cos(th);
+    double t = std::fabs(sx) / (std::fabs(sx) + std::fabs(cz));
+    double dd = cz >= 0.0 ? t : 2.0 - t;
+    return th < 0.0 ? -dd : dd;
+}
+double proxy_q_of_v(double v, double scale) { return v / scale; }
+
+// static_cast<int>(extremum) == bound  <=>  extremum in (bound - 1, bound] / [bound, bound + 1) / (-1, 1)
+void trunc_interval(int bound, double& lo, double& hi) {
+    if (bound < 0) { lo = bound - 1.0; hi = bound; }
+    else if (bound > 0) { lo = bound; hi = bound + 1.0; }
+    else { lo = -1.0; hi = 1.0; }
 }
 
 }  // namespace
@@ -535,51 +571,56 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
             ISX_HIP(hipMemsetAsync(w->scan_side.p, 0xff, 2 * sizeof(unsigned), w->side));
         }
         unsigned* sk = (unsigned*)w->scan_side.p;
-        dim3 sgrid(std::min(cdiv(sw, 256), 4), cdiv(sh, ROI_ROWS));
+        dim3 sgrid(cdiv(sw, 256), cdiv(sh, ROI_ROWS));   // ~8 K waves at 4K: one full-occupancy round
         ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, w->proj, sw, sh, sk);
-        ISX_LAUNCH("roi_check", 0.0, w->side, k_roi_check_rearm, dim3(1), dim3(1), 0, sk, make_int4(planned[0], planned[1], planned[2], planned[3]), (int*)(sk + 5));
+        RoiBounds rb;
+        for (int k = 0; k < 4; ++k) {
+            double lo, hi;
+            trunc_interval(planned[k], lo, hi);
+            const bool is_u = (k == 0 || k == 2);
+            double plo = is_u ? proxy_d_of_u(lo, w->scale) : proxy_q_of_v(lo, w->scale);
+            double phi = is_u ? proxy_d_of_u(hi, w->scale) : proxy_q_of_v(hi, w->scale);
+            // margin: the stand-ins carry a few ulp of error; an extremum this close to an integer boundary is
+            // not flagged (the check is a guard against a stale plan, not a proof)
+            const double m = 4e-6 * std::max(1.0, std::max(std::fabs(plo), std::fabs(phi)));
+            rb.lo[k] = (float)(plo - m); rb.hi[k] = (float)(phi + m);
+        }
+        ISX_LAUNCH("roi_check", 0.0, w->side, k_roi_check_rearm, dim3(1), dim3(1), 0, sk, rb, (int*)(sk + 5));
         return ISX_OK;
     }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
     // previous consumer); the mismatch counter keys[5] is sticky
-    dim3 grid(std::min(cdiv(sw, 256), 4), cdiv(sh, ROI_ROWS));
+    dim3 grid(cdiv(sw, 256), cdiv(sh, ROI_ROWS));
     double px = (double)sw * sh;
     ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
-    // candidate pass: a tolerance of 64 ulp of the largest |u| covers the device atan2f (<= 2 ulp)
-    // vs any faithful host atan2f (<= 2 ulp) with a wide margin
+    // The scan ranked the pixels by the stand-ins (d, q).  Collect every pixel whose stand-in is within
+    // a tolerance of one of the four extrema — the tolerance covers the few-ulp error of v_rcp / v_rsq and
+    // of the host's own atan2f many times over — and evaluate mapForward on exactly those with the host's
+    // libm: the result is what the reference code computes on this host.
     unsigned hk[4];
     ISX_HIP(hipMemcpyAsync(hk, keys, sizeof(hk), hipMemcpyDeviceToHost, st));
     ISX_HIP(hipStreamSynchronize(st));
-    float umin = fkey_inv(hk[0]), vmin = fkey_inv(hk[1]), umax = fkey_inv(hk[2]), vmax = fkey_inv(hk[3]);
-    float amax = std::max(std::fabs(umin), std::fabs(umax));
-    float tol = 64.f * (std::nextafter(amax, std::numeric_limits<float>::infinity()) - amax);
-    // The host's extrema lie within tol of the scanned ones.  When that interval cannot straddle an
-    // integer the ROI is already decided and the refinement pass is skipped (it always runs when the
-    // caller asked for the float extrema themselves).
-    if (!mm && f2i_host(umin - tol) == f2i_host(umin + tol) && f2i_host(umax - tol) == f2i_host(umax + tol) &&
-        std::isfinite(umin) && std::isfinite(umax)) {
-        roi[0] = f2i_host(umin); roi[1] = f2i_host(vmin); roi[2] = f2i_host(umax); roi[3] = f2i_host(vmax);
-        ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
-        return ISX_OK;
-    }
-    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, grid, dim3(256), 0, w->proj, sw, sh, keys, tol, cand, CAND_CAP, count);
+    const float qmin = fkey_inv(hk[1]), qmax = fkey_inv(hk[3]);
+    const float tol_d = 7.62939453125e-06f;                                   // 2^-17 of a (-2, 2] range
+    const float tol_q = 4e-6f * std::max(std::fabs(qmin), std::fabs(qmax)) + 1e-9f;
+    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, grid, dim3(256), 0, w->proj, sw, sh, keys, tol_d, tol_q, cand, CAND_CAP, count);
     int n = 0;
     ISX_HIP(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, st));
     ISX_HIP(hipStreamSynchronize(st));
     ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
     ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
-    w->host_cand.resize((size_t)std::max(n, 1) * 2);
-    if (n > 0) ISX_HIP(hipMemcpy(w->host_cand.data(), cand, (size_t)n * 8, hipMemcpyDeviceToHost));
-    float hu_min = std::numeric_limits<float>::max(), hu_max = -hu_min;
+    ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the %d x %d source (bad K / R / scale?)", sw, sh);
+    w->host_cand.resize((size_t)n * 2);
+    ISX_HIP(hipMemcpy(w->host_cand.data(), cand, (size_t)n * 8, hipMemcpyDeviceToHost));
+    float tl_uf = std::numeric_limits<float>::max(), tl_vf = tl_uf, br_uf = -tl_uf, br_vf = -tl_uf;     // W:66-69
     for (int i = 0; i < n; ++i) {
-        int x = w->host_cand[2 * i], y = w->host_cand[2 * i + 1];
         float u, v;
-        map_forward_host(w->proj, (float)x, (float)y, u, v);
-        hu_min = (std::min)(hu_min, u); hu_max = (std::max)(hu_max, u);
+        map_forward_host(w->proj, (float)w->host_cand[2 * i], (float)w->host_cand[2 * i + 1], u, v);
+        tl_uf = (std::min)(tl_uf, u); tl_vf = (std::min)(tl_vf, v);                                    // W:77-78
+        br_uf = (std::max)(br_uf, u); br_vf = (std::max)(br_vf, v);
     }
-    if (n == 0) { hu_min = umin; hu_max = umax; }   // all-NaN scan: keep the sentinels
-    if (mm) { mm[0] = hu_min; mm[1] = vmin; mm[2] = hu_max; mm[3] = vmax; }
-    roi[0] = f2i_host(hu_min); roi[1] = f2i_host(vmin); roi[2] = f2i_host(hu_max); roi[3] = f2i_host(vmax);   // W:83-86
+    if (mm) { mm[0] = tl_uf; mm[1] = tl_vf; mm[2] = br_uf; mm[3] = br_vf; }
+    roi[0] = f2i_host(tl_uf); roi[1] = f2i_host(tl_vf); roi[2] = f2i_host(br_uf); roi[3] = f2i_host(br_vf);   // W:83-86
     return ISX_OK;
 }
 
