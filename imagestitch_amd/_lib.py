@@ -52,12 +52,14 @@ _SIGS = {
     "isx_warper_warp_with_mask": [C.c_void_p, _MP, _MP, _F9, _F9, _MP, _MP, _IP],
     "isx_warper_warp_with_mask_planned": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],
     "isx_warper_plan_status": [C.c_void_p, _IP],
+    "isx_warper_join": [C.c_void_p],
     "isx_blender_create": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "isx_blender_destroy": [C.c_void_p],
     "isx_blender_set_stream": [C.c_void_p, C.c_void_p],
     "isx_blender_set_num_bands": [C.c_void_p, C.c_int],
     "isx_blender_num_bands": [C.c_void_p, _IP],
     "isx_blender_set_deferred_level0": [C.c_void_p, C.c_int],
+    "isx_blender_set_overlap": [C.c_void_p, C.c_int],
     "isx_blender_prepare": [C.c_void_p, C.c_int, _IP, _IP],
     "isx_blender_prepare_roi": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
     "isx_blender_feed": [C.c_void_p, _MP, _MP, C.c_int, C.c_int],

@@ -41,6 +41,9 @@ class MultiBandBlender:
         """Opt-in (see include/imagestitch_hip.h): fed device mats must then stay valid until blend() returns."""
         check(self._lib.isx_blender_set_deferred_level0(self._h, int(bool(on))))
 
+    def set_overlap(self, on=True):
+        check(self._lib.isx_blender_set_overlap(self._h, int(bool(on))))
+
     def setNumBands(self, n):
         check(self._lib.isx_blender_set_num_bands(self._h, int(n)))
 

@@ -754,6 +754,13 @@ struct isx_blender {
     std::vector<TileRec> tiles;
     std::vector<std::unique_ptr<DevBuf>> tile_arenas;      // one per recorded tile (their pyramids must outlive feed)
     std::vector<std::unique_ptr<MatStage>> tile_img, tile_mask;   // staging of host mats, one per recorded tile
+    // overlap mode (isx_blender_set_overlap): a recorded tile's Gaussian chain starts right away on its own
+    // side stream (it only needs the tile), so the memory-bound chain of tile t runs under the VALU-bound
+    // warp of tile t+1 that the caller enqueues next on the main stream; blend() joins the side streams
+    bool overlap = false;
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> ev_ready, ev_done;
+    std::vector<char> chain_on_side;   // per recorded tile: its chain was launched by feed()
 };
 
 namespace {
@@ -880,11 +887,45 @@ Cover make_cover_n(const isx_blender* b, int level, int n) {
     return c;
 }
 
-// Deferred tiles have had no kernel run for them.  When the cycle cannot stay deferred (level
+template <int M, int SK>
+int launch_down_chain_t(isx_blender* b, const isx_blender::TileRec& r, hipStream_t st) {
+    const int L = b->num_bands, prec = M;
+    for (int k = 0; k < L; ++k) {
+        dim3 grid(cdiv(r.g[k + 1].cols, PD_OW), cdiv(r.g[k + 1].rows, PD_TY));
+        double bytes = (double)r.g[k].rows * r.g[k].cols * (k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
+        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down<M, SK>), grid, dim3(512), 0, r.s0, r.g[0], r.g[1]);
+        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down<M, SK_LEVEL>), grid, dim3(512), 0, r.s0, r.g[k], r.g[k + 1]);
+    }
+    return ISX_OK;
+}
+template <int M>
+int launch_down_chain_k(isx_blender* b, const isx_blender::TileRec& r, hipStream_t st) {
+    switch (r.sk) {
+        case SK_U8: return launch_down_chain_t<M, SK_U8>(b, r, st);
+        case SK_S16: return launch_down_chain_t<M, SK_S16>(b, r, st);
+        default: return launch_down_chain_t<M, SK_F32>(b, r, st);
+    }
+}
+int launch_down_chain(isx_blender* b, const isx_blender::TileRec& r, hipStream_t st) {
+    switch (b->prec) {
+        case M_I16: return launch_down_chain_k<M_I16>(b, r, st);
+        case M_F32: return launch_down_chain_k<M_F32>(b, r, st);
+        default: return launch_down_chain_k<M_F16>(b, r, st);
+    }
+}
+// make the main stream wait for the recorded tiles' side-stream chains
+int join_side_streams(isx_blender* b) {
+    for (size_t t = 0; t < b->tiles.size(); ++t)
+        if (t < b->chain_on_side.size() && b->chain_on_side[t]) ISX_HIP(hipStreamWaitEvent(b->stream, b->ev_done[t], 0));
+    return ISX_OK;
+}
+
+// Deferred tiles have had no accumulation run for them.  When the cycle cannot stay deferred (level
 // introspection, a 9th tile, a tile of another type) they are replayed through the eager feed, in order.
 int flush_deferred(isx_blender* b) {
     if (!b->level0_pending) return ISX_OK;
     const int L = b->num_bands;
+    ISX_TRY(join_side_streams(b));   // the replay rewrites the tiles' pyramid levels
     for (size_t t = 0; t < b->tiles.size(); ++t) {
         isx_blender::TileRec& r = b->tiles[t];
         int rc;
@@ -926,7 +967,10 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     // 1. Gaussian chains: one launch per level for all tiles.  (Per-tile chains on side streams, started
     //    by feed() to overlap with the next tile's VALU-bound warp, were measured: no gain — a kernel that
     //    fills every wave slot leaves nothing for a concurrent one — so the simpler form stays.)
-    for (int k = 0; k < L; ++k) {
+    bool all_on_side = b->chain_on_side.size() >= (size_t)n;
+    for (int t = 0; t < n && all_on_side; ++t) all_on_side = b->chain_on_side[t] != 0;
+    if (all_on_side) ISX_TRY(join_side_streams(b));
+    for (int k = 0; k < L && !all_on_side; ++k) {
         TileSet ts = base(k);
         int maxc = 0, maxr = 0;
         double bytes = 0.0;
@@ -1132,6 +1176,22 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
         r.g[0].rows = height; r.g[0].cols = width;
         b->tiles.push_back(r);
         b->level0_pending = true;
+        if (b->chain_on_side.size() <= slot) b->chain_on_side.resize(slot + 1, 0);
+        b->chain_on_side[slot] = 0;
+        if (b->overlap) {
+            if (b->side.size() <= slot) {
+                hipStream_t sst; hipEvent_t e1, e2;
+                ISX_HIP(hipStreamCreateWithFlags(&sst, hipStreamNonBlocking));
+                ISX_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                ISX_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+                b->side.push_back(sst); b->ev_ready.push_back(e1); b->ev_done.push_back(e2);
+            }
+            ISX_HIP(hipEventRecord(b->ev_ready[slot], b->stream));            // the tile is complete on the main stream here
+            ISX_HIP(hipStreamWaitEvent(b->side[slot], b->ev_ready[slot], 0));
+            ISX_TRY(launch_down_chain(b, b->tiles[slot], b->side[slot]));
+            ISX_HIP(hipEventRecord(b->ev_done[slot], b->side[slot]));
+            b->chain_on_side[slot] = 1;
+        }
         return ISX_OK;
     }
     if (!b->cleared && b->fed.size() >= (size_t)MAX_COVER) {   // more tiles than a Cover holds: clear once, then plain RMW
@@ -1174,6 +1234,10 @@ int isx_blender_destroy(isx_blender* b) {
     if (!b) return ISX_OK;
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
+    for (size_t i = 0; i < b->side.size(); ++i) {
+        (void)hipStreamSynchronize(b->side[i]); (void)hipStreamDestroy(b->side[i]);
+        (void)hipEventDestroy(b->ev_ready[i]); (void)hipEventDestroy(b->ev_done[i]);
+    }
     delete b;
     return ISX_OK;
 }
@@ -1195,6 +1259,12 @@ int isx_blender_set_deferred_level0(isx_blender* b, int on) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_deferred_level0: null blender");
     ISX_CHECK_ARG(!b->prepared || b->fed.empty(), ISX_ERR_STATE, "isx_blender_set_deferred_level0: tiles have already been fed in this cycle");
     b->deferred = on != 0;
+    return ISX_OK;
+}
+
+int isx_blender_set_overlap(isx_blender* b, int on) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_overlap: null blender");
+    b->overlap = on != 0;
     return ISX_OK;
 }
 

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <memory>
 #include <new>
 
 using namespace isx;
@@ -482,11 +483,13 @@ struct isx_warper {
     // main stream; nothing on the main stream depends on it (isx_warper_plan_status joins both).
     hipStream_t side = nullptr;
     hipEvent_t ev_warp = nullptr;   // recorded on the main stream after a planned warp: its scan starts behind it
+    hipEvent_t ev_scan = nullptr;   // recorded on the side stream after the check: isx_warper_join waits on it
     DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
     MatStage st_src, st_mask, st_dst, st_dmask, st_x, st_y;
-    // table cache key
-    int tab_kind = -1, tab_roi[4] = {0, 0, 0, 0};
-    float tab_scale = 0.f;
+    // cache of mapBackward tables, one entry per (kind, scale, roi): a rig's tiles alternate between a few ROIs
+    struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; };
+    std::vector<TabEntry> tab_cache;
+    unsigned long long tab_clock = 0;
     std::vector<float> host_tabs;
     std::vector<int> host_cand;
     float k[9], rinv[9];
@@ -560,6 +563,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         if (!w->side) {
             ISX_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
             ISX_HIP(hipEventCreateWithFlags(&w->ev_warp, hipEventDisableTiming));
+            ISX_HIP(hipEventCreateWithFlags(&w->ev_scan, hipEventDisableTiming));
         }
         // the verification scan is VALU-bound like the warp kernel itself: start it behind this call's warp
         // kernel so that it overlaps with the memory-bound pyramid kernels that follow on the main stream
@@ -586,6 +590,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
             rb.lo[k] = (float)(plo - m); rb.hi[k] = (float)(phi + m);
         }
         ISX_LAUNCH("roi_check", 0.0, w->side, k_roi_check_rearm, dim3(1), dim3(1), 0, sk, rb, (int*)(sk + 5));
+        ISX_HIP(hipEventRecord(w->ev_scan, w->side));
         return ISX_OK;
     }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
@@ -629,8 +634,20 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
     int mw = roi[2] - roi[0] + 1, mh = roi[3] - roi[1] + 1;
     const int mwp = (mw + 3) & ~3, mhp = (mh + 3) & ~3;   // segments padded to 16 bytes: the fused kernel loads float4
     size_t n = (size_t)2 * mwp + 2 * mhp;
-    bool hit = w->tab_kind == w->kind && w->tab_scale == w->scale && std::equal(roi, roi + 4, w->tab_roi) && w->tabs.p != nullptr;
-    if (!hit) {
+    constexpr size_t TAB_SLOTS = 16;
+    isx_warper::TabEntry* e = nullptr;
+    for (auto& c : w->tab_cache)
+        if (c.kind == w->kind && c.scale == w->scale && std::equal(roi, roi + 4, c.roi)) { e = &c; break; }
+    if (!e) {
+        if (w->tab_cache.size() < TAB_SLOTS) {
+            w->tab_cache.emplace_back();
+            e = &w->tab_cache.back();
+            e->buf.reset(new DevBuf());
+        } else {   // evict the least recently used entry (its buffer may still be read by enqueued kernels: drain first)
+            e = &w->tab_cache[0];
+            for (auto& c : w->tab_cache) if (c.stamp < e->stamp) e = &c;
+            ISX_HIP(hipStreamSynchronize(w->stream));
+        }
         w->host_tabs.assign(n, 0.f);
         float* cs = w->host_tabs.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
         for (int i = 0; i < mw; ++i) {
@@ -644,12 +661,13 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
             if (w->kind == ISX_WARP_CYLINDRICAL) { ra[i] = v; rb[i] = 0.f; }          // W:52
             else { ra[i] = sinf(PI_F - v); rb[i] = cosf(PI_F - v); }
         }
-        ISX_TRY(w->tabs.reserve(n * sizeof(float)));
-        ISX_HIP(hipMemcpyAsync(w->tabs.p, w->host_tabs.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
-        ISX_HIP(hipStreamSynchronize(w->stream));   // host_tabs may be rewritten by the next call
-        w->tab_kind = w->kind; w->tab_scale = w->scale; std::copy(roi, roi + 4, w->tab_roi);
+        ISX_TRY(e->buf->reserve(n * sizeof(float)));
+        ISX_HIP(hipMemcpyAsync(e->buf->p, w->host_tabs.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
+        ISX_HIP(hipStreamSynchronize(w->stream));   // host_tabs is rewritten by the next miss
+        e->kind = w->kind; e->scale = w->scale; std::copy(roi, roi + 4, e->roi);
     }
-    const float* base = (const float*)w->tabs.p;
+    e->stamp = ++w->tab_clock;
+    const float* base = (const float*)e->buf->p;
     t->col_s = base; t->col_c = base + mwp; t->row_a = base + 2 * mwp; t->row_b = base + 2 * mwp + mhp;
     return ISX_OK;
 }
@@ -769,7 +787,7 @@ int isx_warper_destroy(isx_warper* w) {
     if (!w) return ISX_OK;
     (void)hipSetDevice(w->device);
     (void)hipStreamSynchronize(w->stream);
-    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); (void)hipEventDestroy(w->ev_warp); }
+    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); (void)hipEventDestroy(w->ev_warp); (void)hipEventDestroy(w->ev_scan); }
     delete w;
     return ISX_OK;
 }
@@ -840,6 +858,15 @@ int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img, con
     clear_error();
     ISX_CHECK_ARG(planned_roi != nullptr, ISX_ERR_INVALID, "planned warp: null planned_roi");
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, planned_roi, true);
+}
+
+int isx_warper_join(isx_warper* w) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_join: null warper");
+    if (!w->side) return ISX_OK;
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_HIP(hipStreamWaitEvent(w->stream, w->ev_scan, 0));
+    return ISX_OK;
 }
 
 int isx_warper_plan_status(isx_warper* w, int* mismatches) {

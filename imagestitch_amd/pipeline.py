@@ -68,7 +68,7 @@ class PairStitcher:
     """One pair of tiles -> one blended mosaic, buffers resident in HBM (torch CUDA tensors)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
-                 device=0, stream=None, out_dtype="int16", deferred=True):
+                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False):
         import torch
         self.torch = torch
         self.imgs, self.K, self.Rs = imgs, K, Rs
@@ -78,6 +78,10 @@ class PairStitcher:
         self.blender = MultiBandBlender(False, num_bands, precision, device, stream)
         # the warped tiles and seam masks below live as long as this object: the deferred level-0 contract holds
         self.blender.set_deferred_level0(deferred)
+        # interleave: warp(t), feed(t), warp(t+1) ... with each tile's Gaussian chain on a side stream.  Measured
+        # on MI355X: no gain (a kernel that fills every wave slot leaves nothing for a concurrent one), so off.
+        self.interleave = interleave
+        self.blender.set_overlap(self.interleave)
         self.precision, self.num_bands = precision, num_bands
         dev = torch.device("cuda", device)
         # plan: ROI per tile (detectResultRoi), output buffers, seam masks
@@ -106,12 +110,41 @@ class PairStitcher:
         GPU for every warp and is compared ON THE DEVICE with the ROI planned in __init__; a mismatch
         raises the sticky flag read by check_plan().  Everything else is the reference's call sequence."""
         n = len(self.imgs)
-        for i in range(n):
-            self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
-        self.blender.prepare(self.corners, self.sizes)
-        for i in range(n):
-            self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+        if self.interleave:   # warp(t), feed(t), warp(t+1), ...: tile t's Gaussian chain runs under tile t+1's warp
+            self.blender.prepare(self.corners, self.sizes)
+            for i in range(n):
+                self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+                self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+        else:
+            for i in range(n):
+                self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+            self.blender.prepare(self.corners, self.sizes)
+            for i in range(n):
+                self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
         self.blender.blend(self.out, self.out_mask)
+        return self.out, self.out_mask
+
+    def capture(self):
+        """Capture the planned step into a hipGraph (one launch per step instead of ~17 API calls):
+        everything the step enqueues is stream work on resident buffers — no allocation, no host copy,
+        no synchronisation — so it is capturable as is; the side-stream ROI scans are re-joined first."""
+        torch = self.torch
+        self.gstream = torch.cuda.Stream(device=self.device)
+        self.warper.set_stream(self.gstream)
+        self.blender.set_stream(self.gstream)
+        self.gstream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.gstream):
+            self.step()
+            self.warper.join()
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.gstream, capture_error_mode="relaxed"):
+            self.step()
+            self.warper.join()
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
         return self.out, self.out_mask
 
     def check_plan(self):

@@ -127,6 +127,10 @@ class RotationWarper:
         check(self._lib.isx_warper_warp_with_mask_planned(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
                                                           roi, C.byref(mdi), C.byref(mdm)))
 
+    def join(self):
+        """Make the handle's stream wait for the side-stream verification scans (needed inside graph capture)."""
+        check(self._lib.isx_warper_join(self._h))
+
     def plan_status(self):
         n = C.c_int()
         check(self._lib.isx_warper_plan_status(self._h, C.byref(n)))

@@ -133,6 +133,10 @@ int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img,
                                       const float R[9], const int planned_roi[4],
                                       isx_mat* dst_img, isx_mat* dst_mask);
 int isx_warper_plan_status(isx_warper* w, int* mismatches /* synchronises the stream */);
+/* The verification scans of planned warps run on an internal side stream.  isx_warper_join makes the
+ * handle's stream wait for them without blocking the host — required before hipStreamEndCapture when
+ * the planned step is captured into a hipGraph (the forked work must re-join the capturing stream).   */
+int isx_warper_join(isx_warper* w);
 
 /* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
 /* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
@@ -167,6 +171,10 @@ int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask,
  * nothing changes for them.  At most 8 tiles of one type are deferred; beyond that, and when
  * isx_blender_debug_level is called, the recorded tiles are replayed through the eager path.       */
 int isx_blender_set_deferred_level0(isx_blender* b, int on);
+/* In deferred mode: start each fed tile's Gaussian chain immediately on an internal side stream, so that
+ * the (memory-bound) chain of tile t overlaps with whatever the caller enqueues next on the handle's
+ * stream — typically the (VALU-bound) warp of tile t+1.  blend() joins the side streams.               */
+int isx_blender_set_overlap(isx_blender* b, int on);
 
 /* size of the result of blend(): dst_roi_final_ (unpadded union of the fed tiles)             */
 int isx_blender_result_size(isx_blender* b, int* width, int* height);

@@ -314,3 +314,29 @@ def test_deferred_level0_identical_to_eager(gpu, oracle, prec, ntiles):
         mb.feed(img, mask, c)
     d, m = mb.blend()
     assert np.array_equal(d, od) and np.array_equal(m, om)
+
+
+def test_pipeline_variants_agree(gpu):
+    """planned step == interleaved (side-stream chains) step == hipGraph replay == eager (non-deferred) step"""
+    import torch
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F = 1024, 600, 800.0
+    K, Rs = synth.camera_pair(W, H, F)
+    dev = torch.device("cuda:0")
+    imgs = [torch.from_numpy(synth.make_tile(H, W, i)).to(dev) for i in range(2)]
+    ref = None
+    for kw in (dict(deferred=False), dict(deferred=True), dict(deferred=True, interleave=True)):
+        ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16", **kw)
+        for _ in range(2):
+            a, am = [t.clone() for t in ps.step()]
+        assert ps.check_plan() == 0
+        if ref is None:
+            ref = (a, am)
+        assert torch.equal(a, ref[0]) and torch.equal(am, ref[1]), kw
+    ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16")
+    ps.capture()
+    for _ in range(3):
+        g, gm = ps.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref[0]) and torch.equal(gm, ref[1])
+    assert ps.check_plan() == 0

@@ -16,14 +16,20 @@ imgs = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generato
 from imagestitch_amd.pipeline import PairStitcher
 ps = PairStitcher(imgs, K, Rs, F, "cylindrical", bands, prec, 0, None, "int16")
 print("corners", ps.corners, "sizes", ps.sizes)
-step = ps.step_sync if (len(sys.argv) > 3 and sys.argv[3] == "sync") else ps.step
+mode = sys.argv[3] if len(sys.argv) > 3 else "planned"
+step = ps.step_sync if mode == "sync" else ps.step
+if mode == "graph":
+    ps.capture()
+    step = ps.replay
 
 for _ in range(3): out = step()
 torch.cuda.synchronize()
 t0 = time.time(); n = 10
 for _ in range(n): out = step()
+th = (time.time() - t0) / n
 torch.cuda.synchronize()
 dt = (time.time() - t0) / n
+print("host enqueue ms/step %.3f" % (th * 1e3))
 print("ms/pair %.3f  Mpix/s %.1f" % (dt * 1e3, 2 * W * H / dt / 1e6))
 lib = _lib.load()
 lib.isx_profile_enable(1); lib.isx_profile_reset()
