@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--focal", type=float, default=3000.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--sync-roi", action="store_true", help="return every warp's corner to the host (one stream sync per tile) instead of the planned, device-checked ROI")
     args = ap.parse_args()
 
@@ -94,8 +96,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
         dist.init_process_group("nccl", device_id=dev)
     lib = imagestitch_amd.load()
     prec = {"i16": _lib.PREC_I16, "f32": _lib.PREC_F32, "f16acc32": _lib.PREC_F16ACC32}[args.precision]
@@ -116,28 +121,71 @@ def main():
                 noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
                 chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
             imgs.append(torch.stack(chans, dim=2).contiguous())
-        pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "int16"))
+        pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16"))
         del yy, xx
     bm = pairs[0].bytes_model()
 
-    gather_buf = None
-    if world > 1:
-        n_out = sum(p.out.numel() for p in pairs)
-        gather_buf = torch.empty((world * n_out,), dtype=torch.int16, device=dev)
-        send = torch.empty((n_out,), dtype=torch.int16, device=dev)
+    from imagestitch_amd import mosaic
+    # N > 1 (BASELINE config 4): every rank's blended mosaics are assembled on every rank with ONE all-gather
+    # per step.  The blend writes the 8-bit panorama (blend + convertTo(CV_8U), W:315) straight into the packed
+    # send block (no pack copy); the gather of step i runs on a communication stream under the compute of
+    # step i+1 (two send blocks), because at 4K the gather, not the blend, is the longer of the two.
+    send, gather_buf, comm, ev_compute, ev_gather = None, None, None, None, None
+    if use_dist:
+        shapes = [tuple(p.out.shape) for p in pairs]
+        n_out = sum(int(np.prod(sh)) for sh in shapes)
+        send = [torch.empty((n_out,), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gather_buf = torch.empty((world * n_out,), dtype=torch.uint8, device=dev)
+        comm = torch.cuda.Stream(device=dev)
+        ev_compute = [torch.cuda.Event() for _ in range(2)]
+        ev_gather = [torch.cuda.Event() for _ in range(2)]
+        views = []
+        for b in range(2):
+            off, vs = 0, []
+            for sh in shapes:
+                n = int(np.prod(sh))
+                vs.append(send[b][off:off + n].view(sh)); off += n
+            views.append(vs)
+    if args.graph:
+        if use_dist:
+            for p, v in zip(pairs, views[0]):
+                p.out = v
+        for p in pairs:
+            p.capture()
+    state = {"i": 0}
 
     def step():
+        b = state["i"] % 2
+        state["i"] += 1
+        main = torch.cuda.current_stream()
+        if use_dist and not args.graph:
+            main.wait_event(ev_gather[b])          # the gather that last read send[b] (two steps ago) is done
+            for p, v in zip(pairs, views[b]):
+                p.out = v
         for p in pairs:
-            p.step_sync() if args.sync_roi else p.step()
-        if world > 1:
-            off = 0
-            for p in pairs:
-                send[off:off + p.out.numel()].copy_(p.out.reshape(-1)); off += p.out.numel()
-            dist.all_gather_into_tensor(gather_buf, send)
+            if args.graph:
+                p.replay()
+            elif args.sync_roi:
+                p.step_sync()
+            else:
+                p.step()
+        if use_dist:
+            if args.graph:   # the graphs run on their own streams and always write send[0]
+                b = 0
+                for p in pairs:
+                    main.wait_stream(p.gstream)
+            ev_compute[b].record(main)
+            comm.wait_event(ev_compute[b])
+            with torch.cuda.stream(comm):
+                mosaic.gather_mosaics(send[b], gather_buf)   # ONE all-gather of every rank's blended mosaics
+                ev_gather[b].record(comm)
+            if args.graph:
+                for p in pairs:
+                    p.gstream.wait_event(ev_gather[b])         # the next replay overwrites send[0]
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -146,7 +194,11 @@ def main():
         step()
     fence()
     lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_reset()
-    step()
+    if args.graph:   # graph replays cannot be bracketed kernel by kernel: profile one eager step instead
+        for p in pairs:
+            p.step()
+    else:
+        step()
     ent = _lib.profile_entries()
     per_kernel = {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "alg_MB": round(v["alg_bytes"] / 1e6, 2)} for k, v in ent.items()}
     # dominant kernel = largest share of the step's kernel time; near-ties (within 10 %) go to the one that
@@ -158,17 +210,23 @@ def main():
     lib.isx_profile_reset()
     # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream)
     lib.isx_profile_filter(dominant.encode() if dominant else None)
+    if args.graph:
+        for _ in range(args.steps):   # the dominant kernel's HIP-event timing comes from eager steps outside the timed region
+            for p in pairs:
+                p.step()
+        ent_graph = _lib.profile_entries()
+        lib.isx_profile_enable(0)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    ent = _lib.profile_entries()
+    ent = ent_graph if args.graph else _lib.profile_entries()
     lib.isx_profile_enable(0)
     for p in pairs:
         p.check_plan()   # raises if any planned step saw a ROI that differs from the plan
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -191,8 +249,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "%d x (2 x %dx%d u8x3 tiles, cylindrical warp f=%g, %d-band %s blend) per GPU per step%s" % (
-                args.pairs, W, H, F, args.bands, args.precision, ", all-gather of the s16x3 mosaics" if world > 1 else ""),
-                "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision,
+                args.pairs, W, H, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
+                "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph),
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
                                   "achieved_GBs": round(bm["total"] / (pair_ms * 1e-3) / 1e9, 1), "frac": round(bm["total"] / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -202,7 +260,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, F, args.bands, prec)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -90,12 +90,12 @@ class MultiBandBlender:
         check(self._lib.isx_blender_debug_level(self._h, int(i), lap.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), C.byref(r), C.byref(c)))
         return lap, w
 
-    def blend(self, dst=None, dst_mask=None, out_f32=False):
-        """blend(result, result_mask) (W:313) -> (result, result_mask)."""
+    def blend(self, dst=None, dst_mask=None, out_f32=False, out_u8=False):
+        """blend(result, result_mask) (W:313) -> (result, result_mask).  out_u8: + result.convertTo(CV_8U)."""
         w, h = self.result_size()
         like = self._like if (self._like is not None and _is_tensor(self._like)) else np.empty(0)
         if dst is None:
-            dst = _empty_like_kind(like, (h, w, 3), np.float32 if out_f32 else np.int16)
+            dst = _empty_like_kind(like, (h, w, 3), np.uint8 if out_u8 else (np.float32 if out_f32 else np.int16))
         if dst_mask is None:
             dst_mask = _empty_like_kind(like, (h, w), np.uint8)
         md, mm = as_mat(dst), as_mat(dst_mask)

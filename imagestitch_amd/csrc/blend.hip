@@ -477,7 +477,7 @@ __device__ __forceinline__ void normalise(Px<M>& d) {
 }
 
 struct OutMat {  // the caller's blend() outputs
-    unsigned char* img; size_t img_step; int img_f32;
+    unsigned char* img; size_t img_step; int img_f32;   // img_f32: 0 = CV_16SC3, 1 = CV_32FC3, 2 = CV_8UC3 (blend + convertTo(CV_8U))
     unsigned char* mask; size_t mask_step;
     int rows, cols;  // dst_roi_final_ size
     int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
@@ -488,7 +488,16 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
     if (x >= o.cols || y >= o.rows) return;      // crop to dst_roi_final_
     bool on = d.w > WEIGHT_EPS;                  // compare(w0, WEIGHT_EPS, CMP_GT)
     if (o.mask) o.mask[(size_t)y * o.mask_step + x] = on ? 255 : 0;
-    if (o.img_f32) {
+    if (o.img_f32 == 2) {   // result.convertTo(CV_8U): saturate_cast<uchar>(short) / saturate_cast<uchar>(cvRound(float))
+        unsigned char* q = o.img + (size_t)y * o.img_step + (size_t)x * 3;
+        if constexpr (M == M_I16) {
+            q[0] = on ? (unsigned char)sat_u8(d.c0) : 0; q[1] = on ? (unsigned char)sat_u8(d.c1) : 0; q[2] = on ? (unsigned char)sat_u8(d.c2) : 0;
+        } else {
+            q[0] = on ? (unsigned char)sat_u8(cvround_x86(d.c0)) : 0;
+            q[1] = on ? (unsigned char)sat_u8(cvround_x86(d.c1)) : 0;
+            q[2] = on ? (unsigned char)sat_u8(cvround_x86(d.c2)) : 0;
+        }
+    } else if (o.img_f32) {
         float* q = (float*)(o.img + (size_t)y * o.img_step) + (size_t)x * 3;
         q[0] = on ? (float)d.c0 : 0.f; q[1] = on ? (float)d.c1 : 0.f; q[2] = on ? (float)d.c2 : 0.f;
     } else {
@@ -1010,7 +1019,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         }
         dim3 grid(cdiv(d[k].cols, WAVE), cdiv(d[k].rows, UP_TY));
         if (k == 1) {
-            bytes += (double)out.rows * out.cols * (out.img_f32 ? 13.0 : 7.0);                  // result + mask
+            bytes += (double)out.rows * out.cols * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));                  // result + mask
             ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true>), grid, dim3(256), 0, ts, d[1], d[0], out);
         } else {
             bytes += (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec);                   // out_{k-1}
@@ -1037,7 +1046,7 @@ int run_blend(isx_blender* b, const OutMat& out) {
     if (L == 0) {
         dim3 grid(cdiv(d[0].cols, 64), cdiv(d[0].rows, 4));
         double px = (double)d[0].rows * d[0].cols;
-        ISX_LAUNCH("norm_top_final", px * alg_d(prec) + (double)out.rows * out.cols * (out.img_f32 ? 13.0 : 7.0), st, (k_norm_top<M, true>), grid, dim3(256), 0, d[0], out, make_cover(b, 0));
+        ISX_LAUNCH("norm_top_final", px * alg_d(prec) + (double)out.rows * out.cols * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0)), st, (k_norm_top<M, true>), grid, dim3(256), 0, d[0], out, make_cover(b, 0));
         return ISX_OK;
     }
     // the top level is normalised while it is staged as the coarse tile of the first collapse step
@@ -1048,7 +1057,7 @@ int run_blend(isx_blender* b, const OutMat& out) {
         Cover cov = make_cover(b, k - 1), ccov = make_cover(b, k);
         const bool normc = k == L;
         if (k == 1) {
-            double bytes = cb + (double)out.rows * out.cols * (alg_d(prec) + (out.img_f32 ? 13.0 : 7.0));
+            double bytes = cb + (double)out.rows * out.cols * (alg_d(prec) + (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0)));
             if (normc) ISX_LAUNCH("collapse_final", bytes, st, (k_collapse<M, true, true>), grid, dim3(256), 0, d[1], d[0], out, cov, ccov);
             else ISX_LAUNCH("collapse_final", bytes, st, (k_collapse<M, true, false>), grid, dim3(256), 0, d[1], d[0], out, cov, ccov);
         } else {
@@ -1350,8 +1359,8 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "blend: null blender");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "blend: prepare() has not been called (or blend() already released the pyramids)");
     ISX_TRY(check_mat(dst, "blend: dst"));
-    ISX_CHECK_ARG(dst->type == ISX_16SC3 || (dst->type == ISX_32FC3 && b->prec != ISX_PREC_I16), ISX_ERR_TYPE,
-                  "blend: dst must be CV_16SC3%s, got %s", b->prec != ISX_PREC_I16 ? " or CV_32FC3" : "", type_name(dst->type));
+    ISX_CHECK_ARG(dst->type == ISX_16SC3 || dst->type == ISX_8UC3 || (dst->type == ISX_32FC3 && b->prec != ISX_PREC_I16), ISX_ERR_TYPE,
+                  "blend: dst must be CV_16SC3, CV_8UC3%s, got %s", b->prec != ISX_PREC_I16 ? " or CV_32FC3" : "", type_name(dst->type));
     ISX_CHECK_ARG(dst->rows == b->fh && dst->cols == b->fw, ISX_ERR_SIZE, "blend: dst is %dx%d, result is %dx%d", dst->cols, dst->rows, b->fw, b->fh);
     if (dst_mask) {
         ISX_TRY(check_mat(dst_mask, "blend: dst_mask"));
@@ -1363,7 +1372,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     ISX_TRY(b->st_out.use_out(dst, b->stream, "blend: dst"));
     if (dst_mask) ISX_TRY(b->st_outmask.use_out(dst_mask, b->stream, "blend: dst_mask"));
     OutMat o;
-    o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3;
+    o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
     o.rows = b->fh; o.cols = b->fw;

@@ -99,8 +99,8 @@ class PairStitcher:
         seam = synth.seam_masks(self.corners, [m.cpu().numpy() for m in self.wmasks])
         self.seam = [torch.from_numpy(s).to(dev) for s in seam]
         self.roi_pad, (fw, fh), self.L = prepare_geometry(self.corners, self.sizes, num_bands)
-        odt = {"int16": torch.int16, "float32": torch.float32}[out_dtype]
-        es = 2 if out_dtype == "int16" else 4
+        odt = {"int16": torch.int16, "float32": torch.float32, "uint8": torch.uint8}[out_dtype]
+        es = {"int16": 2, "float32": 4, "uint8": 1}[out_dtype]
         opitch = (fw * 3 * es + 63) // 64 * 64
         self.out = torch.empty((fh * opitch // es,), dtype=odt, device=dev).as_strided((fh, fw, 3), (opitch // es, 3, 1))
         self.out_mask = pitched(fh, fw, (fh, fw), (1,))

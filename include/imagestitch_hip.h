@@ -179,7 +179,8 @@ int isx_blender_set_overlap(isx_blender* b, int on);
 /* size of the result of blend(): dst_roi_final_ (unpadded union of the fed tiles)             */
 int isx_blender_result_size(isx_blender* b, int* width, int* height);
 /* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast
- * round-half-even) or CV_32FC3 (F32/F16ACC32 only); dst_mask: CV_8UC1.  Releases the pyramids:
+ * round-half-even), CV_32FC3 (F32/F16ACC32 only) or CV_8UC3 (= blend to CV_16SC3 followed by
+ * result.convertTo(CV_8U), what imwrite (W:315) does to the panorama); dst_mask: CV_8UC1.  Releases the pyramids:
  * prepare must be called again before the next feed (as in OpenCV).                           */
 int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask);
 

@@ -340,3 +340,20 @@ def test_pipeline_variants_agree(gpu):
     torch.cuda.synchronize()
     assert torch.equal(g, ref[0]) and torch.equal(gm, ref[1])
     assert ps.check_plan() == 0
+
+
+@pytest.mark.parametrize("prec", [I16, F32])
+def test_blend_u8_output_is_convertTo(gpu, oracle, prec):
+    """dst CV_8UC3 == blend to CV_16SC3 then saturate_cast<uchar> (result.convertTo(CV_8U))"""
+    rng = np.random.default_rng(31)
+    corners, sizes = [(0, 0), (60, 4)], [(100, 80), (90, 77)]
+    tiles = _tiles(rng, sizes)
+    outs = []
+    for u8 in (False, True):
+        mb = gpu.MultiBandBlender(False, 4, prec)
+        mb.prepare(corners, sizes)
+        for (img, mask), c in zip(tiles, corners):
+            mb.feed((img * 3 - 200).astype(np.int16), mask, c)      # values outside [0,255] exercise the saturation
+        outs.append(mb.blend(out_u8=u8))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(np.clip(outs[0][0], 0, 255).astype(np.uint8), outs[1][0])
