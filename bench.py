@@ -201,12 +201,8 @@ def main():
         step()
     ent = _lib.profile_entries()
     per_kernel = {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "alg_MB": round(v["alg_bytes"] / 1e6, 2)} for k, v in ent.items()}
-    # dominant kernel = largest share of the step's kernel time; near-ties (within 10 %) go to the one that
-    # moves more algorithmic bytes (the HBM-roofline-relevant one)
-    dominant = None
-    if ent:
-        tmax = max(v["ms"] for v in ent.values())
-        dominant = max((kv for kv in ent.items() if kv[1]["ms"] >= 0.9 * tmax), key=lambda kv: kv[1]["alg_bytes"])[0]
+    # dominant kernel = the heaviest single launch of the step (largest average launch duration)
+    dominant = max(ent.items(), key=lambda kv: kv[1]["ms"] / max(kv[1]["launches"], 1))[0] if ent else None
     lib.isx_profile_reset()
     # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream)
     lib.isx_profile_filter(dominant.encode() if dominant else None)
