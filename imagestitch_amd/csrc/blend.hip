@@ -186,16 +186,25 @@ __device__ __forceinline__ Px<M> load_any(const Src0& s0, const LevelBuf& L, int
     else return load_src0<M, SK>(s0, x, y);
 }
 
+// Neighbour-lane exchange for the horizontal 5-tap: whole-wavefront shifts by one lane done as DPP moves
+// (wave_shr:1 / wave_shl:1, plain VALU instructions) instead of __shfl_up/__shfl_down, which compile to
+// ds_bpermute_b32 and made the LDS pipe the bottleneck of k_pyr_down (12 per input row; PMC:
+// SQ_ACTIVE_INST_LDS ~ 85 % of the kernel).  Lanes 0 / 63 receive 0 (they are halo lanes, unused).
+__device__ __forceinline__ int dpp_from_lower_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ int dpp_from_upper_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+__device__ __forceinline__ float dpp_from_lower_lane(float v) { return __int_as_float(dpp_from_lower_lane(__float_as_int(v))); }
+__device__ __forceinline__ float dpp_from_upper_lane(float v) { return __int_as_float(dpp_from_upper_lane(__float_as_int(v))); }
+
 template <int M>
-__device__ __forceinline__ Px<M> shfl_up1(const Px<M>& p) {
+__device__ __forceinline__ Px<M> shfl_up1(const Px<M>& p) {   // lane i <- lane i - 1
     Px<M> r;
-    r.c0 = __shfl_up(p.c0, 1); r.c1 = __shfl_up(p.c1, 1); r.c2 = __shfl_up(p.c2, 1); r.w = __shfl_up(p.w, 1);
+    r.c0 = dpp_from_lower_lane(p.c0); r.c1 = dpp_from_lower_lane(p.c1); r.c2 = dpp_from_lower_lane(p.c2); r.w = dpp_from_lower_lane(p.w);
     return r;
 }
 template <int M>
-__device__ __forceinline__ Px<M> shfl_down1(const Px<M>& p) {
+__device__ __forceinline__ Px<M> shfl_down1(const Px<M>& p) {   // lane i <- lane i + 1
     Px<M> r;
-    r.c0 = __shfl_down(p.c0, 1); r.c1 = __shfl_down(p.c1, 1); r.c2 = __shfl_down(p.c2, 1); r.w = __shfl_down(p.w, 1);
+    r.c0 = dpp_from_upper_lane(p.c0); r.c1 = dpp_from_upper_lane(p.c1); r.c2 = dpp_from_upper_lane(p.c2); r.w = dpp_from_upper_lane(p.w);
     return r;
 }
 
