@@ -53,6 +53,8 @@ _SIGS = {
     "isx_warper_warp_with_mask_planned": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],
     "isx_warper_plan_status": [C.c_void_p, _IP],
     "isx_warper_join": [C.c_void_p],
+    "isx_warper_set_deferred_verify": [C.c_void_p, C.c_int],
+    "isx_warper_verify": [C.c_void_p],
     "isx_blender_create": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "isx_blender_destroy": [C.c_void_p],
     "isx_blender_set_stream": [C.c_void_p, C.c_void_p],

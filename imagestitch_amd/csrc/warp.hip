@@ -485,6 +485,12 @@ struct isx_warper {
     hipEvent_t ev_warp = nullptr;   // recorded on the main stream after a planned warp: its scan starts behind it
     hipEvent_t ev_scan = nullptr;   // recorded on the side stream after the check: isx_warper_join waits on it
     DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
+    // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
+    // queued scans behind the main stream's position AT THAT CALL (e.g. after the last warp of a step, so
+    // that they run under the memory-bound pyramid kernels instead of under the next tile's warp)
+    struct Pending { Proj proj; int sw, sh; int planned[4]; };
+    std::vector<Pending> pending;
+    bool defer_verify = false;
     MatStage st_src, st_mask, st_dst, st_dmask, st_x, st_y;
     // cache of mapBackward tables, one entry per (kind, scale, roi): a rig's tiles alternate between a few ROIs
     struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; };
@@ -513,6 +519,46 @@ int set_camera(isx_warper* w, const float K[9], const float R[9]) {
     mat3_mul(K, w->rinv, w->proj.k_rinv);                                   // W:113
     w->proj.scale = w->scale;
     w->proj.kind = w->kind;
+    return ISX_OK;
+}
+
+// Enqueue the queued verification scans of planned warps on the side stream, behind the main stream's
+// current position.  The scan is VALU-bound like the warp kernel: it should run under memory-bound work.
+int flush_verify(isx_warper* w) {
+    if (w->pending.empty()) return ISX_OK;
+    hipStream_t st = w->stream;
+    if (!w->side) {
+        ISX_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+        ISX_HIP(hipEventCreateWithFlags(&w->ev_warp, hipEventDisableTiming));
+        ISX_HIP(hipEventCreateWithFlags(&w->ev_scan, hipEventDisableTiming));
+    }
+    ISX_HIP(hipEventRecord(w->ev_warp, st));
+    ISX_HIP(hipStreamWaitEvent(w->side, w->ev_warp, 0));
+    if (!w->scan_side.p) {
+        ISX_TRY(w->scan_side.reserve(64));
+        ISX_HIP(hipMemsetAsync(w->scan_side.p, 0, 64, w->side));
+        ISX_HIP(hipMemsetAsync(w->scan_side.p, 0xff, 2 * sizeof(unsigned), w->side));
+    }
+    unsigned* sk = (unsigned*)w->scan_side.p;
+    for (const isx_warper::Pending& pd : w->pending) {
+        dim3 sgrid(cdiv(pd.sw, 256), cdiv(pd.sh, ROI_ROWS));   // ~8 K waves at 4K: one full-occupancy round
+        ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, pd.proj, pd.sw, pd.sh, sk);
+        RoiBounds rb;
+        for (int k = 0; k < 4; ++k) {
+            double lo, hi;
+            trunc_interval(pd.planned[k], lo, hi);
+            const bool is_u = (k == 0 || k == 2);
+            double plo = is_u ? proxy_d_of_u(lo, pd.proj.scale) : proxy_q_of_v(lo, pd.proj.scale);
+            double phi = is_u ? proxy_d_of_u(hi, pd.proj.scale) : proxy_q_of_v(hi, pd.proj.scale);
+            // margin: the stand-ins carry a few ulp of error; an extremum this close to an integer boundary is
+            // not flagged (the check is a guard against a stale plan, not a proof)
+            const double m = 4e-6 * std::max(1.0, std::max(std::fabs(plo), std::fabs(phi)));
+            rb.lo[k] = (float)(plo - m); rb.hi[k] = (float)(phi + m);
+        }
+        ISX_LAUNCH("roi_check", 0.0, w->side, k_roi_check_rearm, dim3(1), dim3(1), 0, sk, rb, (int*)(sk + 5));
+    }
+    ISX_HIP(hipEventRecord(w->ev_scan, w->side));
+    w->pending.clear();
     return ISX_OK;
 }
 
@@ -560,37 +606,11 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         return ISX_OK;
     }
     if (sync_free) {
-        if (!w->side) {
-            ISX_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
-            ISX_HIP(hipEventCreateWithFlags(&w->ev_warp, hipEventDisableTiming));
-            ISX_HIP(hipEventCreateWithFlags(&w->ev_scan, hipEventDisableTiming));
-        }
-        // the verification scan is VALU-bound like the warp kernel itself: start it behind this call's warp
-        // kernel so that it overlaps with the memory-bound pyramid kernels that follow on the main stream
-        ISX_HIP(hipEventRecord(w->ev_warp, st));
-        ISX_HIP(hipStreamWaitEvent(w->side, w->ev_warp, 0));
-        if (!w->scan_side.p) {
-            ISX_TRY(w->scan_side.reserve(64));
-            ISX_HIP(hipMemsetAsync(w->scan_side.p, 0, 64, w->side));
-            ISX_HIP(hipMemsetAsync(w->scan_side.p, 0xff, 2 * sizeof(unsigned), w->side));
-        }
-        unsigned* sk = (unsigned*)w->scan_side.p;
-        dim3 sgrid(cdiv(sw, 256), cdiv(sh, ROI_ROWS));   // ~8 K waves at 4K: one full-occupancy round
-        ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, w->proj, sw, sh, sk);
-        RoiBounds rb;
-        for (int k = 0; k < 4; ++k) {
-            double lo, hi;
-            trunc_interval(planned[k], lo, hi);
-            const bool is_u = (k == 0 || k == 2);
-            double plo = is_u ? proxy_d_of_u(lo, w->scale) : proxy_q_of_v(lo, w->scale);
-            double phi = is_u ? proxy_d_of_u(hi, w->scale) : proxy_q_of_v(hi, w->scale);
-            // margin: the stand-ins carry a few ulp of error; an extremum this close to an integer boundary is
-            // not flagged (the check is a guard against a stale plan, not a proof)
-            const double m = 4e-6 * std::max(1.0, std::max(std::fabs(plo), std::fabs(phi)));
-            rb.lo[k] = (float)(plo - m); rb.hi[k] = (float)(phi + m);
-        }
-        ISX_LAUNCH("roi_check", 0.0, w->side, k_roi_check_rearm, dim3(1), dim3(1), 0, sk, rb, (int*)(sk + 5));
-        ISX_HIP(hipEventRecord(w->ev_scan, w->side));
+        isx_warper::Pending pd;
+        pd.proj = w->proj; pd.sw = sw; pd.sh = sh;
+        std::copy(planned, planned + 4, pd.planned);
+        w->pending.push_back(pd);
+        if (!w->defer_verify) return flush_verify(w);
         return ISX_OK;
     }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
@@ -860,11 +880,25 @@ int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img, con
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, planned_roi, true);
 }
 
+int isx_warper_set_deferred_verify(isx_warper* w, int on) {
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_deferred_verify: null warper");
+    w->defer_verify = on != 0;
+    return ISX_OK;
+}
+
+int isx_warper_verify(isx_warper* w) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_verify: null warper");
+    ISX_HIP(hipSetDevice(w->device));
+    return flush_verify(w);
+}
+
 int isx_warper_join(isx_warper* w) {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_join: null warper");
-    if (!w->side) return ISX_OK;
     ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(flush_verify(w));
+    if (!w->side) return ISX_OK;
     ISX_HIP(hipStreamWaitEvent(w->stream, w->ev_scan, 0));
     return ISX_OK;
 }
@@ -873,8 +907,9 @@ int isx_warper_plan_status(isx_warper* w, int* mismatches) {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && mismatches != nullptr, ISX_ERR_INVALID, "plan_status: null argument");
     *mismatches = 0;
-    if (!w->scan_side.p) return ISX_OK;
     ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(flush_verify(w));
+    if (!w->scan_side.p) return ISX_OK;
     ISX_HIP(hipStreamSynchronize(w->side));
     ISX_HIP(hipStreamSynchronize(w->stream));
     ISX_HIP(hipMemcpy(mismatches, (int*)w->scan_side.p + 5, sizeof(int), hipMemcpyDeviceToHost));

@@ -75,6 +75,7 @@ class PairStitcher:
         self.device = device
         creator = CylindricalWarper if kind == "cylindrical" else SphericalWarper
         self.warper = creator(device, stream).create(scale)
+        self.warper.set_deferred_verify(True)   # both ROI scans start after the last warp of a step (see step())
         self.blender = MultiBandBlender(False, num_bands, precision, device, stream)
         # the warped tiles and seam masks below live as long as this object: the deferred level-0 contract holds
         self.blender.set_deferred_level0(deferred)
@@ -118,6 +119,7 @@ class PairStitcher:
         else:
             for i in range(n):
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+            self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
             for i in range(n):
                 self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])

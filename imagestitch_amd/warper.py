@@ -127,6 +127,13 @@ class RotationWarper:
         check(self._lib.isx_warper_warp_with_mask_planned(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
                                                           roi, C.byref(mdi), C.byref(mdm)))
 
+    def set_deferred_verify(self, on=True):
+        check(self._lib.isx_warper_set_deferred_verify(self._h, int(bool(on))))
+
+    def verify(self):
+        """Enqueue the queued verification scans of planned warps behind the stream's current position."""
+        check(self._lib.isx_warper_verify(self._h))
+
     def join(self):
         """Make the handle's stream wait for the side-stream verification scans (needed inside graph capture)."""
         check(self._lib.isx_warper_join(self._h))

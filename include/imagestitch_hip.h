@@ -137,6 +137,12 @@ int isx_warper_plan_status(isx_warper* w, int* mismatches /* synchronises the st
  * handle's stream wait for them without blocking the host — required before hipStreamEndCapture when
  * the planned step is captured into a hipGraph (the forked work must re-join the capturing stream).   */
 int isx_warper_join(isx_warper* w);
+/* By default the verification scan of a planned warp is enqueued right behind its warp kernel.  With
+ * deferred verification the scans are queued and isx_warper_verify enqueues them behind the stream's
+ * position at THAT call — e.g. after the last warp of a step, so that the (VALU-bound) scans run under the
+ * (memory-bound) pyramid kernels that follow.  join / plan_status flush the queue themselves.            */
+int isx_warper_set_deferred_verify(isx_warper* w, int on);
+int isx_warper_verify(isx_warper* w);
 
 /* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
 /* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
