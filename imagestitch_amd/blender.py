@@ -103,12 +103,43 @@ class MultiBandBlender:
         return dst, dst_mask
 
 
+class FeatherBlender(MultiBandBlender):
+    """cv::detail::FeatherBlender as every reference demo runs it (W:278-281,302,313):
+    blender = Blender.createDefault(Blender.FEATHER, False); blender.setSharpness(0.1)."""
+
+    def __init__(self, try_gpu=False, sharpness=0.02, device=0, stream=None):
+        del try_gpu
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.isx_blender_create(_lib.BLEND_FEATHER, 0, PREC_I16, int(device), C.byref(self._h)))
+        self.precision = PREC_I16
+        self._like = None
+        if stream is not None:
+            self.set_stream(stream)
+        self.setSharpness(sharpness)
+
+    def setSharpness(self, val):
+        check(self._lib.isx_blender_set_sharpness(self._h, float(val)))
+
+
+def dilate_and(mask, kw, kh, other=None, device=0, stream=None):
+    """dilate(mask, getStructuringElement(MORPH_RECT, Size(kw, kh))) [& other]  (W:286-301)."""
+    out = _empty_like_kind(mask, tuple(mask.shape), np.uint8)
+    mm, mo = as_mat(mask), as_mat(out)
+    mt = as_mat(other) if other is not None else None
+    ptr = getattr(stream, "cuda_stream", stream)
+    check(_lib.load().isx_mask_dilate_and(C.byref(mm), C.byref(mt) if mt is not None else None, int(kw), int(kh), C.byref(mo), int(device), C.c_void_p(ptr or 0)))
+    return out
+
+
 class Blender:
     """cv::detail::Blender factory (W:271,276,278)."""
     NO, FEATHER, MULTI_BAND = 0, 1, 2
 
     @staticmethod
     def createDefault(blend_type, try_gpu=False, **kw):
+        if blend_type == Blender.FEATHER:
+            return FeatherBlender(try_gpu, **kw)
         if blend_type != Blender.MULTI_BAND:
-            raise IsxError(6, "Blender::createDefault: only MULTI_BAND is implemented on this path (got %d)" % blend_type)
+            raise IsxError(6, "Blender::createDefault: MULTI_BAND and FEATHER are implemented on this path (got %d)" % blend_type)
         return MultiBandBlender(try_gpu, **kw)

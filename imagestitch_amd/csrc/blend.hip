@@ -723,6 +723,108 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N2  FeatherBlender (W:278-281,302,313; OpenCV 3.4.2 blenders.cpp createWeightMap / feed / blend)
+//   weight = min(distanceTransform(mask, DIST_L1, 3) * sharpness, 1)
+//   dst.c += short(img.c * weight) (wrapping), dst_w += weight;  blend: c / (w + 1e-5), mask = w > 1e-5
+// distanceTransform_3x3 with metrics {1, 2} in 16.16 fixed point is the exact city-block distance to the
+// nearest zero pixel, min'ed with the chamfer distance from the INIT_DIST0 border (only reachable when no
+// zero pixel is near): computed separably — nearest zero along the row (block prefix-max / suffix-min of
+// zero positions), then a forward / backward "+1" sweep down the columns (lanes = adjacent columns).
+// ------------------------------------------------------------------------------------------------
+constexpr int DT_BIG = 1 << 28;
+
+// one block per row: rowd[y][x] = |x - nearest zero of row y| (DT_BIG when the row has no zero)
+__global__ __launch_bounds__(256) void k_dt_rows(const unsigned char* mask, size_t mstep, int rows, int cols, int* rowd) {
+    __shared__ int s_last[256], s_next[256];
+    const int y = blockIdx.x, t = threadIdx.x;
+    const unsigned char* m = mask + (size_t)y * mstep;
+    const int chunk = (cols + 255) / 256, c0 = min(t * chunk, cols), c1 = min(c0 + chunk, cols);
+    int last = -DT_BIG, next = DT_BIG;
+    for (int x = c0; x < c1; ++x) if (!m[x]) { last = x; if (next == DT_BIG) next = x; }
+    s_last[t] = last; s_next[t] = next;
+    __syncthreads();
+    // exclusive prefix-max of the chunks' last zero, exclusive suffix-min of their first zero (256 entries: serial per thread is fine)
+    int pl = -DT_BIG, nn = DT_BIG;
+    for (int i = 0; i < t; ++i) pl = max(pl, s_last[i]);
+    for (int i = 255; i > t; --i) nn = min(nn, s_next[i]);
+    int* out = rowd + (size_t)y * cols;
+    int cur = pl;
+    for (int x = c0; x < c1; ++x) { if (!m[x]) cur = x; out[x] = cur <= -DT_BIG ? DT_BIG : x - cur; }
+    cur = nn;
+    for (int x = c1 - 1; x >= c0; --x) { if (!m[x]) cur = x; int d = cur >= DT_BIG ? DT_BIG : cur - x; out[x] = min(out[x], d); }
+}
+
+// one thread per column: forward then backward sweep, then the weight map (in place: int -> float)
+__global__ __launch_bounds__(64) void k_dt_cols_weight(int* rowd, int rows, int cols, float sharpness) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= cols) return;
+    int d = DT_BIG;
+    for (int y = 0; y < rows; ++y) {
+        int* p = rowd + (size_t)y * cols + x;
+        d = min(d + 1, *p);
+        *p = d;
+    }
+    d = DT_BIG;
+    const unsigned INIT = (unsigned)(INT_MAX >> 2);
+    for (int y = rows - 1; y >= 0; --y) {
+        int* p = rowd + (size_t)y * cols + x;
+        d = min(d + 1, *p);
+        // chamfer value in 16.16: city-block distance to a zero pixel, or INIT_DIST0 + distance to the border ring
+        const unsigned border = INIT + ((unsigned)(1 + min(min(x, cols - 1 - x), min(y, rows - 1 - y))) << 16);
+        const unsigned t0 = d >= DT_BIG / 2 ? border : min((unsigned)d << 16, border);
+        float w = ((float)t0 * (1.f / 65536.f)) * sharpness;       // multiply(weight, sharpness)
+        w = w > 1.f ? 1.f : w;                                      // threshold(1.f, THRESH_TRUNC)
+        *(float*)p = w;
+    }
+}
+
+template <int SK>
+__global__ __launch_bounds__(256) void k_feather_acc(const unsigned char* img, size_t istep, const float* weight, int rows, int cols,
+                                                     LevelBuf dst, int dx, int dy) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    int c0, c1, c2;
+    if constexpr (SK == SK_U8) { const unsigned char* q = img + (size_t)y * istep + (size_t)x * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+    else { const short* q = (const short*)(img + (size_t)y * istep) + (size_t)x * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+    const float w = weight[(size_t)y * cols + x];
+    Px<M_I16> d = load_px<M_I16, true>(dst, dx + x, dy + y);
+    d.c0 = wrap_s16(d.c0 + f2s_x86((float)c0 * w));
+    d.c1 = wrap_s16(d.c1 + f2s_x86((float)c1 * w));
+    d.c2 = wrap_s16(d.c2 + f2s_x86((float)c2 * w));
+    d.w = d.w + w;
+    store_px<M_I16, true>(dst, dx + x, dy + y, d);
+}
+
+__global__ __launch_bounds__(256) void k_feather_blend(LevelBuf dst, OutMat out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dst.cols || y >= dst.rows) return;
+    Px<M_I16> d = load_px<M_I16, true>(dst, x, y);
+    normalise<M_I16>(d);
+    write_final<M_I16>(out, x, y, d);
+}
+
+// N3  dilate(mask, MORPH_RECT kw x kh) [& other]  (W:286-301): separable running max, anchor (kw/2, kh/2)
+__global__ __launch_bounds__(256) void k_dilate_rows(const unsigned char* src, size_t sstep, int rows, int cols, int kw, unsigned char* tmp) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const unsigned char* s = src + (size_t)y * sstep;
+    const int lo = max(x - kw / 2, 0), hi = min(x - kw / 2 + kw, cols);
+    int m = 0;
+    for (int k = lo; k < hi; ++k) m = max(m, (int)s[k]);
+    tmp[(size_t)y * cols + x] = (unsigned char)m;
+}
+__global__ __launch_bounds__(256) void k_dilate_cols_and(const unsigned char* tmp, int rows, int cols, int kh, const unsigned char* other, size_t ostep,
+                                                         unsigned char* dst, size_t dstep) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const int lo = max(y - kh / 2, 0), hi = min(y - kh / 2 + kh, rows);
+    int m = 0;
+    for (int k = lo; k < hi; ++k) m = max(m, (int)tmp[(size_t)k * cols + x]);
+    if (other) m &= other[(size_t)y * ostep + x];
+    dst[(size_t)y * dstep + x] = (unsigned char)m;
+}
+
 // zero every pixel of a level that no fed tile covers (only needed when more than MAX_COVER tiles are
 // fed, and by the level-introspection entry point)
 template <int M>
@@ -775,6 +877,8 @@ struct isx_blender {
     // overlap mode (isx_blender_set_overlap): a recorded tile's Gaussian chain starts right away on its own
     // side stream (it only needs the tile), so the memory-bound chain of tile t runs under the VALU-bound
     // warp of tile t+1 that the caller enqueues next on the main stream; blend() joins the side streams
+    float sharpness = 0.02f;        // FeatherBlender(float sharpness = 0.02f)
+    DevBuf feather_w;               // weight map of the tile being fed (int row distances, then float weights)
     bool overlap = false;
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_ready, ev_done;
@@ -1094,16 +1198,49 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     layout_levels(b->dst, L, height, width, b->prec, true, nullptr, &total);
     ISX_TRY(b->dst_arena.reserve(total));
     layout_levels(b->dst, L, height, width, b->prec, true, (char*)b->dst_arena.p, &total);
-    // dst_.setTo(0) / weights setTo(0) are not executed: uncovered pixels are defined as zero (Cover)
+    // MULTI_BAND: dst_.setTo(0) / weights setTo(0) are not executed, uncovered pixels are defined as zero (Cover).
+    // FEATHER (one full-resolution level, plain read-modify-write): cleared as OpenCV does.
+    if (b->type == ISX_BLEND_FEATHER) ISX_HIP(hipMemsetAsync(b->dst_arena.p, 0, total, b->stream));
     b->fed.clear();
-    b->cleared = false;
+    b->cleared = b->type == ISX_BLEND_FEATHER;
     b->tiles.clear();
     b->level0_pending = false;
     b->prepared = true;
     return ISX_OK;
 }
 
+// FeatherBlender::feed (createWeightMap + the weighted accumulate loop)
+int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
+    ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released the accumulators)");
+    ISX_TRY(check_mat(img, "feed: img"));
+    ISX_TRY(check_mat(mask, "feed: mask"));
+    if (u8_entry) ISX_CHECK_ARG(img->type == ISX_8UC3, ISX_ERR_TYPE, "feed_u8: img must be CV_8UC3, got %s", type_name(img->type));
+    else ISX_CHECK_ARG(img->type == ISX_16SC3, ISX_ERR_TYPE, "FeatherBlender::feed: img must be CV_16SC3, got %s", type_name(img->type));
+    ISX_CHECK_ARG(mask->type == ISX_8UC1, ISX_ERR_TYPE, "feed: mask must be CV_8U, got %s", type_name(mask->type));
+    ISX_CHECK_ARG(mask->rows == img->rows && mask->cols == img->cols, ISX_ERR_SIZE, "feed: mask %dx%d does not match img %dx%d",
+                  mask->cols, mask->rows, img->cols, img->rows);
+    const int dx = tl_x - b->rx, dy = tl_y - b->ry;
+    ISX_CHECK_ARG(dx >= 0 && dy >= 0 && dx + img->cols <= b->rw && dy + img->rows <= b->rh, ISX_ERR_INVALID,
+                  "feed: tile at (%d,%d) %dx%d lies outside the prepared ROI", tl_x, tl_y, img->cols, img->rows);
+    ISX_HIP(hipSetDevice(b->device));
+    hipStream_t st = b->stream;
+    ISX_TRY(b->st_img.use_in(img, st, "feed: img"));
+    ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
+    const int rows = img->rows, cols = img->cols;
+    ISX_TRY(b->feather_w.reserve((size_t)rows * cols * 4));
+    int* rowd = (int*)b->feather_w.p;
+    ISX_LAUNCH("dt_rows", (double)rows * cols * 5.0, st, k_dt_rows, dim3(rows), dim3(256), 0, (const unsigned char*)b->st_mask.d.data, b->st_mask.d.step, rows, cols, rowd);
+    ISX_LAUNCH("dt_cols_weight", (double)rows * cols * 16.0, st, k_dt_cols_weight, dim3(cdiv(cols, 64)), dim3(64), 0, rowd, rows, cols, b->sharpness);
+    dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
+    const double bytes = (double)rows * cols * ((u8_entry ? 3.0 : 6.0) + 4.0 + 2.0 * 10.0);
+    if (u8_entry) ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_U8>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step, (const float*)rowd, rows, cols, b->dst[0], dx, dy);
+    else ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_S16>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step, (const float*)rowd, rows, cols, b->dst[0], dx, dy);
+    return ISX_OK;
+}
+
 int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "feed: null blender");
+    if (b->type == ISX_BLEND_FEATHER) return do_feed_feather(b, img, mask, tl_x, tl_y, u8_entry);
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "feed: null blender");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released the pyramids)");
     ISX_TRY(check_mat(img, "feed: img"));
@@ -1235,7 +1372,9 @@ int isx_blender_create(int type, int num_bands, int precision, int device, isx_b
     clear_error();
     ISX_CHECK_ARG(out != nullptr, ISX_ERR_INVALID, "isx_blender_create: null out pointer");
     *out = nullptr;
-    ISX_CHECK_ARG(type == ISX_BLEND_MULTI_BAND, ISX_ERR_UNSUPPORTED, "isx_blender_create: only Blender::MULTI_BAND (2) is implemented, got %d", type);
+    ISX_CHECK_ARG(type == ISX_BLEND_MULTI_BAND || type == ISX_BLEND_FEATHER, ISX_ERR_UNSUPPORTED,
+                  "isx_blender_create: Blender::MULTI_BAND (2) and Blender::FEATHER (1) are implemented, got %d", type);
+    if (type == ISX_BLEND_FEATHER) { num_bands = 0; precision = ISX_PREC_I16; }   // CV_16SC3 accumulator + CV_32F weights, one level
     ISX_CHECK_ARG(num_bands >= 0 && num_bands < MAX_LEVELS - 1, ISX_ERR_INVALID, "isx_blender_create: num_bands %d out of range", num_bands);
     ISX_CHECK_ARG(precision >= ISX_PREC_I16 && precision <= ISX_PREC_F16ACC32, ISX_ERR_INVALID, "isx_blender_create: bad precision %d", precision);
     int n = 0;
@@ -1277,6 +1416,43 @@ int isx_blender_set_deferred_level0(isx_blender* b, int on) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_deferred_level0: null blender");
     ISX_CHECK_ARG(!b->prepared || b->fed.empty(), ISX_ERR_STATE, "isx_blender_set_deferred_level0: tiles have already been fed in this cycle");
     b->deferred = on != 0;
+    return ISX_OK;
+}
+
+int isx_blender_set_sharpness(isx_blender* b, float sharpness) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_sharpness: null blender");
+    ISX_CHECK_ARG(b->type == ISX_BLEND_FEATHER, ISX_ERR_STATE, "setSharpness: not a FeatherBlender");
+    ISX_CHECK_ARG(sharpness == sharpness, ISX_ERR_INVALID, "setSharpness: NaN");
+    b->sharpness = sharpness;
+    return ISX_OK;
+}
+
+int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int kh, isx_mat* out, int device, void* hip_stream) {
+    clear_error();
+    ISX_TRY(check_mat(mask, "dilate: mask"));
+    ISX_TRY(check_mat(out, "dilate: out"));
+    ISX_CHECK_ARG(mask->type == ISX_8UC1 && out->type == ISX_8UC1, ISX_ERR_TYPE, "dilate: masks must be CV_8U");
+    ISX_CHECK_ARG(out->rows == mask->rows && out->cols == mask->cols, ISX_ERR_SIZE, "dilate: out is %dx%d, mask is %dx%d", out->cols, out->rows, mask->cols, mask->rows);
+    ISX_CHECK_ARG(kw >= 1 && kh >= 1 && kw <= 4096 && kh <= 4096, ISX_ERR_INVALID, "dilate: bad structuring element %dx%d", kw, kh);
+    if (other) {
+        ISX_TRY(check_mat(other, "dilate: other"));
+        ISX_CHECK_ARG(other->type == ISX_8UC1 && other->rows == mask->rows && other->cols == mask->cols, ISX_ERR_SIZE, "dilate: the AND operand must be a CV_8U mask of the same size");
+    }
+    ISX_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    MatStage sm, so, sd;
+    DevBuf tmp;
+    ISX_TRY(sm.use_in(mask, st, "dilate: mask"));
+    if (other) ISX_TRY(so.use_in(other, st, "dilate: other"));
+    ISX_TRY(sd.use_out(out, st, "dilate: out"));
+    const int rows = mask->rows, cols = mask->cols;
+    ISX_TRY(tmp.reserve((size_t)rows * cols));
+    dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
+    ISX_LAUNCH("dilate_rows", (double)rows * cols * 2.0, st, k_dilate_rows, grid, dim3(256), 0, (const unsigned char*)sm.d.data, sm.d.step, rows, cols, kw, (unsigned char*)tmp.p);
+    ISX_LAUNCH("dilate_cols_and", (double)rows * cols * 3.0, st, k_dilate_cols_and, grid, dim3(256), 0, (const unsigned char*)tmp.p, rows, cols, kh,
+               other ? (const unsigned char*)so.d.data : nullptr, other ? so.d.step : 0, (unsigned char*)sd.d.data, sd.d.step);
+    ISX_TRY(sd.finish_out(st));
+    ISX_HIP(hipStreamSynchronize(st));   // tmp is freed on return
     return ISX_OK;
 }
 
@@ -1386,11 +1562,16 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
     o.rows = b->fh; o.cols = b->fw;
     o.vec = ((uintptr_t)o.img % 4 == 0) && (o.img_step % 4 == 0) && (!o.mask || (((uintptr_t)o.mask % 2 == 0) && (o.mask_step % 2 == 0)));
-    int rc;
-    switch (b->prec) {
-        case M_I16: rc = run_blend<M_I16>(b, o); break;
-        case M_F32: rc = run_blend<M_F32>(b, o); break;
-        default: rc = run_blend<M_F16>(b, o); break;
+    int rc = ISX_OK;
+    if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend
+        dim3 grid(cdiv(b->dst[0].cols, 64), cdiv(b->dst[0].rows, 4));
+        ISX_LAUNCH("feather_blend", (double)b->fw * b->fh * 17.0, b->stream, k_feather_blend, grid, dim3(256), 0, b->dst[0], o);
+    } else {
+        switch (b->prec) {
+            case M_I16: rc = run_blend<M_I16>(b, o); break;
+            case M_F32: rc = run_blend<M_F32>(b, o); break;
+            default: rc = run_blend<M_F16>(b, o); break;
+        }
     }
     ISX_TRY(rc);
     ISX_TRY(b->st_out.finish_out(b->stream));

@@ -165,9 +165,26 @@ public:
     void setNumBands(int val) { check(isx_blender_set_num_bands(h_, val)); }   // W:273
 };
 
+// cv::detail::FeatherBlender — the blender every reference demo actually runs (W:278-280)
+class FeatherBlender : public Blender {
+public:
+    FeatherBlender(float sharpness = 0.02f, int device = 0) {
+        check(isx_blender_create(ISX_BLEND_FEATHER, 0, ISX_PREC_I16, device, &h_));
+        setSharpness(sharpness);
+    }
+    void setSharpness(float val) { check(isx_blender_set_sharpness(h_, val)); }   // fb->setSharpness(0.1)  W:280
+};
+
 inline std::shared_ptr<Blender> Blender::createDefault(int type, bool try_gpu, int precision) {
-    if (type != MULTI_BAND) throw Exception(ISX_ERR_UNSUPPORTED, "Blender::createDefault: only MULTI_BAND is implemented on this path");
+    if (type == FEATHER) return std::make_shared<FeatherBlender>();
+    if (type != MULTI_BAND) throw Exception(ISX_ERR_UNSUPPORTED, "Blender::createDefault: MULTI_BAND and FEATHER are implemented on this path");
     return std::make_shared<MultiBandBlender>(try_gpu, 5, precision);
+}
+
+// dilate(mask, getStructuringElement(MORPH_RECT, Size(kw, kh))) [& other]  (W:286-301)
+inline void dilateAnd(const Mat& mask, int kw, int kh, const Mat* other, Mat& out, int device = 0) {
+    out.create(mask.rows(), mask.cols(), ISX_8UC1);
+    check(isx_mask_dilate_and(mask.c(), other ? other->c() : nullptr, kw, kh, out.c(), device, nullptr));
 }
 
 }  // namespace isx

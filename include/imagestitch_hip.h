@@ -146,12 +146,14 @@ int isx_warper_verify(isx_warper* w);
 
 /* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
 /* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
- * type must be ISX_BLEND_MULTI_BAND; num_bands default in OpenCV is 5.                        */
+ * type: ISX_BLEND_MULTI_BAND (num_bands default in OpenCV: 5) or ISX_BLEND_FEATHER (the blender every
+ * reference demo actually runs, W:278-280; num_bands / precision are ignored, sharpness 0.02).     */
 int isx_blender_create(int type, int num_bands, int precision, int device, isx_blender** out);
 int isx_blender_destroy(isx_blender* b);
 int isx_blender_set_stream(isx_blender* b, void* hip_stream);
 int isx_blender_set_num_bands(isx_blender* b, int num_bands);   /* mb->setNumBands(n), W:273 */
 int isx_blender_num_bands(isx_blender* b, int* num_bands);      /* after prepare: the clamped */
+int isx_blender_set_sharpness(isx_blender* b, float sharpness); /* fb->setSharpness(0.1), W:280 */
 
 /* blender->prepare(corners, sizes) (W:281): corners_xy = {x0,y0,x1,y1,...}, sizes_wh likewise */
 int isx_blender_prepare(isx_blender* b, int n, const int* corners_xy, const int* sizes_wh);
@@ -195,6 +197,12 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask);
  * rows*cols float.  Either may be NULL.  rows/cols are always written.                        */
 int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
                             int* rows, int* cols);
+
+/* ---- mask preparation between seam finding and feed (W:286-301) ----------------------------- */
+/* dilate(masks_seam[k], element) with element = getStructuringElement(MORPH_RECT, Size(kw, kh))
+ * (W:286,295) followed by `& masks_warped[k]` (W:299; `other` may be NULL = dilate only).          */
+int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int kh, isx_mat* out,
+                        int device, void* hip_stream);
 
 /* ---- the reference's in-tree single-band seam-ramp blend (B:141-717) --------------------- */
 /* images1/images2: CV_32FC3 warped tiles (B:143-145), tl1/tl2 their corners (B:148-149),

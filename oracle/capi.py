@@ -237,6 +237,61 @@ class MultiBand:
         return dst, m
 
 
+# ---------------------------------------------------------------- N3 / N2
+def dilate_rect(mask, kw, kh):
+    m = _c(mask, np.uint8)
+    out = np.empty_like(m)
+    lib().orc_dilate_rect_u8(_p(m), m.shape[0], m.shape[1], int(kw), int(kh), _p(out))
+    return out
+
+
+def distance_transform_l1(mask):
+    m = _c(mask, np.uint8)
+    out = np.empty(m.shape, np.float32)
+    lib().orc_distance_transform_l1(_p(m), m.shape[0], m.shape[1], _p(out))
+    return out
+
+
+def feather_weight_map(mask, sharpness):
+    m = _c(mask, np.uint8)
+    out = np.empty(m.shape, np.float32)
+    lib().orc_feather_weight_map(_p(m), m.shape[0], m.shape[1], C.c_float(sharpness), _p(out))
+    return out
+
+
+class Feather:
+    """orc_fb_*: OpenCV 3.4.2 FeatherBlender restated (the blender every reference demo runs, W:278-280)."""
+
+    def __init__(self, sharpness=0.02):
+        lib().orc_fb_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_fb_create(C.c_float(sharpness)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_fb_destroy(self.h)
+            self.h = None
+
+    def prepare(self, corners, sizes):
+        c = _c(np.asarray(corners).reshape(-1), np.int32)
+        s = _c(np.asarray(sizes).reshape(-1), np.int32)
+        lib().orc_fb_prepare(self.h, len(c) // 2, _p(c), _p(s))
+
+    def result_size(self):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_fb_result_size(self.h, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def feed(self, img, mask, tl):
+        img, mask = _c(img, np.int16), _c(mask, np.uint8)
+        lib().orc_fb_feed(self.h, _p(img), _p(mask), img.shape[0], img.shape[1], int(tl[0]), int(tl[1]))
+
+    def blend(self):
+        w, h = self.result_size()
+        dst, m = np.empty((h, w, 3), np.int16), np.empty((h, w), np.uint8)
+        lib().orc_fb_blend(self.h, _p(dst), _p(m))
+        return dst, m
+
+
 # ---------------------------------------------------------------- A13
 def blend_pair_linear(img1, img2, tl1, tl2):
     img1, img2 = _c(img1, np.float32), _c(img2, np.float32)

@@ -810,3 +810,124 @@ int orc_blend_pair_linear(const float* img1, int rows1, int cols1,
     free(costV); free(seam); free(ga); free(gb); free(m1); free(m2);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N3  mask preparation  W:286-301: dilate(masks_seam, MORPH_RECT 20x20) then & masks_warped     */
+/* ------------------------------------------------------------------------------------------ */
+/* cv::dilate with a MORPH_RECT kernel, default anchor (-1,-1) = (kw/2, kh/2), BORDER_CONSTANT with
+ * morphologyDefaultBorderValue (outside pixels never win the max): out(x,y) = max src over
+ * [x - kw/2, x - kw/2 + kw) x [y - kh/2, y - kh/2 + kh) clipped to the image.  (OpenCV 3.4.2
+ * imgproc/src/morph.cpp; source absent: parity unpinned, known-answer tests only.) */
+void orc_dilate_rect_u8(const uint8_t* src, int h, int w, int kw, int kh, uint8_t* dst) {
+    int ax = kw / 2, ay = kh / 2;
+    uint8_t* tmp = (uint8_t*)malloc((size_t)h * w);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int lo = x - ax < 0 ? 0 : x - ax, hi = x - ax + kw > w ? w : x - ax + kw, m = 0;
+            for (int k = lo; k < hi; ++k) if (src[(size_t)y * w + k] > m) m = src[(size_t)y * w + k];
+            tmp[(size_t)y * w + x] = (uint8_t)m;
+        }
+    for (int y = 0; y < h; ++y) {
+        int lo = y - ay < 0 ? 0 : y - ay, hi = y - ay + kh > h ? h : y - ay + kh;
+        for (int x = 0; x < w; ++x) {
+            int m = 0;
+            for (int k = lo; k < hi; ++k) if (tmp[(size_t)k * w + x] > m) m = tmp[(size_t)k * w + x];
+            dst[(size_t)y * w + x] = (uint8_t)m;
+        }
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* N2  FeatherBlender  W:278-281,302,313 (OpenCV 3.4.2 stitching/src/blenders.cpp, absent)       */
+/* ------------------------------------------------------------------------------------------ */
+/* distanceTransform(mask, CV_32F, DIST_L1, 3) = distanceTransform_3x3 with metrics {1, 2} in 16.16 fixed
+ * point (imgproc/src/distransform.cpp): a 1-pixel border of INIT_DIST0, forward + backward chamfer pass. */
+void orc_distance_transform_l1(const uint8_t* src, int h, int w, float* dst) {
+    const unsigned HV = 1u << 16, DIAG = 2u << 16, INIT = (unsigned)(INT_MAX >> 2);
+    const float scale = 1.f / 65536.f;
+    int step = w + 2;
+    unsigned* t = (unsigned*)malloc((size_t)(h + 2) * step * sizeof(unsigned));
+    for (size_t i = 0; i < (size_t)(h + 2) * step; ++i) t[i] = INIT;
+    for (int i = 0; i < h; ++i) {
+        unsigned* tmp = t + (size_t)(i + 1) * step + 1;
+        for (int j = 0; j < w; ++j) {
+            if (!src[(size_t)i * w + j]) tmp[j] = 0;
+            else {
+                unsigned t0 = tmp[j - step - 1] + DIAG, v = tmp[j - step] + HV;
+                if (t0 > v) t0 = v;
+                v = tmp[j - step + 1] + DIAG; if (t0 > v) t0 = v;
+                v = tmp[j - 1] + HV; if (t0 > v) t0 = v;
+                tmp[j] = t0;
+            }
+        }
+    }
+    for (int i = h - 1; i >= 0; --i) {
+        unsigned* tmp = t + (size_t)(i + 1) * step + 1;
+        for (int j = w - 1; j >= 0; --j) {
+            unsigned t0 = tmp[j];
+            if (t0 > HV) {
+                unsigned v = tmp[j + step + 1] + DIAG; if (t0 > v) t0 = v;
+                v = tmp[j + step] + HV; if (t0 > v) t0 = v;
+                v = tmp[j + step - 1] + DIAG; if (t0 > v) t0 = v;
+                v = tmp[j + 1] + HV; if (t0 > v) t0 = v;
+                tmp[j] = t0;
+            }
+            dst[(size_t)i * w + j] = (float)t0 * scale;
+        }
+    }
+    free(t);
+}
+
+/* createWeightMap: distanceTransform, multiply(weight, sharpness), threshold(1.f, THRESH_TRUNC) */
+void orc_feather_weight_map(const uint8_t* mask, int h, int w, float sharpness, float* weight) {
+    orc_distance_transform_l1(mask, h, w, weight);
+    for (size_t i = 0; i < (size_t)h * w; ++i) {
+        float v = weight[i] * sharpness;
+        weight[i] = v > 1.f ? 1.f : v;
+    }
+}
+
+struct orc_fb { float sharpness; int rx, ry, rw, rh; int16_t* dst; float* wgt; };
+orc_fb* orc_fb_create(float sharpness) { orc_fb* b = (orc_fb*)calloc(1, sizeof(orc_fb)); b->sharpness = sharpness; return b; }
+void orc_fb_destroy(orc_fb* b) { if (b) { free(b->dst); free(b->wgt); free(b); } }
+void orc_fb_prepare(orc_fb* b, int n, const int* c, const int* s) {
+    int tlx = INT_MAX, tly = INT_MAX, brx = INT_MIN, bry = INT_MIN;
+    for (int i = 0; i < n; ++i) {
+        if (c[2 * i] < tlx) tlx = c[2 * i];
+        if (c[2 * i + 1] < tly) tly = c[2 * i + 1];
+        if (c[2 * i] + s[2 * i] > brx) brx = c[2 * i] + s[2 * i];
+        if (c[2 * i + 1] + s[2 * i + 1] > bry) bry = c[2 * i + 1] + s[2 * i + 1];
+    }
+    free(b->dst); free(b->wgt);
+    b->rx = tlx; b->ry = tly; b->rw = brx - tlx; b->rh = bry - tly;
+    b->dst = (int16_t*)calloc((size_t)b->rw * b->rh * 3, sizeof(int16_t));
+    b->wgt = (float*)calloc((size_t)b->rw * b->rh, sizeof(float));
+}
+void orc_fb_result_size(const orc_fb* b, int* w, int* h) { *w = b->rw; *h = b->rh; }
+void orc_fb_feed(orc_fb* b, const int16_t* img, const uint8_t* mask, int rows, int cols, int tl_x, int tl_y) {
+    float* wm = (float*)malloc((size_t)rows * cols * sizeof(float));
+    orc_feather_weight_map(mask, rows, cols, b->sharpness, wm);
+    int dx = tl_x - b->rx, dy = tl_y - b->ry;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            size_t di = (size_t)(dy + y) * b->rw + dx + x, si = (size_t)y * cols + x;
+            float w = wm[si];
+            for (int c = 0; c < 3; ++c)
+                b->dst[di * 3 + c] = (int16_t)(b->dst[di * 3 + c] + f2s_trunc((float)img[si * 3 + c] * w));
+            b->wgt[di] = b->wgt[di] + w;
+        }
+    free(wm);
+}
+void orc_fb_blend(orc_fb* b, int16_t* dst, uint8_t* dst_mask) {
+    size_t n = (size_t)b->rw * b->rh;
+    for (size_t k = 0; k < n; ++k) {
+        float d = b->wgt[k] + WEIGHT_EPS;
+        int on = b->wgt[k] > WEIGHT_EPS;
+        if (dst_mask) dst_mask[k] = on ? 255 : 0;
+        for (int c = 0; c < 3; ++c) {
+            int16_t v = f2s_trunc((float)b->dst[k * 3 + c] / d);   /* normalizeUsingWeightMap */
+            dst[k * 3 + c] = on ? v : 0;                            /* Blender::blend: setTo(0, mask == 0) */
+        }
+    }
+}

@@ -102,6 +102,18 @@ int  orc_blend_pair_linear(const float* img1, int rows1, int cols1,
                            const float* img2, int rows2, int cols2,
                            int tl1x, int tl1y, int tl2x, int tl2y, float* pano, int* seam_x);
 
+/* N3 mask preparation W:286-301 (cv::dilate MORPH_RECT) and N2 FeatherBlender W:278-281,302,313 */
+void orc_dilate_rect_u8(const uint8_t* src, int h, int w, int kw, int kh, uint8_t* dst);
+void orc_distance_transform_l1(const uint8_t* src, int h, int w, float* dst);
+void orc_feather_weight_map(const uint8_t* mask, int h, int w, float sharpness, float* weight);
+typedef struct orc_fb orc_fb;
+orc_fb* orc_fb_create(float sharpness);
+void    orc_fb_destroy(orc_fb* b);
+void    orc_fb_prepare(orc_fb* b, int n, const int* corners_xy, const int* sizes_wh);
+void    orc_fb_result_size(const orc_fb* b, int* w, int* h);
+void    orc_fb_feed(orc_fb* b, const int16_t* img, const uint8_t* mask, int rows, int cols, int tl_x, int tl_y);
+void    orc_fb_blend(orc_fb* b, int16_t* dst, uint8_t* dst_mask);
+
 #ifdef __cplusplus
 }
 #endif

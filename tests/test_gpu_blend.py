@@ -135,7 +135,7 @@ def test_blender_errors(gpu):
         mb.blend()
     assert e.value.code == 3  # blend() released the pyramids
     with pytest.raises(gpu.IsxError):
-        gpu.Blender.createDefault(gpu.Blender.FEATHER)
+        gpu.Blender.createDefault(gpu.Blender.NO)
 
 
 @pytest.mark.parametrize("dy", [3, -5, 0])

@@ -164,3 +164,37 @@ def test_linear_blend_properties(oracle):
     assert np.allclose(pano, 100.0, atol=1e-3)
     rc, _, _ = oracle.blend_pair_linear(a, b, (0, 0), (200, 0))
     assert rc == 1                                                                     # no overlap: B:182-183
+
+
+def test_dilate_and_distance_transform_known_answers(oracle):
+    m = np.zeros((9, 12), np.uint8)
+    m[4, 5] = 255
+    d = oracle.dilate_rect(m, 4, 3)              # anchor (2, 1): columns x-2..x+1 -> 4..7, rows y-1..y+1 -> 3..5
+    exp = np.zeros_like(m)
+    exp[3:6, 4:8] = 255
+    assert np.array_equal(d, exp)
+    d20 = oracle.dilate_rect(m, 20, 20)          # 20x20 (W:286): window [x-10, x+9] around the pixel, mirrored for the set pixel
+    ys, xs = np.nonzero(d20)
+    assert xs.min() == max(5 - 9, 0) and xs.max() == min(5 + 10, 11)
+    rng = np.random.default_rng(0)
+    mk = (rng.random((40, 55)) > 0.02).astype(np.uint8) * 255
+    dt = oracle.distance_transform_l1(mk)
+    ys, xs = np.nonzero(mk == 0)
+    Y, X = np.mgrid[0:40, 0:55]
+    brute = np.min(np.abs(Y[..., None] - ys) + np.abs(X[..., None] - xs), axis=2)
+    assert np.array_equal(dt, brute.astype(np.float32))          # chamfer {1, 2} == exact city-block distance
+    full = oracle.distance_transform_l1(np.full((3, 5), 255, np.uint8))
+    assert full.tolist() == [[8193.0] * 5, [8193.0, 8194.0, 8194.0, 8194.0, 8193.0], [8193.0] * 5]   # INIT_DIST0 border ring
+    w = oracle.feather_weight_map(np.pad(np.full((30, 30), 255, np.uint8), 1), 0.1)
+    assert w[0, 0] == 0.0 and w[1, 1] == np.float32(1.0) * np.float32(0.1) and w[16, 16] == 1.0 and abs(w[5, 16] - 0.5) < 1e-6
+
+
+def test_feather_properties(oracle):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (60, 80, 3)).astype(np.int16)
+    full = np.full((60, 80), 255, np.uint8)
+    fb = oracle.Feather(0.1)
+    fb.prepare([(0, 0)], [(80, 60)])
+    fb.feed(img, full, (0, 0))
+    d, m = fb.blend()
+    assert np.all(m == 255) and np.abs(d.astype(int) - img).max() <= 1 and (d.astype(int) - img).max() <= 0   # weight 1, -1 truncation bias
