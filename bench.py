@@ -189,16 +189,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up; the last warm-up step runs with every kernel bracketed to find the dominant one
+    # warm-up; the last warm-up step runs serialised (the reference's own call sequence, ROI scan on the launch
+    # stream, no side-stream overlap) with every kernel bracketed by HIP events: isolated durations, from which the
+    # dominant kernel is chosen.  In the live planned step the ROI verification runs concurrently on a side stream and
+    # would be charged to whichever kernel it overlaps.
     for _ in range(max(args.warmup - 1, 0)):
         step()
     fence()
     lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_reset()
-    if args.graph:   # graph replays cannot be bracketed kernel by kernel: profile one eager step instead
-        for p in pairs:
-            p.step()
-    else:
-        step()
+    for p in pairs:
+        p.step_sync()
     ent = _lib.profile_entries()
     per_kernel = {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "alg_MB": round(v["alg_bytes"] / 1e6, 2)} for k, v in ent.items()}
     # dominant kernel = the heaviest single launch of the step (largest average launch duration)

@@ -229,14 +229,14 @@ constexpr int PD_WAVES = 8;
 constexpr int PD_RPW = (PD_NR + PD_WAVES - 1) / PD_WAVES;
 
 template <int M, int SK>
-__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst) {
+__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by) {
     using WT = typename WorkT<M>::t;
     __shared__ Px<M> hb[PD_NR][WAVE];
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
     const int sh = (SK == SK_LEVEL) ? src.rows : s0.height;
     const int dw = dst.cols, dh = dst.rows;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ox = blockIdx.x * PD_OW + lane - 1, oy0 = blockIdx.y * PD_TY;
+    const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
     const int cA = reflect101(2 * ox, sw), cB = reflect101(2 * ox + 1, sw);
     Px<M> A[PD_RPW], B[PD_RPW];
 #pragma unroll
@@ -287,7 +287,7 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
 
 template <int M, int SK>
 __global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBuf dst) {
-    pyr_down_block<M, SK>(s0, src, dst);
+    pyr_down_block<M, SK>(s0, src, dst, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
     if (blockIdx.x * PD_OW >= dst.cols || blockIdx.y * PD_TY >= dst.rows) return;
-    pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst);
+    pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y);
 }
 
 // top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t}))
@@ -755,27 +755,51 @@ __global__ __launch_bounds__(256) void k_dt_rows(const unsigned char* mask, size
     for (int x = c1 - 1; x >= c0; --x) { if (!m[x]) cur = x; int d = cur >= DT_BIG ? DT_BIG : cur - x; out[x] = min(out[x], d); }
 }
 
-// one thread per column: forward then backward sweep, then the weight map (in place: int -> float)
-__global__ __launch_bounds__(64) void k_dt_cols_weight(int* rowd, int rows, int cols, float sharpness) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
+// Column pass.  The "+1" sweeps are min-plus scans: forward d_f[y] = y + min_{k<=y}(r[k] - k), backward
+// d_b[y] = -y + min_{k>=y}(r[k] + k), result min(d_f, d_b) — so they parallelise as prefix / suffix minima over
+// DT_SEG-row segments: k_dt_seg_min reduces each segment, k_dt_cols_weight combines the segments before / after its
+// own, finishes the scans in registers and writes the weight map (in place: int -> float).
+constexpr int DT_SEG = 32;
+
+__global__ __launch_bounds__(64) void k_dt_seg_min(const int* rowd, int rows, int cols, int* seg_f, int* seg_b) {
+    const int x = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
     if (x >= cols) return;
-    int d = DT_BIG;
-    for (int y = 0; y < rows; ++y) {
-        int* p = rowd + (size_t)y * cols + x;
-        d = min(d + 1, *p);
-        *p = d;
+    const int y0 = s * DT_SEG;
+    int mf = 2 * DT_BIG, mb = 2 * DT_BIG;
+#pragma unroll 8
+    for (int j = 0; j < DT_SEG; ++j) {
+        const int y = y0 + j;
+        if (y < rows) { const int r = rowd[(size_t)y * cols + x]; mf = min(mf, r - y); mb = min(mb, r + y); }
     }
-    d = DT_BIG;
+    seg_f[(size_t)s * cols + x] = mf;
+    seg_b[(size_t)s * cols + x] = mb;
+}
+
+__global__ __launch_bounds__(64) void k_dt_cols_weight(int* rowd, int rows, int cols, const int* seg_f, const int* seg_b, int nseg,
+                                                       float sharpness) {
+    const int x = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
+    if (x >= cols) return;
+    const int y0 = s * DT_SEG;
+    int run_f = 2 * DT_BIG, run_b = 2 * DT_BIG;
+    for (int i = 0; i < s; ++i) run_f = min(run_f, seg_f[(size_t)i * cols + x]);
+    for (int i = nseg - 1; i > s; --i) run_b = min(run_b, seg_b[(size_t)i * cols + x]);
+    int r[DT_SEG], db[DT_SEG];
+#pragma unroll
+    for (int j = 0; j < DT_SEG; ++j) r[j] = y0 + j < rows ? rowd[(size_t)(y0 + j) * cols + x] : DT_BIG;
+#pragma unroll
+    for (int j = DT_SEG - 1; j >= 0; --j) { run_b = min(run_b, r[j] + (y0 + j)); db[j] = run_b - (y0 + j); }
     const unsigned INIT = (unsigned)(INT_MAX >> 2);
-    for (int y = rows - 1; y >= 0; --y) {
-        int* p = rowd + (size_t)y * cols + x;
-        d = min(d + 1, *p);
+#pragma unroll
+    for (int j = 0; j < DT_SEG; ++j) {
+        const int y = y0 + j;
+        run_f = min(run_f, r[j] - y);
+        const int d = min(run_f + y, db[j]);
         // chamfer value in 16.16: city-block distance to a zero pixel, or INIT_DIST0 + distance to the border ring
         const unsigned border = INIT + ((unsigned)(1 + min(min(x, cols - 1 - x), min(y, rows - 1 - y))) << 16);
         const unsigned t0 = d >= DT_BIG / 2 ? border : min((unsigned)d << 16, border);
         float w = ((float)t0 * (1.f / 65536.f)) * sharpness;       // multiply(weight, sharpness)
         w = w > 1.f ? 1.f : w;                                      // threshold(1.f, THRESH_TRUNC)
-        *(float*)p = w;
+        if (y < rows) *(float*)(rowd + (size_t)y * cols + x) = w;
     }
 }
 
@@ -1227,10 +1251,16 @@ int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int
     ISX_TRY(b->st_img.use_in(img, st, "feed: img"));
     ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
     const int rows = img->rows, cols = img->cols;
-    ISX_TRY(b->feather_w.reserve((size_t)rows * cols * 4));
+    const int nseg = cdiv(rows, DT_SEG);
+    const size_t map_bytes = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
+    ISX_TRY(b->feather_w.reserve(map_bytes + (size_t)nseg * cols * 8));
     int* rowd = (int*)b->feather_w.p;
+    int* seg_f = (int*)((char*)b->feather_w.p + map_bytes);
+    int* seg_b = seg_f + (size_t)nseg * cols;
     ISX_LAUNCH("dt_rows", (double)rows * cols * 5.0, st, k_dt_rows, dim3(rows), dim3(256), 0, (const unsigned char*)b->st_mask.d.data, b->st_mask.d.step, rows, cols, rowd);
-    ISX_LAUNCH("dt_cols_weight", (double)rows * cols * 16.0, st, k_dt_cols_weight, dim3(cdiv(cols, 64)), dim3(64), 0, rowd, rows, cols, b->sharpness);
+    ISX_LAUNCH("dt_seg_min", (double)rows * cols * 4.0, st, k_dt_seg_min, dim3(cdiv(cols, 64), nseg), dim3(64), 0, (const int*)rowd, rows, cols, seg_f, seg_b);
+    ISX_LAUNCH("dt_cols_weight", (double)rows * cols * 8.0, st, k_dt_cols_weight, dim3(cdiv(cols, 64), nseg), dim3(64), 0, rowd, rows, cols, (const int*)seg_f,
+               (const int*)seg_b, nseg, b->sharpness);
     dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
     const double bytes = (double)rows * cols * ((u8_entry ? 3.0 : 6.0) + 4.0 + 2.0 * 10.0);
     if (u8_entry) ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_U8>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step, (const float*)rowd, rows, cols, b->dst[0], dx, dy);

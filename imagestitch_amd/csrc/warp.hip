@@ -211,6 +211,9 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
     const unsigned step = (unsigned)img.step;
     const unsigned mis = (unsigned)((uintptr_t)base & 3);                     // misalignment of the base pointer
     const unsigned safe_end = (unsigned)(img.rows - 1) * step + (unsigned)img.cols * 3 + mis;
+    const float hx = (float)img.cols - 0.5f, hy = (float)img.rows - 0.5f;
+    const float hi_x = ((img.cols - 1) & 1) ? hx : __uint_as_float(__float_as_uint(hx) + 1u);
+    const float hi_y = ((img.rows - 1) & 1) ? hy : __uint_as_float(__float_as_uint(hy) + 1u);
     float mx[4], my[4];
     unsigned wq[4];        // fx | fy << 8
     unsigned o0[4], o1[4]; // byte offsets of the two rows relative to the ALIGNED base (base - mis)
@@ -265,9 +268,10 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
         } else px[k] = 0;
         if (k < n) {
             if (has_mask) m[k] = slow_nearest_u8(msk.data, (unsigned)msk.step, msk.rows, msk.cols, mx[k], my[k]);
-            else {  // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT; short saturation cannot turn an outside index into an inside one
-                const int sx = cvround_x86(mx[k]), sy = cvround_x86(my[k]);
-                m[k] = ((unsigned)sx < (unsigned)img.cols && (unsigned)sy < (unsigned)img.rows) ? 255u : 0u;
+            else {  // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT: 255 iff cvRound(x) in [0, cols) and cvRound(y) in [0, rows).
+                // Round-half-even makes that an interval test: x >= -0.5 (the tie -0.5 rounds to 0) and x < cols - 0.5, the
+                // upper tie cols - 0.5 rounding to cols - 1 exactly when cols - 1 is even (hi_* is then one ulp larger).  NaN fails.
+                m[k] = (mx[k] >= -0.5f && mx[k] < hi_x && my[k] >= -0.5f && my[k] < hi_y) ? 255u : 0u;
             }
         } else m[k] = 0;
     }
