@@ -734,25 +734,103 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
 // ------------------------------------------------------------------------------------------------
 constexpr int DT_BIG = 1 << 28;
 
-// one block per row: rowd[y][x] = |x - nearest zero of row y| (DT_BIG when the row has no zero)
-__global__ __launch_bounds__(256) void k_dt_rows(const unsigned char* mask, size_t mstep, int rows, int cols, int* rowd) {
-    __shared__ int s_last[256], s_next[256];
-    const int y = blockIdx.x, t = threadIdx.x;
-    const unsigned char* m = mask + (size_t)y * mstep;
-    const int chunk = (cols + 255) / 256, c0 = min(t * chunk, cols), c1 = min(c0 + chunk, cols);
-    int last = -DT_BIG, next = DT_BIG;
-    for (int x = c0; x < c1; ++x) if (!m[x]) { last = x; if (next == DT_BIG) next = x; }
-    s_last[t] = last; s_next[t] = next;
-    __syncthreads();
-    // exclusive prefix-max of the chunks' last zero, exclusive suffix-min of their first zero (256 entries: serial per thread is fine)
-    int pl = -DT_BIG, nn = DT_BIG;
-    for (int i = 0; i < t; ++i) pl = max(pl, s_last[i]);
-    for (int i = 255; i > t; --i) nn = min(nn, s_next[i]);
-    int* out = rowd + (size_t)y * cols;
-    int cur = pl;
-    for (int x = c0; x < c1; ++x) { if (!m[x]) cur = x; out[x] = cur <= -DT_BIG ? DT_BIG : x - cur; }
-    cur = nn;
-    for (int x = c1 - 1; x >= c0; --x) { if (!m[x]) cur = x; int d = cur >= DT_BIG ? DT_BIG : cur - x; out[x] = min(out[x], d); }
+// Row pass, one block per row: rowd[y][x] = |x - nearest zero of row y| (DT_BIG when the row has no zero).
+// Each thread owns 16 consecutive pixels (the row is staged through LDS as aligned dwords, so any mask pointer /
+// step works), finds the last / first zero inside them, the block combines those with an exclusive prefix-max /
+// suffix-min (wave shuffles + 4 LDS words), and the thread writes its 16 distances as four int4 stores (the row
+// pitch of the map is a multiple of 4).  Rows wider than 4096 take a forward sweep over their chunks followed by
+// a backward sweep that min-merges in place.
+constexpr int DTR_PX = 16;
+constexpr int DTR_CHUNK = 256 * DTR_PX;
+
+__global__ __launch_bounds__(256) void k_dt_rows(const unsigned char* mask, size_t mstep, int rows, int cols, int* rowd, int pitch) {
+    __shared__ unsigned s_row[DTR_CHUNK / 4 + 4];
+    __shared__ int s_wl[4], s_wf[4];
+    const int y = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned char* mrow = mask + (size_t)y * mstep;
+    int* out = rowd + (size_t)y * pitch;
+    const int nch = (cols + DTR_CHUNK - 1) / DTR_CHUNK;
+    int carry_last = -DT_BIG, carry_first = DT_BIG;
+    for (int pass = 0; pass < (nch > 1 ? 2 : 1); ++pass) {
+        const bool fwd = pass == 0, bwd = pass == 1 || nch == 1;
+        for (int ci = 0; ci < nch; ++ci) {
+            const int c = pass == 0 ? ci : nch - 1 - ci;
+            const int xb = c * DTR_CHUNK, n = min(DTR_CHUNK, cols - xb);
+            const unsigned char* p = mrow + xb;
+            const unsigned mis = (unsigned)((uintptr_t)p & 3);
+            const unsigned* pa = (const unsigned*)(p - mis);   // every dword read holds at least one byte of the row
+            const int ndw = (n + (int)mis + 3) >> 2;
+            __syncthreads();
+            for (int i = t; i < ndw; i += 256) s_row[i] = pa[i];
+            __syncthreads();
+            const uint4 q = ((const uint4*)s_row)[t];
+            const unsigned q4 = s_row[4 * t + 4];
+            const unsigned w[4] = {__builtin_amdgcn_alignbyte(q.y, q.x, mis), __builtin_amdgcn_alignbyte(q.z, q.y, mis),
+                                   __builtin_amdgcn_alignbyte(q.w, q.z, mis), __builtin_amdgcn_alignbyte(q4, q.w, mis)};
+            const int x0 = DTR_PX * t;
+            int f[DTR_PX], g[DTR_PX];
+            int last = -DT_BIG, first = DT_BIG;
+#pragma unroll
+            for (int i = 0; i < DTR_PX; ++i) {
+                const bool z = ((w[i >> 2] >> (8 * (i & 3))) & 255u) == 0u && x0 + i < n;
+                last = z ? xb + x0 + i : last;
+                f[i] = last;
+            }
+#pragma unroll
+            for (int i = DTR_PX - 1; i >= 0; --i) {
+                const bool z = ((w[i >> 2] >> (8 * (i & 3))) & 255u) == 0u && x0 + i < n;
+                first = z ? xb + x0 + i : first;
+                g[i] = first;
+            }
+            int pl = -DT_BIG, nn = DT_BIG;
+            if (fwd) {
+                int v = last;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v = max(v, u); }
+                pl = __shfl_up(v, 1);
+                if (lane == 0) pl = -DT_BIG;
+                if (lane == 63) s_wl[wv] = v;
+            }
+            if (bwd) {
+                int v = first;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_down(v, o); if (lane + o < 64) v = min(v, u); }
+                nn = __shfl_down(v, 1);
+                if (lane == 63) nn = DT_BIG;
+                if (lane == 0) s_wf[wv] = v;
+            }
+            __syncthreads();
+            if (fwd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i < wv) pl = max(pl, s_wl[i]);
+                pl = max(pl, carry_last);
+                carry_last = max(max(carry_last, max(s_wl[0], s_wl[1])), max(s_wl[2], s_wl[3]));
+            }
+            if (bwd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i > wv) nn = min(nn, s_wf[i]);
+                nn = min(nn, carry_first);
+                carry_first = min(min(carry_first, min(s_wf[0], s_wf[1])), min(s_wf[2], s_wf[3]));
+            }
+#pragma unroll
+            for (int k = 0; k < DTR_PX / 4; ++k) {
+                const int gx0 = xb + x0 + 4 * k;
+                if (gx0 >= pitch || x0 + 4 * k >= n) continue;
+                int d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * k + j, gx = gx0 + j;
+                    int v = DT_BIG;
+                    if (fwd) v = gx - max(f[i], pl);
+                    if (bwd) v = min(v, min(g[i], nn) - gx);
+                    d[j] = v >= DT_BIG / 2 ? DT_BIG : v;
+                }
+                int4* o4 = (int4*)(out + gx0);
+                if (!fwd) { const int4 e = *o4; d[0] = min(d[0], e.x); d[1] = min(d[1], e.y); d[2] = min(d[2], e.z); d[3] = min(d[3], e.w); }
+                *o4 = make_int4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
 }
 
 // Column pass.  The "+1" sweeps are min-plus scans: forward d_f[y] = y + min_{k<=y}(r[k] - k), backward
@@ -761,7 +839,7 @@ __global__ __launch_bounds__(256) void k_dt_rows(const unsigned char* mask, size
 // own, finishes the scans in registers and writes the weight map (in place: int -> float).
 constexpr int DT_SEG = 32;
 
-__global__ __launch_bounds__(64) void k_dt_seg_min(const int* rowd, int rows, int cols, int* seg_f, int* seg_b) {
+__global__ __launch_bounds__(64) void k_dt_seg_min(const int* rowd, int pitch, int rows, int cols, int* seg_f, int* seg_b) {
     const int x = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
     if (x >= cols) return;
     const int y0 = s * DT_SEG;
@@ -769,23 +847,25 @@ __global__ __launch_bounds__(64) void k_dt_seg_min(const int* rowd, int rows, in
 #pragma unroll 8
     for (int j = 0; j < DT_SEG; ++j) {
         const int y = y0 + j;
-        if (y < rows) { const int r = rowd[(size_t)y * cols + x]; mf = min(mf, r - y); mb = min(mb, r + y); }
+        if (y < rows) { const int r = rowd[(size_t)y * pitch + x]; mf = min(mf, r - y); mb = min(mb, r + y); }
     }
     seg_f[(size_t)s * cols + x] = mf;
     seg_b[(size_t)s * cols + x] = mb;
 }
 
-__global__ __launch_bounds__(64) void k_dt_cols_weight(int* rowd, int rows, int cols, const int* seg_f, const int* seg_b, int nseg,
+__global__ __launch_bounds__(64) void k_dt_cols_weight(int* rowd, int pitch, int rows, int cols, const int* seg_f, const int* seg_b, int nseg,
                                                        float sharpness) {
     const int x = blockIdx.x * 64 + threadIdx.x, s = blockIdx.y;
     if (x >= cols) return;
     const int y0 = s * DT_SEG;
     int run_f = 2 * DT_BIG, run_b = 2 * DT_BIG;
+#pragma unroll 4
     for (int i = 0; i < s; ++i) run_f = min(run_f, seg_f[(size_t)i * cols + x]);
+#pragma unroll 4
     for (int i = nseg - 1; i > s; --i) run_b = min(run_b, seg_b[(size_t)i * cols + x]);
     int r[DT_SEG], db[DT_SEG];
 #pragma unroll
-    for (int j = 0; j < DT_SEG; ++j) r[j] = y0 + j < rows ? rowd[(size_t)(y0 + j) * cols + x] : DT_BIG;
+    for (int j = 0; j < DT_SEG; ++j) r[j] = y0 + j < rows ? rowd[(size_t)(y0 + j) * pitch + x] : DT_BIG;
 #pragma unroll
     for (int j = DT_SEG - 1; j >= 0; --j) { run_b = min(run_b, r[j] + (y0 + j)); db[j] = run_b - (y0 + j); }
     const unsigned INIT = (unsigned)(INT_MAX >> 2);
@@ -799,20 +879,22 @@ __global__ __launch_bounds__(64) void k_dt_cols_weight(int* rowd, int rows, int 
         const unsigned t0 = d >= DT_BIG / 2 ? border : min((unsigned)d << 16, border);
         float w = ((float)t0 * (1.f / 65536.f)) * sharpness;       // multiply(weight, sharpness)
         w = w > 1.f ? 1.f : w;                                      // threshold(1.f, THRESH_TRUNC)
-        if (y < rows) *(float*)(rowd + (size_t)y * cols + x) = w;
+        if (y < rows) *(float*)(rowd + (size_t)y * pitch + x) = w;
     }
 }
 
 template <int SK>
-__global__ __launch_bounds__(256) void k_feather_acc(const unsigned char* img, size_t istep, const float* weight, int rows, int cols,
-                                                     LevelBuf dst, int dx, int dy) {
+__global__ __launch_bounds__(256) void k_feather_acc(const unsigned char* img, size_t istep, const float* weight, int wpitch, int rows, int cols,
+                                                     LevelBuf dst, int dx, int dy, Cover cov) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     int c0, c1, c2;
     if constexpr (SK == SK_U8) { const unsigned char* q = img + (size_t)y * istep + (size_t)x * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
     else { const short* q = (const short*)(img + (size_t)y * istep) + (size_t)x * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
-    const float w = weight[(size_t)y * cols + x];
-    Px<M_I16> d = load_px<M_I16, true>(dst, dx + x, dy + y);
+    const float w = weight[(size_t)y * wpitch + x];
+    Px<M_I16> d;   // dst_ / dst_weight_map_ are not cleared by prepare(): a pixel no earlier feed covered is zero by definition
+    if (covered(cov, dx + x, dy + y)) d = load_px<M_I16, true>(dst, dx + x, dy + y);
+    else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
     d.c0 = wrap_s16(d.c0 + f2s_x86((float)c0 * w));
     d.c1 = wrap_s16(d.c1 + f2s_x86((float)c1 * w));
     d.c2 = wrap_s16(d.c2 + f2s_x86((float)c2 * w));
@@ -820,15 +902,189 @@ __global__ __launch_bounds__(256) void k_feather_acc(const unsigned char* img, s
     store_px<M_I16, true>(dst, dx + x, dy + y, d);
 }
 
-__global__ __launch_bounds__(256) void k_feather_blend(LevelBuf dst, OutMat out) {
+__global__ __launch_bounds__(256) void k_feather_blend(LevelBuf dst, OutMat out, Cover cov) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dst.cols || y >= dst.rows) return;
-    Px<M_I16> d = load_px<M_I16, true>(dst, x, y);
+    Px<M_I16> d;
+    if (covered(cov, x, y)) d = load_px<M_I16, true>(dst, x, y);
+    else { d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f; }
     normalise<M_I16>(d);
     write_final<M_I16>(out, x, y, d);
 }
 
-// N3  dilate(mask, MORPH_RECT kw x kh) [& other]  (W:286-301): separable running max, anchor (kw/2, kh/2)
+// Deferred FeatherBlender cycle (isx_blender_set_deferred_level0): feed() only builds the tile's weight map, blend()
+// gathers dst(x, y) = SUM_t short(img_t * w_t) (wrapping, feed order) and SUM_t w_t over the tiles covering the pixel,
+// normalises and writes the caller's mats — dst_ / dst_weight_map_ are never materialised.  Adding the tiles that do
+// not cover a pixel would add exact zeros, so the result is the eager one bit for bit.
+struct FeatherSet {
+    int n;
+    const unsigned char* img[DEF_MAX];
+    size_t istep[DEF_MAX];
+    const float* wgt[DEF_MAX];
+    int wpitch[DEF_MAX];
+    int x[DEF_MAX], y[DEF_MAX], w[DEF_MAX], h[DEF_MAX];
+};
+
+template <int SK>
+__global__ __launch_bounds__(256) void k_feather_gather(FeatherSet fs, OutMat out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= out.cols || y >= out.rows) return;
+    Px<M_I16> d; d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f;
+    for (int t = 0; t < fs.n; ++t) {
+        const int lx = x - fs.x[t], ly = y - fs.y[t];
+        if ((unsigned)lx < (unsigned)fs.w[t] && (unsigned)ly < (unsigned)fs.h[t]) {
+            int c0, c1, c2;
+            if constexpr (SK == SK_U8) { const unsigned char* q = fs.img[t] + (size_t)ly * fs.istep[t] + (size_t)lx * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+            else { const short* q = (const short*)(fs.img[t] + (size_t)ly * fs.istep[t]) + (size_t)lx * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+            const float w = fs.wgt[t][(size_t)ly * fs.wpitch[t] + lx];
+            d.c0 = wrap_s16(d.c0 + f2s_x86((float)c0 * w));
+            d.c1 = wrap_s16(d.c1 + f2s_x86((float)c1 * w));
+            d.c2 = wrap_s16(d.c2 + f2s_x86((float)c2 * w));
+            d.w = d.w + w;
+        }
+    }
+    normalise<M_I16>(d);
+    write_final<M_I16>(out, x, y, d);
+}
+
+// N3  dilate(mask, MORPH_RECT kw x kh) [& other]  (W:286-301), anchor (kw/2, kh/2), pixels outside the image do
+// not take part.  Structuring elements up to 33 x 33 (the reference uses 20 x 20): one fused kernel, a 64 x 128
+// output tile per block — input tile + halo staged in LDS, row maxima into a second LDS plane, column maxima from
+// there; every thread produces 4 adjacent outputs from one run of k + 3 bytes (the k - 3 bytes common to the four
+// windows are reduced once).  Larger elements: the two generic kernels below through a temporary plane.
+constexpr int DIL_MAXK = 33, DIL_TW = 64, DIL_TH = 128, DIL_NT = 512;
+constexpr int DIL_AWD = (DIL_TW + DIL_MAXK - 1 + 3 + 3) / 4;   // dwords per staged row: 96 bytes + up to 3 of misalignment
+constexpr int DIL_AH = DIL_TH + DIL_MAXK - 1;   // 160
+
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+// four bytes as two pairs of 16-bit lanes (even bytes, odd bytes): v_pk_max_u16 then is a 4-way byte maximum
+struct B4 { unsigned e, o; };
+__device__ __forceinline__ B4 b4_split(unsigned d) { B4 r; r.e = d & 0x00ff00ffu; r.o = (d >> 8) & 0x00ff00ffu; return r; }
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    us2_t x, y;
+    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    const us2_t z = __builtin_elementwise_max(x, y);
+    unsigned r; __builtin_memcpy(&r, &z, 4);
+    return r;
+}
+__device__ __forceinline__ B4 b4_max(B4 a, B4 b) { B4 r; r.e = pk_max_u16(a.e, b.e); r.o = pk_max_u16(a.o, b.o); return r; }
+__device__ __forceinline__ unsigned b4_join(B4 a) { return a.e | (a.o << 8); }
+
+__global__ __launch_bounds__(DIL_NT) void k_dilate_and(const unsigned char* src, size_t sstep, int rows, int cols, int kw, int kh,
+                                                    const unsigned char* other, size_t ostep, unsigned char* dst, size_t dstep) {
+    // A: input tile + halo; LDS dword (r, j) = the 4 pixels of image row Y0 - ay + r from column X0 - ax + 4 j on, built
+    // from the two ALIGNED source dwords around them (v_alignbyte; 8 loads in flight per thread), outside pixels zeroed.
+    __shared__ unsigned A[DIL_AH][DIL_AWD];
+    __shared__ unsigned B[DIL_AH][DIL_TW / 4];     // row maxima, 4 columns per dword
+    const int X0 = blockIdx.x * DIL_TW, Y0 = blockIdx.y * DIL_TH, ax = kw / 2, ay = kh / 2;
+    const int th = min(DIL_TH, rows - Y0), ah = th + kh - 1;
+    const uintptr_t base = (uintptr_t)src + (intptr_t)(X0 - ax);
+    const unsigned* safe = (const unsigned*)((uintptr_t)src & ~(uintptr_t)3);
+    for (int i0 = threadIdx.x; i0 < ah * DIL_AWD; i0 += 4 * DIL_NT) {
+        unsigned lo[4], hi[4], keep[4], sh[4];
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * DIL_NT, ah * DIL_AWD - 1);
+            const int r = i / DIL_AWD, j = i - r * DIL_AWD;
+            const int gy = Y0 - ay + r;
+            const uintptr_t p = base + (uintptr_t)((intptr_t)gy * (intptr_t)sstep) + (uintptr_t)(4 * j);   // address of the first pixel
+            const int mis = (int)(p & 3);
+            const int gx0 = X0 - ax + 4 * j;                      // its image column
+            const bool rowok = (unsigned)gy < (unsigned)rows;
+            // an aligned dword may be read when it holds at least one byte of row gy
+            const bool any0 = rowok && gx0 - mis + 3 >= 0 && gx0 - mis < cols;
+            const bool any1 = rowok && mis != 0 && gx0 - mis + 7 >= 0 && gx0 - mis + 4 < cols;
+            unsigned m = 0xffffffffu;                             // bytes of the dword that are image pixels
+            if (gx0 < 0) m = gx0 <= -4 ? 0u : m << (8 * -gx0);
+            if (gx0 + 3 >= cols) m = gx0 >= cols ? 0u : m & (0xffffffffu >> (8 * (gx0 + 4 - cols)));
+            keep[u] = rowok ? m : 0u;
+            lo[u] = *(any0 ? (const unsigned*)(p - mis) : safe);
+            hi[u] = *(any1 ? (const unsigned*)(p - mis + 4) : safe);
+            sh[u] = (unsigned)mis;
+            idx[u] = i;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) (&A[0][0])[idx[u]] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh[u]) & keep[u];
+    }
+    __syncthreads();
+    // row pass: one task = 4 adjacent outputs (one dword) of one staged row.  With e(j) = (byte j, byte j + 2) as two 16-bit
+    // lanes, the even output bytes are max e(j) over [0, kw) and the odd ones max e(j) over [1, kw + 1): one packed running
+    // maximum over [1, kw) serves both.  e(4n) / e(4n+1) are the even / odd bytes of dword n, e(4n+2) / e(4n+3) those
+    // shifted by one 16-bit lane into dword n + 1.
+    for (int i = threadIdx.x; i < ah * (DIL_TW / 4); i += DIL_NT) {
+        const int r = i / (DIL_TW / 4), g = i % (DIL_TW / 4);
+        const unsigned* ar = &A[r][g];
+        const B4 first = b4_split(ar[0]);
+        B4 prev = first;
+        unsigned common = 0, ekw = 0;
+        for (int n = 0; 4 * n <= kw; ++n) {              // taps 4n .. 4n + 3 (uniform trip count)
+            const B4 next = b4_split(ar[n + 1]);
+            const unsigned t[4] = {prev.e, prev.o, __builtin_amdgcn_alignbyte(next.e, prev.e, 2), __builtin_amdgcn_alignbyte(next.o, prev.o, 2)};
+            if (n > 0 && 4 * n + 3 < kw) {
+                common = pk_max_u16(pk_max_u16(common, t[0]), pk_max_u16(t[1], pk_max_u16(t[2], t[3])));
+            } else {
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) {
+                    const int j = 4 * n + sft;
+                    if (j >= 1 && j < kw) common = pk_max_u16(common, t[sft]);
+                    if (j == kw) ekw = t[sft];
+                }
+            }
+            prev = next;
+        }
+        B4 o;
+        o.e = pk_max_u16(common, first.e);
+        o.o = pk_max_u16(common, ekw);
+        B[r][g] = b4_join(o);
+    }
+    __syncthreads();
+    // column pass: one task = 4 adjacent columns x 4 adjacent output rows, byte maxima as packed 16-bit maxima
+    for (int i = threadIdx.x; i < (DIL_TW / 4) * (DIL_TH / 4); i += DIL_NT) {
+        const int xg = i % (DIL_TW / 4), q = i / (DIL_TW / 4);
+        const int gx = X0 + 4 * xg;
+        if (4 * q >= th || gx >= cols) continue;
+        B4 o[4];
+        const B4 zero = {0u, 0u};
+        if (kh >= 4) {
+            B4 mid = zero;
+#pragma unroll 4
+            for (int k = 3; k < kh; ++k) mid = b4_max(mid, b4_split(B[4 * q + k][xg]));
+            const B4 a0 = b4_split(B[4 * q][xg]), a1 = b4_split(B[4 * q + 1][xg]), a2 = b4_split(B[4 * q + 2][xg]);
+            const B4 b0 = b4_split(B[4 * q + kh][xg]), b1 = b4_split(B[4 * q + kh + 1][xg]), b2 = b4_split(B[4 * q + kh + 2][xg]);
+            o[0] = b4_max(mid, b4_max(a0, b4_max(a1, a2)));      // rows past the staged ones only reach outputs past the image
+            o[1] = b4_max(mid, b4_max(a1, b4_max(a2, b0)));
+            o[2] = b4_max(mid, b4_max(a2, b4_max(b0, b1)));
+            o[3] = b4_max(mid, b4_max(b0, b4_max(b1, b2)));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = zero;
+                for (int k = 0; k < kh; ++k) o[j] = b4_max(o[j], b4_split(B[4 * q + j + k][xg]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = Y0 + 4 * q + j;
+            if (gy >= rows) continue;
+            unsigned m = b4_join(o[j]);
+            unsigned char* dp = dst + (size_t)gy * dstep + gx;
+            const unsigned char* op = other ? other + (size_t)gy * ostep + gx : nullptr;
+            if (gx + 3 < cols && ((uintptr_t)dp & 3) == 0 && ((uintptr_t)op & 3) == 0) {
+                if (op) m &= *(const unsigned*)op;
+                *(unsigned*)dp = m;
+            } else {
+                for (int k = 0; k < 4 && gx + k < cols; ++k) {
+                    unsigned v = (m >> (8 * k)) & 255u;
+                    if (op) v &= op[k];
+                    dp[k] = (unsigned char)v;
+                }
+            }
+        }
+    }
+}
+
+// generic element sizes: separable running max through a temporary plane
 __global__ __launch_bounds__(256) void k_dilate_rows(const unsigned char* src, size_t sstep, int rows, int cols, int kw, unsigned char* tmp) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
@@ -903,6 +1159,8 @@ struct isx_blender {
     // warp of tile t+1 that the caller enqueues next on the main stream; blend() joins the side streams
     float sharpness = 0.02f;        // FeatherBlender(float sharpness = 0.02f)
     DevBuf feather_w;               // weight map of the tile being fed (int row distances, then float weights)
+    struct FeatherRec { const unsigned char* img; size_t istep; int sk; float* wgt; int wpitch, dx, dy, rows, cols; };
+    std::vector<FeatherRec> ftiles; // deferred FeatherBlender cycle: tiles recorded by feed(), gathered by blend()
     bool overlap = false;
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_ready, ev_done;
@@ -1222,14 +1480,37 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     layout_levels(b->dst, L, height, width, b->prec, true, nullptr, &total);
     ISX_TRY(b->dst_arena.reserve(total));
     layout_levels(b->dst, L, height, width, b->prec, true, (char*)b->dst_arena.p, &total);
-    // MULTI_BAND: dst_.setTo(0) / weights setTo(0) are not executed, uncovered pixels are defined as zero (Cover).
-    // FEATHER (one full-resolution level, plain read-modify-write): cleared as OpenCV does.
-    if (b->type == ISX_BLEND_FEATHER) ISX_HIP(hipMemsetAsync(b->dst_arena.p, 0, total, b->stream));
+    // dst_.setTo(0) / the weight maps' setTo(0) are not executed: uncovered pixels are defined as zero (Cover).
     b->fed.clear();
-    b->cleared = b->type == ISX_BLEND_FEATHER;
+    b->cleared = false;
     b->tiles.clear();
+    b->ftiles.clear();
     b->level0_pending = false;
     b->prepared = true;
+    return ISX_OK;
+}
+
+// dst += short(img * w), dst_weight += w for one tile (eager FeatherBlender::feed, and the replay of recorded tiles)
+int feather_accumulate(isx_blender* b, const isx_blender::FeatherRec& r) {
+    hipStream_t st = b->stream;
+    if (!b->cleared && b->fed.size() >= (size_t)MAX_COVER) {   // more tiles than a Cover holds: clear once, then plain RMW
+        ISX_TRY(fill_uncovered(b, 0));
+        b->cleared = true;
+    }
+    const Cover cov = make_cover(b, 0);
+    dim3 grid(cdiv(r.cols, 64), cdiv(r.rows, 4));
+    const double bytes = (double)r.rows * r.cols * ((r.sk == SK_U8 ? 3.0 : 6.0) + 4.0 + 2.0 * 12.0);
+    if (r.sk == SK_U8) ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_U8>), grid, dim3(256), 0, r.img, r.istep, (const float*)r.wgt, r.wpitch, r.rows, r.cols, b->dst[0], r.dx, r.dy, cov);
+    else ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_S16>), grid, dim3(256), 0, r.img, r.istep, (const float*)r.wgt, r.wpitch, r.rows, r.cols, b->dst[0], r.dx, r.dy, cov);
+    if (!b->cleared) b->fed.push_back(make_int4(r.dx, r.dy, r.cols, r.rows));
+    return ISX_OK;
+}
+
+// leave the deferred FeatherBlender cycle: accumulate the recorded tiles now (their buffers stay in use until blend())
+int flush_feather(isx_blender* b) {
+    std::vector<isx_blender::FeatherRec> recs;
+    recs.swap(b->ftiles);
+    for (const auto& r : recs) ISX_TRY(feather_accumulate(b, r));
     return ISX_OK;
 }
 
@@ -1248,24 +1529,38 @@ int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int
                   "feed: tile at (%d,%d) %dx%d lies outside the prepared ROI", tl_x, tl_y, img->cols, img->rows);
     ISX_HIP(hipSetDevice(b->device));
     hipStream_t st = b->stream;
-    ISX_TRY(b->st_img.use_in(img, st, "feed: img"));
+    // deferred cycle (the fed mats outlive blend()): only the weight map is built here, into a buffer of the tile's own
+    const int sk = u8_entry ? SK_U8 : SK_S16;
+    const bool can_defer = b->deferred && !b->cleared && (b->ftiles.empty() ? b->fed.empty() : true) && b->ftiles.size() < (size_t)DEF_MAX &&
+                           (b->ftiles.empty() || b->ftiles[0].sk == sk);
+    if (!can_defer) ISX_TRY(flush_feather(b));
+    const size_t slot = b->ftiles.size();
+    if (can_defer && b->tile_arenas.size() <= slot) {
+        b->tile_arenas.emplace_back(new DevBuf());
+        b->tile_img.emplace_back(new MatStage());
+        b->tile_mask.emplace_back(new MatStage());
+    }
+    MatStage& st_img = can_defer ? *b->tile_img[slot] : b->st_img;
+    DevBuf& wbuf = can_defer ? *b->tile_arenas[slot] : b->feather_w;
+    ISX_TRY(st_img.use_in(img, st, "feed: img"));
     ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
     const int rows = img->rows, cols = img->cols;
     const int nseg = cdiv(rows, DT_SEG);
-    const size_t map_bytes = ((size_t)rows * cols * 4 + 255) & ~(size_t)255;
-    ISX_TRY(b->feather_w.reserve(map_bytes + (size_t)nseg * cols * 8));
-    int* rowd = (int*)b->feather_w.p;
-    int* seg_f = (int*)((char*)b->feather_w.p + map_bytes);
+    const int pitch = (cols + 3) & ~3;   // int4 stores of the row pass
+    const size_t map_bytes = ((size_t)rows * pitch * 4 + 255) & ~(size_t)255;
+    ISX_TRY(wbuf.reserve(map_bytes + (size_t)nseg * cols * 8));
+    int* rowd = (int*)wbuf.p;
+    int* seg_f = (int*)((char*)wbuf.p + map_bytes);
     int* seg_b = seg_f + (size_t)nseg * cols;
-    ISX_LAUNCH("dt_rows", (double)rows * cols * 5.0, st, k_dt_rows, dim3(rows), dim3(256), 0, (const unsigned char*)b->st_mask.d.data, b->st_mask.d.step, rows, cols, rowd);
-    ISX_LAUNCH("dt_seg_min", (double)rows * cols * 4.0, st, k_dt_seg_min, dim3(cdiv(cols, 64), nseg), dim3(64), 0, (const int*)rowd, rows, cols, seg_f, seg_b);
-    ISX_LAUNCH("dt_cols_weight", (double)rows * cols * 8.0, st, k_dt_cols_weight, dim3(cdiv(cols, 64), nseg), dim3(64), 0, rowd, rows, cols, (const int*)seg_f,
+    ISX_LAUNCH("dt_rows", (double)rows * cols * 5.0, st, k_dt_rows, dim3(rows), dim3(256), 0, (const unsigned char*)b->st_mask.d.data, b->st_mask.d.step, rows, cols, rowd, pitch);
+    ISX_LAUNCH("dt_seg_min", (double)rows * cols * 4.0, st, k_dt_seg_min, dim3(cdiv(cols, 64), nseg), dim3(64), 0, (const int*)rowd, pitch, rows, cols, seg_f, seg_b);
+    ISX_LAUNCH("dt_cols_weight", (double)rows * cols * 8.0, st, k_dt_cols_weight, dim3(cdiv(cols, 64), nseg), dim3(64), 0, rowd, pitch, rows, cols, (const int*)seg_f,
                (const int*)seg_b, nseg, b->sharpness);
-    dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
-    const double bytes = (double)rows * cols * ((u8_entry ? 3.0 : 6.0) + 4.0 + 2.0 * 10.0);
-    if (u8_entry) ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_U8>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step, (const float*)rowd, rows, cols, b->dst[0], dx, dy);
-    else ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_S16>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step, (const float*)rowd, rows, cols, b->dst[0], dx, dy);
-    return ISX_OK;
+    isx_blender::FeatherRec r;
+    r.img = (const unsigned char*)st_img.d.data; r.istep = st_img.d.step; r.sk = sk; r.wgt = (float*)rowd; r.wpitch = pitch;
+    r.dx = dx; r.dy = dy; r.rows = rows; r.cols = cols;
+    if (can_defer) { b->ftiles.push_back(r); return ISX_OK; }
+    return feather_accumulate(b, r);
 }
 
 int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
@@ -1476,6 +1771,14 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
     if (other) ISX_TRY(so.use_in(other, st, "dilate: other"));
     ISX_TRY(sd.use_out(out, st, "dilate: out"));
     const int rows = mask->rows, cols = mask->cols;
+    if (kw <= DIL_MAXK && kh <= DIL_MAXK) {
+        ISX_LAUNCH("dilate_and", (double)rows * cols * (other ? 3.0 : 2.0), st, k_dilate_and, dim3(cdiv(cols, DIL_TW), cdiv(rows, DIL_TH)), dim3(DIL_NT), 0,
+                   (const unsigned char*)sm.d.data, sm.d.step, rows, cols, kw, kh, other ? (const unsigned char*)so.d.data : nullptr, other ? so.d.step : 0,
+                   (unsigned char*)sd.d.data, sd.d.step);
+        ISX_TRY(sd.finish_out(st));
+        if (mask->device < 0 || out->device < 0 || (other && other->device < 0)) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
+        return ISX_OK;
+    }
     ISX_TRY(tmp.reserve((size_t)rows * cols));
     dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
     ISX_LAUNCH("dilate_rows", (double)rows * cols * 2.0, st, k_dilate_rows, grid, dim3(256), 0, (const unsigned char*)sm.d.data, sm.d.step, rows, cols, kw, (unsigned char*)tmp.p);
@@ -1545,6 +1848,7 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
     *rows = d.rows; *cols = d.cols;
     size_t n = (size_t)d.rows * d.cols;
     ISX_TRY(flush_deferred(b));                           // deferred tiles: replay them through the eager feed now
+    ISX_TRY(flush_feather(b));
     if (!b->cleared) ISX_TRY(fill_uncovered(b, level));   // materialise the "uncovered == 0" definition
     ISX_HIP(hipStreamSynchronize(b->stream));
     if (b->prec == M_I16) {
@@ -1595,7 +1899,21 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     int rc = ISX_OK;
     if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend
         dim3 grid(cdiv(b->dst[0].cols, 64), cdiv(b->dst[0].rows, 4));
-        ISX_LAUNCH("feather_blend", (double)b->fw * b->fh * 17.0, b->stream, k_feather_blend, grid, dim3(256), 0, b->dst[0], o);
+        if (!b->ftiles.empty()) {   // deferred cycle: gather over the recorded tiles
+            FeatherSet fs;
+            memset(&fs, 0, sizeof(fs));
+            fs.n = (int)b->ftiles.size();
+            double bytes = (double)b->fw * b->fh * 7.0;
+            for (int t = 0; t < fs.n; ++t) {
+                const auto& r = b->ftiles[t];
+                fs.img[t] = r.img; fs.istep[t] = r.istep; fs.wgt[t] = r.wgt; fs.wpitch[t] = r.wpitch;
+                fs.x[t] = r.dx; fs.y[t] = r.dy; fs.w[t] = r.cols; fs.h[t] = r.rows;
+                bytes += (double)r.rows * r.cols * ((r.sk == SK_U8 ? 3.0 : 6.0) + 4.0);
+            }
+            if (b->ftiles[0].sk == SK_U8) ISX_LAUNCH("feather_gather", bytes, b->stream, (k_feather_gather<SK_U8>), grid, dim3(256), 0, fs, o);
+            else ISX_LAUNCH("feather_gather", bytes, b->stream, (k_feather_gather<SK_S16>), grid, dim3(256), 0, fs, o);
+        } else
+        ISX_LAUNCH("feather_blend", (double)b->fw * b->fh * 17.0, b->stream, k_feather_blend, grid, dim3(256), 0, b->dst[0], o, make_cover(b, 0));
     } else {
         switch (b->prec) {
             case M_I16: rc = run_blend<M_I16>(b, o); break;
@@ -1607,6 +1925,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     ISX_TRY(b->st_out.finish_out(b->stream));
     if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
     b->tiles.clear();
+    b->ftiles.clear();
     b->level0_pending = false;
     b->prepared = false;   // dst_pyr_laplace_.clear(); dst_band_weights_.clear()
     return ISX_OK;

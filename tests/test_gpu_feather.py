@@ -118,3 +118,133 @@ def test_feather_full_size_4k(gpu, oracle):
     d, m = fb.blend()
     od, om = ob.blend()
     assert np.array_equal(m.cpu().numpy(), om) and np.array_equal(d.cpu().numpy(), od)
+
+
+@pytest.mark.parametrize("shape,off", [((37, 4200), 0), ((70, 9001), 3), ((33, 64), 1), ((130, 4097), 2), ((5, 17), 1)])
+def test_weight_map_wide_rows_and_unaligned_views(gpu, oracle, shape, off):
+    """createWeightMap on rows wider than one 4096-pixel pass of the row kernel and on device views whose rows start at
+    any byte offset: the accumulated weight of a single fed tile IS its weight map."""
+    import torch
+    h, w = shape
+    rng = np.random.default_rng(h * w + off)
+    big = np.full((h, w + off), 255, np.uint8)
+    big[rng.random(big.shape) < 0.0008] = 0
+    big[h // 2, :] = 255                       # a row without any zero
+    if h > 8: big[3, w // 3: w // 3 + 900] = 0  # a long run of zeros crossing a chunk boundary on the wide cases
+    mask = big[:, off:]
+    img = rng.integers(-300, 300, (h, w, 3)).astype(np.int16)
+    fb = gpu.FeatherBlender(False, 0.02)
+    fb.prepare([(0, 0)], [(w, h)])
+    fb.feed(torch.from_numpy(img).cuda(), torch.from_numpy(big).cuda()[:, off:], (0, 0))
+    _, wgt = fb.level(0)
+    ref = oracle.feather_weight_map(np.ascontiguousarray(mask), 0.02)
+    assert np.array_equal(wgt, ref), np.argwhere(wgt != ref)[:5]
+    ob = oracle.Feather(0.02)
+    ob.prepare([(0, 0)], [(w, h)])
+    ob.feed(img, np.ascontiguousarray(mask), (0, 0))
+    d, m = fb.blend()
+    od, om = ob.blend()
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(m.cpu().numpy(), om)
+
+
+def test_feather_many_tiles_without_clear(gpu, oracle):
+    """More tiles than one Cover holds (8): the accumulators are never memset, uncovered pixels are defined as zero."""
+    rng = np.random.default_rng(11)
+    n = 11
+    sizes = [(40 + 3 * i, 30 + 2 * i) for i in range(n)]
+    corners = [(int(rng.integers(-20, 120)), int(rng.integers(-10, 60))) for _ in range(n)]
+    fb, ob = gpu.FeatherBlender(False, 0.1), oracle.Feather(0.1)
+    for cycle in range(2):                      # second cycle re-uses the (dirty) arena
+        fb.prepare(corners, sizes)
+        ob.prepare(corners, sizes)
+        for i, ((w, h), c) in enumerate(zip(sizes, corners)):
+            img = synth.make_tile(h, w, 100 + i + cycle, noise_only=True).astype(np.int16)
+            mask = _mask(rng, h, w, True, p=0.01)
+            fb.feed(img, mask, c)
+            ob.feed(img, mask, c)
+        d, m = fb.blend()
+        od, om = ob.blend()
+        assert np.array_equal(m, om) and np.array_equal(d, od)
+
+
+@pytest.mark.parametrize("shape,ksize,off", [((300, 517), (20, 20), 1), ((129, 65), (33, 33), 0), ((64, 128), (1, 1), 2),
+                                             ((257, 300), (2, 31), 3), ((200, 180), (34, 5), 0), ((90, 70), (7, 60), 1)])
+def test_dilate_tiles_halo_and_fallback(gpu, oracle, shape, ksize, off):
+    """Sizes that straddle the 64 x 128 tile of the fused kernel, unaligned device views, and structuring elements
+    beyond 33 (generic two-kernel path)."""
+    import torch
+    h, w = shape
+    rng = np.random.default_rng(h + w + sum(ksize))
+    big = rng.integers(0, 256, (h, w + off)).astype(np.uint8)
+    big[rng.random(big.shape) < 0.97] = 0
+    other = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    m = np.ascontiguousarray(big[:, off:])
+    ref = oracle.dilate_rect(m, *ksize)
+    assert np.array_equal(gpu.dilate_and(m, *ksize), ref)
+    out = gpu.dilate_and(torch.from_numpy(big).cuda()[:, off:], *ksize, other=torch.from_numpy(other).cuda())
+    assert np.array_equal(out.cpu().numpy(), ref & other)
+
+
+@pytest.mark.parametrize("n", [2, 5, 11])
+def test_feather_deferred_gather_equals_eager_and_oracle(gpu, oracle, n):
+    """isx_blender_set_deferred_level0 on a FeatherBlender: feed() builds only the weight maps, blend() gathers over the
+    recorded tiles (no accumulators); beyond 8 tiles the cycle falls back to the eager path. Device tiles, u8 entry."""
+    import torch
+    rng = np.random.default_rng(n)
+    sizes = [(90 + 7 * i, 60 + 5 * i) for i in range(n)]
+    corners = [(int(rng.integers(-30, 150)), int(rng.integers(-20, 80))) for _ in range(n)]
+    imgs = [synth.make_tile(h, w, 40 + i, noise_only=True) for i, (w, h) in enumerate(sizes)]
+    masks = [_mask(rng, h, w, True, p=0.004) for (w, h) in sizes]
+    timgs = [torch.from_numpy(a).cuda() for a in imgs]
+    tmasks = [torch.from_numpy(a).cuda() for a in masks]
+    ob = oracle.Feather(0.05)
+    ob.prepare(corners, sizes)
+    for im, mk, c in zip(imgs, masks, corners):
+        ob.feed(im.astype(np.int16), mk, c)
+    od, om = ob.blend()
+    outs = []
+    for deferred in (False, True):
+        fb = gpu.FeatherBlender(False, 0.05)
+        fb.set_deferred_level0(deferred)
+        for cycle in range(2):
+            fb.prepare(corners, sizes)
+            for im, mk, c in zip(timgs, tmasks, corners):
+                fb.feed_u8(im, mk, c)
+            d, m = fb.blend()
+        outs.append((d.cpu().numpy(), m.cpu().numpy()))
+        assert np.array_equal(outs[-1][1], om) and np.array_equal(outs[-1][0], od)
+
+
+def test_feather_deferred_uses_gather_and_flushes(gpu, oracle):
+    import torch
+    lib = gpu._lib.load()
+    rng = np.random.default_rng(5)
+    sizes, corners = [(120, 80), (100, 90)], [(0, 0), (70, 10)]
+    imgs = [synth.make_tile(h, w, 3 + i, noise_only=True) for i, (w, h) in enumerate(sizes)]
+    masks = [_mask(rng, h, w, True, p=0.004) for (w, h) in sizes]
+    ob = oracle.Feather(0.1)
+    ob.prepare(corners, sizes)
+    for im, mk, c in zip(imgs, masks, corners):
+        ob.feed(im.astype(np.int16), mk, c)
+    od, om = ob.blend()
+    fb = gpu.FeatherBlender(False, 0.1)
+    fb.set_deferred_level0(True)
+    # (a) pure deferred cycle: one gather launch, no accumulate / normalise launches
+    lib.isx_profile_enable(1); lib.isx_profile_reset()
+    fb.prepare(corners, sizes)
+    keep = [(torch.from_numpy(im).cuda(), torch.from_numpy(mk).cuda()) for im, mk in zip(imgs, masks)]   # the contract: alive until blend()
+    for (im, mk), c in zip(keep, corners):
+        fb.feed_u8(im, mk, c)
+    d, m = fb.blend()
+    ent = gpu._lib.profile_entries()
+    lib.isx_profile_enable(0)
+    assert ent["feather_gather"]["launches"] == 1 and "feather_acc" not in ent and "feather_blend" not in ent
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(m.cpu().numpy(), om)
+    # (b) a second source type in the same cycle (CV_16SC3 after CV_8UC3) and level introspection flush to the eager path
+    fb.prepare(corners, sizes)
+    fb.feed_u8(imgs[0], masks[0], corners[0])
+    fb.feed(imgs[1].astype(np.int16), masks[1], corners[1])
+    _, w = fb.level(0)
+    assert w.max() > 0
+    d, m = fb.blend()
+    assert np.array_equal(d, od) and np.array_equal(m, om)

@@ -13,6 +13,7 @@ imgs = [torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device=dev, generato
 masks = [torch.full((h, w), 255, dtype=torch.uint8, device=dev) for (w, h) in sizes]
 for m in masks: m[:40, :300] = 0
 fb = I.FeatherBlender(False, 0.1)
+fb.set_deferred_level0(len(sys.argv) < 2 or sys.argv[1] != "eager")
 
 def step():
     fb.prepare(corners, sizes)
