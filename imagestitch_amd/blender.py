@@ -41,6 +41,13 @@ class MultiBandBlender:
         """Opt-in (see include/imagestitch_hip.h): fed device mats must then stay valid until blend() returns."""
         check(self._lib.isx_blender_set_deferred_level0(self._h, int(bool(on))))
 
+    def set_mark_event(self, event, after_level=0):
+        """A deferred blend() records `event` (torch.cuda.Event / hipEvent_t / None) right after its pyrDown launch of
+        level `after_level`: see isx_blender_set_mark_event."""
+        self._mark = event   # keep it alive
+        ptr = getattr(event, "cuda_event", event) if event is not None else None
+        check(self._lib.isx_blender_set_mark_event(self._h, C.c_void_p(ptr or 0), int(after_level)))
+
     def set_overlap(self, on=True):
         check(self._lib.isx_blender_set_overlap(self._h, int(bool(on))))
 

@@ -1161,6 +1161,8 @@ struct isx_blender {
     DevBuf feather_w;               // weight map of the tile being fed (int row distances, then float weights)
     struct FeatherRec { const unsigned char* img; size_t istep; int sk; float* wgt; int wpitch, dx, dy, rows, cols; };
     std::vector<FeatherRec> ftiles; // deferred FeatherBlender cycle: tiles recorded by feed(), gathered by blend()
+    hipEvent_t mark_event = nullptr;   // isx_blender_set_mark_event: recorded inside a deferred blend()
+    int mark_level = 0;
     bool overlap = false;
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_ready, ev_done;
@@ -1387,6 +1389,8 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
         if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
         else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+        // the full-size level-0 kernel is behind us: from here to the last collapse step the launches are small
+        if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
     }
     // 2. top level: gather + normalise into the collapsed pyramid's level L
     //    (algorithmic bytes of the launches below = the traffic their own dataflow needs: every input
@@ -1741,6 +1745,13 @@ int isx_blender_set_deferred_level0(isx_blender* b, int on) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_deferred_level0: null blender");
     ISX_CHECK_ARG(!b->prepared || b->fed.empty(), ISX_ERR_STATE, "isx_blender_set_deferred_level0: tiles have already been fed in this cycle");
     b->deferred = on != 0;
+    return ISX_OK;
+}
+
+int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_mark_event: null blender");
+    b->mark_event = (hipEvent_t)hip_event;
+    b->mark_level = after_level;
     return ISX_OK;
 }
 

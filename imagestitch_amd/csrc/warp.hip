@@ -528,7 +528,7 @@ int set_camera(isx_warper* w, const float K[9], const float R[9]) {
 
 // Enqueue the queued verification scans of planned warps on the side stream, behind the main stream's
 // current position.  The scan is VALU-bound like the warp kernel: it should run under memory-bound work.
-int flush_verify(isx_warper* w) {
+int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
     if (w->pending.empty()) return ISX_OK;
     hipStream_t st = w->stream;
     if (!w->side) {
@@ -536,8 +536,11 @@ int flush_verify(isx_warper* w) {
         ISX_HIP(hipEventCreateWithFlags(&w->ev_warp, hipEventDisableTiming));
         ISX_HIP(hipEventCreateWithFlags(&w->ev_scan, hipEventDisableTiming));
     }
-    ISX_HIP(hipEventRecord(w->ev_warp, st));
-    ISX_HIP(hipStreamWaitEvent(w->side, w->ev_warp, 0));
+    if (after) ISX_HIP(hipStreamWaitEvent(w->side, after, 0));
+    else {
+        ISX_HIP(hipEventRecord(w->ev_warp, st));
+        ISX_HIP(hipStreamWaitEvent(w->side, w->ev_warp, 0));
+    }
     if (!w->scan_side.p) {
         ISX_TRY(w->scan_side.reserve(64));
         ISX_HIP(hipMemsetAsync(w->scan_side.p, 0, 64, w->side));
@@ -895,6 +898,13 @@ int isx_warper_verify(isx_warper* w) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_verify: null warper");
     ISX_HIP(hipSetDevice(w->device));
     return flush_verify(w);
+}
+
+int isx_warper_verify_after(isx_warper* w, void* hip_event) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr && hip_event != nullptr, ISX_ERR_INVALID, "isx_warper_verify_after: null argument");
+    ISX_HIP(hipSetDevice(w->device));
+    return flush_verify(w, (hipEvent_t)hip_event);
 }
 
 int isx_warper_join(isx_warper* w) {

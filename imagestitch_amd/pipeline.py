@@ -5,6 +5,8 @@ PairStitcher owns the device buffers so that the steady state allocates nothing.
 output of the seam finder, which is out of scope: SURVEY §8(f) N1) are inputs: they are built
 once from the warped masks with synth.seam_masks and stay resident.
 """
+import os
+
 import numpy as np
 
 from . import _lib, synth
@@ -68,7 +70,7 @@ class PairStitcher:
     """One pair of tiles -> one blended mosaic, buffers resident in HBM (torch CUDA tensors)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
-                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False):
+                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1):
         import torch
         self.torch = torch
         self.imgs, self.K, self.Rs = imgs, K, Rs
@@ -100,6 +102,17 @@ class PairStitcher:
         seam = synth.seam_masks(self.corners, [m.cpu().numpy() for m in self.wmasks])
         self.seam = [torch.from_numpy(s).to(dev) for s in seam]
         self.roi_pad, (fw, fh), self.L = prepare_geometry(self.corners, self.sizes, num_bands)
+        # Where the ROI verification scans of a planned step start.  verify_at < 0: right after the last warp (they then
+        # run under the level-0 pyrDown, which they slow down by more than their own length).  verify_at = k >= 0:
+        # inside blend(), behind the pyrDown launch of level k — from there to the last collapse step the launches are
+        # small and leave most of the GPU idle.  Measured on MI355X, 4K pair: -1: 0.377 ms, 0: 0.371, 1: 0.354, 2: 0.362.
+        if os.environ.get("ISX_VERIFY_AT", "") != "":
+            verify_at = int(os.environ["ISX_VERIFY_AT"])
+        self.mark = None
+        if deferred and not interleave and verify_at is not None and verify_at >= 0 and self.L >= 1:
+            self.mark = torch.cuda.Event()
+            self.mark.record()   # materialise the hipEvent_t
+            self.blender.set_mark_event(self.mark, min(verify_at, self.L - 1))
         odt = {"int16": torch.int16, "float32": torch.float32, "uint8": torch.uint8}[out_dtype]
         es = {"int16": 2, "float32": 4, "uint8": 1}[out_dtype]
         opitch = (fw * 3 * es + 63) // 64 * 64
@@ -119,11 +132,14 @@ class PairStitcher:
         else:
             for i in range(n):
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
-            self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
+            if self.mark is None:
+                self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
             for i in range(n):
                 self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
         self.blender.blend(self.out, self.out_mask)
+        if self.mark is not None and not self.interleave:
+            self.warper.verify_after(self.mark)   # blend() recorded the mark behind its level-`verify_at` pyrDown
         return self.out, self.out_mask
 
     def capture(self):

@@ -134,6 +134,10 @@ class RotationWarper:
         """Enqueue the queued verification scans of planned warps behind the stream's current position."""
         check(self._lib.isx_warper_verify(self._h))
 
+    def verify_after(self, event):
+        """verify(), but the scans start when `event` (torch.cuda.Event or raw hipEvent_t, already recorded) completes."""
+        check(self._lib.isx_warper_verify_after(self._h, C.c_void_p(getattr(event, "cuda_event", event))))
+
     def join(self):
         """Make the handle's stream wait for the side-stream verification scans (needed inside graph capture)."""
         check(self._lib.isx_warper_join(self._h))

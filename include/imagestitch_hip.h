@@ -143,6 +143,9 @@ int isx_warper_join(isx_warper* w);
  * (memory-bound) pyramid kernels that follow.  join / plan_status flush the queue themselves.            */
 int isx_warper_set_deferred_verify(isx_warper* w, int on);
 int isx_warper_verify(isx_warper* w);
+/* Same, but the scans start once `hip_event` (a hipEvent_t already recorded, e.g. by
+ * isx_blender_set_mark_event during blend()) has completed instead of at the stream's current position.  */
+int isx_warper_verify_after(isx_warper* w, void* hip_event);
 
 /* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
 /* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
@@ -183,6 +186,11 @@ int isx_blender_set_deferred_level0(isx_blender* b, int on);
  * the (memory-bound) chain of tile t overlaps with whatever the caller enqueues next on the handle's
  * stream — typically the (VALU-bound) warp of tile t+1.  blend() joins the side streams.               */
 int isx_blender_set_overlap(isx_blender* b, int on);
+/* Scheduling hook, nothing in the reference: a deferred blend() records `hip_event` (hipEvent_t, NULL = off) on its
+ * stream right after the pyrDown launch that produces level after_level + 1 of the tile pyramids.  From there to the
+ * last collapse step the launches are small and leave most of the GPU idle: the place for unrelated VALU-bound work
+ * such as the ROI verification scans (isx_warper_verify_after).                                           */
+int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level);
 
 /* size of the result of blend(): dst_roi_final_ (unpadded union of the fed tiles)             */
 int isx_blender_result_size(isx_blender* b, int* width, int* height);

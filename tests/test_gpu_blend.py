@@ -317,7 +317,8 @@ def test_deferred_level0_identical_to_eager(gpu, oracle, prec, ntiles):
 
 
 def test_pipeline_variants_agree(gpu):
-    """planned step == interleaved (side-stream chains) step == hipGraph replay == eager (non-deferred) step"""
+    """planned step == interleaved (side-stream chains) step == hipGraph replay == eager (non-deferred) step, wherever the
+    ROI verification scans are scheduled (after the last warp / behind a marked launch inside blend())"""
     import torch
     from imagestitch_amd.pipeline import PairStitcher
     W, H, F = 1024, 600, 800.0
@@ -325,7 +326,8 @@ def test_pipeline_variants_agree(gpu):
     dev = torch.device("cuda:0")
     imgs = [torch.from_numpy(synth.make_tile(H, W, i)).to(dev) for i in range(2)]
     ref = None
-    for kw in (dict(deferred=False), dict(deferred=True), dict(deferred=True, interleave=True)):
+    for kw in (dict(deferred=False), dict(deferred=True), dict(deferred=True, interleave=True), dict(verify_at=-1), dict(verify_at=0),
+               dict(verify_at=9)):
         ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16", **kw)
         for _ in range(2):
             a, am = [t.clone() for t in ps.step()]
