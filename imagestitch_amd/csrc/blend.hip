@@ -91,7 +91,8 @@ __device__ __forceinline__ bool covered(const Cover& c, int x, int y, int k = 0)
 
 template <int M, bool DST>
 __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
-    const unsigned i = (unsigned)y * (unsigned)L.cols + (unsigned)x;   // levels hold < 2^31 records (checked by prepare)
+    // levels hold < 2^31 records and fewer than 2^24 rows / columns (checked by prepare): 24-bit multiply = full-rate VALU
+    const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
     Px<M> p;
     if constexpr (M == M_I16) {
         short4 v = ((const short4*)L.img)[i];
@@ -109,7 +110,7 @@ __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
 
 template <int M, bool DST>
 __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const Px<M>& p) {
-    const unsigned i = (unsigned)y * (unsigned)L.cols + (unsigned)x;
+    const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
     if constexpr (M == M_I16) {
         ((short4*)L.img)[i] = make_short4((short)p.c0, (short)p.c1, (short)p.c2, 0);
         L.wgt[i] = p.w;
@@ -159,8 +160,8 @@ __device__ __forceinline__ void load_src0_pair(const Src0& s, int x, int y, Px<M
     if constexpr (SK == SK_U8) {
         const int yr = y - s.top, xr = x - s.left;
         if ((unsigned)yr < (unsigned)s.rows && xr >= 0 && xr + 1 < s.cols) {
-            const unsigned io = (unsigned)yr * (unsigned)s.img_step + (unsigned)xr * 3u + s.imis;    // offset from img_al
-            const unsigned mo = (unsigned)yr * (unsigned)s.mask_step + (unsigned)xr + s.mmis;       // offset from mask_al
+            const unsigned io = __umul24((unsigned)yr, (unsigned)s.img_step) + __umul24((unsigned)xr, 3u) + s.imis;    // offset from img_al (steps < 2^24)
+            const unsigned mo = __umul24((unsigned)yr, (unsigned)s.mask_step) + (unsigned)xr + s.mmis;       // offset from mask_al
             if ((io & ~3u) + 12u <= s.iend && (mo & ~3u) + 8u <= s.mend) {
                 const U3 v = *(const U3*)(s.img_al + (io & ~3u));
                 const U2 q = *(const U2*)(s.mask_al + (mo & ~3u));
@@ -496,9 +497,10 @@ template <int M>
 __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const Px<M>& d) {
     if (x >= o.cols || y >= o.rows) return;      // crop to dst_roi_final_
     bool on = d.w > WEIGHT_EPS;                  // compare(w0, WEIGHT_EPS, CMP_GT)
-    if (o.mask) o.mask[(size_t)y * o.mask_step + x] = on ? 255 : 0;
+    // blend() checks rows * step < 2^32 and step < 2^24 for both mats: 32-bit offsets from full-rate 24-bit multiplies
+    if (o.mask) o.mask[__umul24((unsigned)y, (unsigned)o.mask_step) + (unsigned)x] = on ? 255 : 0;
     if (o.img_f32 == 2) {   // result.convertTo(CV_8U): saturate_cast<uchar>(short) / saturate_cast<uchar>(cvRound(float))
-        unsigned char* q = o.img + (size_t)y * o.img_step + (size_t)x * 3;
+        unsigned char* q = o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 3u);
         if constexpr (M == M_I16) {
             q[0] = on ? (unsigned char)sat_u8(d.c0) : 0; q[1] = on ? (unsigned char)sat_u8(d.c1) : 0; q[2] = on ? (unsigned char)sat_u8(d.c2) : 0;
         } else {
@@ -507,10 +509,10 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
             q[2] = on ? (unsigned char)sat_u8(cvround_x86(d.c2)) : 0;
         }
     } else if (o.img_f32) {
-        float* q = (float*)(o.img + (size_t)y * o.img_step) + (size_t)x * 3;
+        float* q = (float*)(o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 12u));
         q[0] = on ? (float)d.c0 : 0.f; q[1] = on ? (float)d.c1 : 0.f; q[2] = on ? (float)d.c2 : 0.f;
     } else {
-        short* q = (short*)(o.img + (size_t)y * o.img_step) + (size_t)x * 3;
+        short* q = (short*)(o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 6u));
         if constexpr (M == M_I16) {
             q[0] = on ? (short)d.c0 : 0; q[1] = on ? (short)d.c1 : 0; q[2] = on ? (short)d.c2 : 0;
         } else {  // saturate_cast<short>(float)
@@ -540,11 +542,11 @@ __device__ __forceinline__ void write_final_pair(const OutMat& o, int x, int y, 
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { if (!on0) v[i] = 0; if (!on1) v[3 + i] = 0; }
-    unsigned* q = (unsigned*)(o.img + (size_t)y * o.img_step + (size_t)x * 6);
+    unsigned* q = (unsigned*)(o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 6u));
     q[0] = (unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16);
     q[1] = (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16);
     q[2] = (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16);
-    if (o.mask) *(unsigned short*)(o.mask + (size_t)y * o.mask_step + x) = (unsigned short)((on0 ? 255u : 0u) | (on1 ? 0xff00u : 0u));
+    if (o.mask) *(unsigned short*)(o.mask + (__umul24((unsigned)y, (unsigned)o.mask_step) + (unsigned)x)) = (unsigned short)((on0 ? 255u : 0u) | (on1 ? 0xff00u : 0u));
 }
 
 // top level of blend(): normalise in place (or straight to the caller's mat when num_bands == 0)
@@ -649,9 +651,14 @@ __global__ __launch_bounds__(256) void k_top_gather(TileSet ts, LevelBuf out) {
 // result goes to the caller's mats (crop, mask, zero fill); otherwise fine = G_{k-1,t} and the result is
 // stored as level k-1 of the collapsed pyramid.
 template <int M, int SK, bool FINE0>
-__global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     using WT = typename WorkT<M>::t;
-    __shared__ Px<M> ct[UP_TY + 2][WAVE + 2];
+    // Tiles are taken G at a time: their coarse tiles (and, in the last round, that of out_k) are staged in ONE phase —
+    // every global load of the round in flight together, the fine-level pixels included, one barrier pair per round
+    // instead of one per source.  G = 2 (a pair of tiles = a single round) for the upper steps; the last step keeps
+    // G = 1: its level-0 decode needs the registers (152 VGPRs = 3 waves per SIMD with G = 2, measured slower).
+    constexpr int G = FINE0 ? 1 : 2;
+    __shared__ Px<M> ct[G + 1][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
     WT acc[2][2][3];
@@ -660,29 +667,69 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc[i][j][0] = 0; acc[i][j][1] = 0; acc[i][j][2] = 0; accw[i][j] = 0.f; }
-    for (int t = 0; t < ts.n; ++t) {
-        // block-uniform: does the block's fine region touch the tile's rectangle?
-        const int tx = ts.x_tl[t], ty = ts.y_tl[t];
-        if (2 * cx0 >= tx + ts.w[t] || 2 * cx0 + 2 * WAVE <= tx || 2 * cy0 >= ty + ts.h[t] || 2 * cy0 + 2 * UP_TY <= ty) continue;
-        const int lx0 = cx0 - (tx >> 1), ly0 = cy0 - (ty >> 1);      // block origin in the tile's coarse coordinates
-        __syncthreads();
-        stage_coarse<M, false>(ct, ts.coarse[t], lx0, ly0);
-        __syncthreads();
-        const int lcx = lx0 + lane, lcy = ly0 + wv;
-        const int cw = ts.coarse[t].cols, ch = ts.coarse[t].rows;
-        if ((unsigned)lcx < (unsigned)cw && (unsigned)lcy < (unsigned)ch) {
-            Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, lcx, cw);
-            Px<M> gg[2][2];
+    constexpr int NCT = (UP_TY + 2) * (WAVE + 2);
+    for (int t0 = 0; t0 < max(ts.n, 1); t0 += G) {
+        const bool with_out = t0 + G >= ts.n;
+        bool touch[G], mine[G];
+        int lx0[G], ly0[G];
+        Px<M> gg[G][2][2];
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                if constexpr (FINE0) load_src0_pair<M, SK>(ts.s0[t], 2 * lcx, 2 * lcy + dy, gg[dy][0], gg[dy][1]);
-                else { gg[dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
+        for (int s = 0; s < G; ++s) {
+            const int t = t0 + s;
+            touch[s] = false; mine[s] = false; lx0[s] = 0; ly0[s] = 0;
+            if (t < ts.n) {
+                // block-uniform: does the block's fine region touch the tile's rectangle?
+                const int tx = ts.x_tl[t], ty = ts.y_tl[t];
+                touch[s] = !(2 * cx0 >= tx + ts.w[t] || 2 * cx0 + 2 * WAVE <= tx || 2 * cy0 >= ty + ts.h[t] || 2 * cy0 + 2 * UP_TY <= ty);
+                lx0[s] = cx0 - (tx >> 1); ly0[s] = cy0 - (ty >> 1);      // block origin in the tile's coarse coordinates
+                const int lcx = lx0[s] + lane, lcy = ly0[s] + wv;
+                mine[s] = touch[s] && (unsigned)lcx < (unsigned)ts.coarse[t].cols && (unsigned)lcy < (unsigned)ts.coarse[t].rows;
+                if (mine[s]) {   // the thread's 2x2 fine pixels of this tile: issued before anything waits
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        if constexpr (FINE0) load_src0_pair<M, SK>(ts.s0[t], 2 * lcx, 2 * lcy + dy, gg[s][dy][0], gg[s][dy][1]);
+                        else { gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
+                    }
+                }
             }
+        }
+        Px<M> sv[G + 1][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            if (i < NCT) {
+                const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+#pragma unroll
+                for (int s = 0; s < G; ++s)
+                    if (touch[s]) {
+                        const LevelBuf& c = ts.coarse[t0 + s];
+                        sv[s][it] = load_px<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
+                    }
+                if (with_out) sv[G][it] = load_px<M, true>(coarse_out, min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), up_row_map<M>(cy0 - 1 + ry, coarse_out.rows));
+            }
+        }
+        if (t0 > 0) __syncthreads();     // the previous round's readers are done with ct
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            if (i < NCT) {
+                const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+#pragma unroll
+                for (int s = 0; s < G; ++s) if (touch[s]) ct[s][ry][rx] = sv[s][it];
+                if (with_out) ct[G][ry][rx] = sv[G][it];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            if (!mine[s]) continue;
+            const int t = t0 + s;
+            Up4<M> u = pyr_up_2x2<M>(ct[s], lane, wv, lx0[s] + lane, ts.coarse[t].cols);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const Px<M> g = gg[dy][dx];
+                    const Px<M> g = gg[s][dy][dx];
                     if constexpr (M == M_I16) {
                         acc[dy][dx][0] = wrap_s16(acc[dy][dx][0] + f2s_x86((float)sat_s16(g.c0 - u.v[dy][dx][0]) * g.w));
                         acc[dy][dx][1] = wrap_s16(acc[dy][dx][1] + f2s_x86((float)sat_s16(g.c1 - u.v[dy][dx][1]) * g.w));
@@ -696,12 +743,9 @@ __global__ __launch_bounds__(256) void k_collapse_gather(TileSet ts, LevelBuf co
                 }
         }
     }
-    __syncthreads();
-    stage_coarse<M, true>(ct, coarse_out, cx0, cy0);
-    __syncthreads();
     const int cx = cx0 + lane, cy = cy0 + wv;
     if (cx >= coarse_out.cols || cy >= coarse_out.rows) return;
-    Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse_out.cols);
+    Up4<M> u = pyr_up_2x2<M>(ct[G], lane, wv, cx, coarse_out.cols);
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         const int fy = 2 * cy + dy;
@@ -1479,6 +1523,9 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     int L = b->num_bands, m = 1 << L;
     width += (m - width % m) % m;
     height += (m - height % m) % m;
+    // device indexing: 32-bit record indices built from 24-bit multiplies
+    ISX_CHECK_ARG(width < (1 << 24) && height < (1 << 24) && (unsigned long long)width * height < (1ull << 31), ISX_ERR_UNSUPPORTED,
+                  "prepare: destination ROI %d x %d exceeds the supported 2^31 pixels / 2^24 per side", width, height);
     b->rx = x; b->ry = y; b->rw = width; b->rh = height;
     size_t total = 0;
     layout_levels(b->dst, L, height, width, b->prec, true, nullptr, &total);
@@ -1633,7 +1680,8 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     s0.imis = (unsigned)((uintptr_t)s0.img & 3); s0.mmis = (unsigned)((uintptr_t)s0.mask & 3);
     s0.img_al = s0.img - s0.imis; s0.mask_al = s0.mask - s0.mmis;
     s0.iend = 0; s0.mend = 0;
-    if (img->type == ISX_8UC3 && (unsigned long long)di.step * img->rows < (1ull << 31) && (unsigned long long)dm.step * img->rows < (1ull << 31)) {
+    if (img->type == ISX_8UC3 && (unsigned long long)di.step * img->rows < (1ull << 31) && (unsigned long long)dm.step * img->rows < (1ull << 31) &&
+        di.step < (1u << 24) && dm.step < (1u << 24)) {
         s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * 3) + s0.imis;
         s0.mend = (unsigned)((size_t)(img->rows - 1) * dm.step + (size_t)img->cols) + s0.mmis;
     }
@@ -1900,7 +1948,12 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     }
     ISX_HIP(hipSetDevice(b->device));
     ISX_TRY(b->st_out.use_out(dst, b->stream, "blend: dst"));
-    if (dst_mask) ISX_TRY(b->st_outmask.use_out(dst_mask, b->stream, "blend: dst_mask"));
+    ISX_CHECK_ARG(b->st_out.d.step < (1u << 24) && (unsigned long long)b->st_out.d.step * dst->rows < (1ull << 32), ISX_ERR_UNSUPPORTED,
+                  "blend: dst of %zu bytes per row x %d rows exceeds the supported 4 GiB / 16 MiB per row", b->st_out.d.step, dst->rows);
+    if (dst_mask) {
+        ISX_TRY(b->st_outmask.use_out(dst_mask, b->stream, "blend: dst_mask"));
+        ISX_CHECK_ARG(b->st_outmask.d.step < (1u << 24), ISX_ERR_UNSUPPORTED, "blend: dst_mask row pitch %zu exceeds 16 MiB", b->st_outmask.d.step);
+    }
     OutMat o;
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;

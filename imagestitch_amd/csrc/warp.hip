@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
         wq[k] = (unsigned)(isx & 31) | ((unsigned)(isy & 31) << 8);
         const int sx = isx >> 5, sy = isy >> 5;   // no short saturation needed on the fast path (sx < cols <= 32767... checked below)
         fast[k] = k < n && (unsigned)sx < (unsigned)(img.cols - 1) && (unsigned)sy < (unsigned)(img.rows - 1);
-        const unsigned a0 = (unsigned)sy * step + (unsigned)sx * 3 + mis;
+        const unsigned a0 = __umul24((unsigned)sy, step) + __umul24((unsigned)sx, 3u) + mis;   // step < 2^24 (host); 24-bit multiplies are full-rate
         // the aligned 12-byte window of row 1 must end inside the buffer
         fast[k] = fast[k] && ((a0 + step) & ~3u) + 12 <= safe_end;
         o0[k] = fast[k] ? a0 : 0;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
     // stage 5: stores
     if (VEC && n == 4) {
         if constexpr (OUT16) {
-            unsigned* q = (unsigned*)(dimg + (size_t)dy * dimg_step + (size_t)dx0 * 6);
+            unsigned* q = (unsigned*)(dimg + (__umul24((unsigned)dy, (unsigned)dimg_step) + (unsigned)dx0 * 6u));
 #pragma unroll
             for (int k = 0; k < 4; k += 2) {   // 2 pixels = 6 shorts = 3 dwords
                 const unsigned a = px[k], b2 = px[k + 1];
@@ -287,12 +287,12 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
                 q[3 * (k / 2) + 2] = ((b2 >> 8) & 255) | (((b2 >> 16) & 255) << 16);
             }
         } else {
-            unsigned* q = (unsigned*)(dimg + (size_t)dy * dimg_step + (size_t)dx0 * 3);
+            unsigned* q = (unsigned*)(dimg + (__umul24((unsigned)dy, (unsigned)dimg_step) + (unsigned)dx0 * 3u));
             q[0] = px[0] | (px[1] << 24);
             q[1] = (px[1] >> 8) | (px[2] << 16);
             q[2] = (px[2] >> 16) | (px[3] << 8);
         }
-        *(unsigned*)(dmask + (size_t)dy * dmask_step + dx0) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+        *(unsigned*)(dmask + (__umul24((unsigned)dy, (unsigned)dmask_step) + (unsigned)dx0)) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
     } else {
         for (int k = 0; k < n; ++k) {
             if constexpr (OUT16) {
@@ -731,8 +731,8 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
     double spx = (double)src->rows * src->cols, dpx = (double)dw * dh;
     if (fused) {
         ISX_CHECK_ARG(src->type == ISX_8UC3, ISX_ERR_TYPE, "warp_with_mask: src_img must be CV_8UC3, got %s", type_name(src->type));
-        ISX_CHECK_ARG((unsigned long long)w->st_src.d.step * src->rows < (1ull << 31) && src->cols <= 32767 && src->rows <= 32767, ISX_ERR_UNSUPPORTED,
-                      "warp_with_mask: source larger than 2 GiB or 32767 pixels per side");
+        ISX_CHECK_ARG((unsigned long long)w->st_src.d.step * src->rows < (1ull << 31) && w->st_src.d.step < (1u << 24) && src->cols <= 32767 && src->rows <= 32767,
+                      ISX_ERR_UNSUPPORTED, "warp_with_mask: source larger than 2 GiB, 16 MiB per row or 32767 pixels per side");
         ISX_CHECK_ARG(dst->type == ISX_8UC3 || dst->type == ISX_16SC3, ISX_ERR_TYPE, "warp_with_mask: dst_img must be CV_8UC3 or CV_16SC3, got %s", type_name(dst->type));
         ISX_TRY(check_mat(dst_mask, "warp_with_mask: dst_mask"));
         ISX_CHECK_ARG(dst_mask->type == ISX_8UC1, ISX_ERR_TYPE, "warp_with_mask: dst_mask must be CV_8U, got %s", type_name(dst_mask->type));
@@ -753,6 +753,8 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         const isx_mat& dd = w->st_dst.d;
         const isx_mat& dm = w->st_dmask.d;
         const bool vec = ((uintptr_t)dd.data % 4 == 0) && (dd.step % 4 == 0) && ((uintptr_t)dm.data % 4 == 0) && (dm.step % 4 == 0);
+        ISX_CHECK_ARG(dd.step < (1u << 24) && dm.step < (1u << 24) && (unsigned long long)dd.step * dh < (1ull << 32), ISX_ERR_UNSUPPORTED,
+                      "warp_with_mask: destination larger than 4 GiB or 16 MiB per row");
         dim3 grid4(cdiv(dw, 256), cdiv(dh, 4));
         // sync path: the scan ran on this stream and the host has consumed its keys; the kernel re-arms them.
         // planned path: scan + check run on the side stream, nothing to do here.
