@@ -65,6 +65,7 @@ _SIGS = {
     "isx_blender_set_deferred_level0": [C.c_void_p, C.c_int],
     "isx_blender_set_sharpness": [C.c_void_p, C.c_float],
     "isx_mask_dilate_and": [_MP, _MP, C.c_int, C.c_int, _MP, C.c_int, C.c_void_p],
+    "isx_gain_apply": [_MP, C.c_double, C.c_int, C.c_void_p],
     "isx_blender_set_overlap": [C.c_void_p, C.c_int],
     "isx_blender_prepare": [C.c_void_p, C.c_int, _IP, _IP],
     "isx_blender_prepare_roi": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],

@@ -139,6 +139,14 @@ def dilate_and(mask, kw, kh, other=None, device=0, stream=None):
     return out
 
 
+def gain_apply(image, gain, device=0, stream=None):
+    """GainCompensator::apply: multiply(image, gain, image) in place on a CV_8U image (W:241-244).  Returns image."""
+    mi = as_mat(image)
+    ptr = getattr(stream, "cuda_stream", stream)
+    check(_lib.load().isx_gain_apply(C.byref(mi), C.c_double(float(gain)), int(device), C.c_void_p(ptr or 0)))
+    return image
+
+
 class Blender:
     """cv::detail::Blender factory (W:271,276,278)."""
     NO, FEATHER, MULTI_BAND = 0, 1, 2

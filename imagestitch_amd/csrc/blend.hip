@@ -1149,6 +1149,32 @@ __global__ __launch_bounds__(256) void k_dilate_cols_and(const unsigned char* tm
     dst[(size_t)y * dstep + x] = (unsigned char)m;
 }
 
+// N3  GainCompensator::apply (W:241-244): multiply(image, gains_(index, 0), image) on a CV_8U image.  cv::multiply with
+// a double scalar works in CV_64F (arithm_op: muldiv => depth2 = CV_64F, wtype = CV_64F): every byte becomes
+// saturate_cast<uchar>(cvRound((double)byte * gain)), cvRound = cvtsd2si (round-half-even, NaN / overflow -> INT_MIN -> 0).
+__device__ __forceinline__ unsigned gain_byte(unsigned v, double gain) {
+    const double t = __builtin_rint((double)v * gain);
+    const int iv = (t >= -2147483648.0 && t <= 2147483647.0) ? (int)t : INT_MIN;
+    return (unsigned)iv <= 255u ? (unsigned)iv : (iv > 0 ? 255u : 0u);
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_gain_apply(const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep, int rows, int row_bytes, double gain) {
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= rows) return;
+    if constexpr (VEC) {
+        const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+        if (x >= row_bytes) return;
+        const unsigned v = *(const unsigned*)(src + (size_t)y * sstep + x);   // row_bytes is padded to the step: the last dword stays inside the row
+        const unsigned o = gain_byte(v & 255u, gain) | (gain_byte((v >> 8) & 255u, gain) << 8) | (gain_byte((v >> 16) & 255u, gain) << 16) | (gain_byte(v >> 24, gain) << 24);
+        if (x + 4 <= row_bytes) *(unsigned*)(dst + (size_t)y * dstep + x) = o;
+        else for (int k = 0; x + k < row_bytes; ++k) dst[(size_t)y * dstep + x + k] = (unsigned char)((o >> (8 * k)) & 255u);
+    } else {
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (x >= row_bytes) return;
+        dst[(size_t)y * dstep + x] = (unsigned char)gain_byte(src[(size_t)y * sstep + x], gain);
+    }
+}
+
 // zero every pixel of a level that no fed tile covers (only needed when more than MAX_COVER tiles are
 // fed, and by the level-introspection entry point)
 template <int M>
@@ -1845,6 +1871,29 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
                other ? (const unsigned char*)so.d.data : nullptr, other ? so.d.step : 0, (unsigned char*)sd.d.data, sd.d.step);
     ISX_TRY(sd.finish_out(st));
     ISX_HIP(hipStreamSynchronize(st));   // tmp is freed on return
+    return ISX_OK;
+}
+
+int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream) {
+    clear_error();
+    ISX_TRY(check_mat(image, "gain_apply: image"));
+    ISX_CHECK_ARG(image->type == ISX_8UC3 || image->type == ISX_8UC1, ISX_ERR_TYPE, "gain_apply: image must be CV_8UC3 or CV_8UC1, got %s", type_name(image->type));
+    ISX_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    MatStage si, so;
+    ISX_TRY(si.use_in(image, st, "gain_apply: image"));
+    ISX_TRY(so.use_out(image, st, "gain_apply: image"));
+    const int rows = image->rows, row_bytes = image->cols * (image->type == ISX_8UC3 ? 3 : 1);
+    // dword path: aligned rows whose last (possibly partial) dword still lies inside the row pitch
+    const bool vec = ((uintptr_t)si.d.data % 4 == 0) && (si.d.step % 4 == 0) && ((uintptr_t)so.d.data % 4 == 0) && (so.d.step % 4 == 0) &&
+                     (size_t)((row_bytes + 3) & ~3) <= si.d.step;
+    const double bytes = 2.0 * rows * row_bytes;
+    if (vec) ISX_LAUNCH("gain_apply", bytes, st, (k_gain_apply<true>), dim3(cdiv(cdiv(row_bytes, 4), 64), cdiv(rows, 4)), dim3(256), 0,
+                        (const unsigned char*)si.d.data, si.d.step, (unsigned char*)so.d.data, so.d.step, rows, row_bytes, gain);
+    else ISX_LAUNCH("gain_apply", bytes, st, (k_gain_apply<false>), dim3(cdiv(row_bytes, 64), cdiv(rows, 4)), dim3(256), 0,
+                    (const unsigned char*)si.d.data, si.d.step, (unsigned char*)so.d.data, so.d.step, rows, row_bytes, gain);
+    ISX_TRY(so.finish_out(st));
+    if (image->device < 0) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
     return ISX_OK;
 }
 

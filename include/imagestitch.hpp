@@ -187,4 +187,7 @@ inline void dilateAnd(const Mat& mask, int kw, int kh, const Mat* other, Mat& ou
     check(isx_mask_dilate_and(mask.c(), other ? other->c() : nullptr, kw, kh, out.c(), device, nullptr));
 }
 
+// GainCompensator::apply: multiply(image, gain, image)  (W:241-244)
+inline void gainApply(Mat& image, double gain, int device = 0) { check(isx_gain_apply(image.c(), gain, device, nullptr)); }
+
 }  // namespace isx

@@ -212,6 +212,12 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
 int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int kh, isx_mat* out,
                         int device, void* hip_stream);
 
+/* ---- exposure compensation, the per-pixel part (W:241-244) ------------------------------------ */
+/* compensator->apply(i, corners[i], images_warped[i], masks_warped[i]) of the GainCompensator every demo creates
+ * (W:238-239): multiply(image, gain, image) in place on a CV_8UC3 (or CV_8UC1) image, gain = gains_(i, 0) as
+ * computed by compensator->feed (a small linear solve on the host, not part of this library).              */
+int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream);
+
 /* ---- the reference's in-tree single-band seam-ramp blend (B:141-717) --------------------- */
 /* images1/images2: CV_32FC3 warped tiles (B:143-145), tl1/tl2 their corners (B:148-149),
  * pano: caller-allocated CV_32FC3 of isx_blend_pair_linear_size().  seam_x (optional, may be

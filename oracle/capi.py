@@ -245,6 +245,12 @@ def dilate_rect(mask, kw, kh):
     return out
 
 
+def gain_apply(img, gain):
+    a = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    lib().orc_gain_apply_u8(_p(a), C.c_size_t(a.size), C.c_double(gain))
+    return a
+
+
 def distance_transform_l1(mask):
     m = _c(mask, np.uint8)
     out = np.empty(m.shape, np.float32)

@@ -838,6 +838,20 @@ void orc_dilate_rect_u8(const uint8_t* src, int h, int w, int kw, int kh, uint8_
     free(tmp);
 }
 
+/* N3  GainCompensator::apply  W:241-244: multiply(image, gains_(index, 0), image).  OpenCV 3.4.2 core/src/arithm.cpp
+ * arithm_op with a scalar second operand: for mul/div depth2 = CV_64F, so wtype = CV_64F — the bytes are converted
+ * to double, multiplied by the gain (mul64f, scale == 1) and stored with saturate_cast<uchar>(double) =
+ * clamp(cvRound(v)), cvRound(double) = cvtsd2si: round-half-even, NaN / out of int range -> INT_MIN (-> 0).
+ * (Source absent: parity unpinned, known-answer tests only.) */
+void orc_gain_apply_u8(uint8_t* img, size_t n, double gain) {
+    for (size_t i = 0; i < n; ++i) {
+        double v = (double)img[i] * gain;
+        double t = nearbyint(v);                       /* default rounding mode: to nearest even */
+        int iv = (t >= -2147483648.0 && t <= 2147483647.0) ? (int)t : INT_MIN;
+        img[i] = (uint8_t)((unsigned)iv <= 255u ? iv : (iv > 0 ? 255 : 0));
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* N2  FeatherBlender  W:278-281,302,313 (OpenCV 3.4.2 stitching/src/blenders.cpp, absent)       */
 /* ------------------------------------------------------------------------------------------ */

@@ -104,6 +104,8 @@ int  orc_blend_pair_linear(const float* img1, int rows1, int cols1,
 
 /* N3 mask preparation W:286-301 (cv::dilate MORPH_RECT) and N2 FeatherBlender W:278-281,302,313 */
 void orc_dilate_rect_u8(const uint8_t* src, int h, int w, int kw, int kh, uint8_t* dst);
+/* N3 GainCompensator::apply W:241-244: multiply(image, gain, image) on n bytes of a CV_8U image, in place */
+void orc_gain_apply_u8(uint8_t* img, size_t n, double gain);
 void orc_distance_transform_l1(const uint8_t* src, int h, int w, float* dst);
 void orc_feather_weight_map(const uint8_t* mask, int h, int w, float sharpness, float* weight);
 typedef struct orc_fb orc_fb;

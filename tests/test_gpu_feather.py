@@ -248,3 +248,30 @@ def test_feather_deferred_uses_gather_and_flushes(gpu, oracle):
     assert w.max() > 0
     d, m = fb.blend()
     assert np.array_equal(d, od) and np.array_equal(m, om)
+
+
+@pytest.mark.parametrize("gain", [1.0, 0.5, 0.9731, 1.0379, 2.5, -1.0, 1e8, float("inf"), float("nan")])
+def test_gain_apply(gpu, oracle, gain):
+    """compensator->apply (W:241-244) in place, host mats, pitched / unaligned device views, 1 and 3 channels."""
+    import torch
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (67, 131, 3)).astype(np.uint8)
+    ref = oracle.gain_apply(img, gain)
+    a = img.copy()
+    assert gpu.gain_apply(a, gain) is a and np.array_equal(a, ref)
+    t = torch.from_numpy(img).cuda()
+    gpu.gain_apply(t, gain)
+    assert np.array_equal(t.cpu().numpy(), ref)
+    big = torch.from_numpy(rng.integers(0, 256, (67, 140, 3)).astype(np.uint8)).cuda()     # a view: rows start at odd addresses
+    view = big[:, 3:134]
+    before = big.cpu().numpy().copy()
+    gpu.gain_apply(view, gain)
+    after = big.cpu().numpy()
+    assert np.array_equal(after[:, 3:134], oracle.gain_apply(before[:, 3:134], gain))
+    assert np.array_equal(after[:, :3], before[:, :3]) and np.array_equal(after[:, 134:], before[:, 134:])   # nothing outside the view
+    pitched = torch.zeros((50, 256), dtype=torch.uint8, device="cuda")                      # aligned pitch, row length 201 (dword tail)
+    m = rng.integers(0, 256, (50, 201)).astype(np.uint8)
+    pitched[:, :201] = torch.from_numpy(m).cuda()
+    gpu.gain_apply(pitched[:, :201], gain)
+    out = pitched.cpu().numpy()
+    assert np.array_equal(out[:, :201], oracle.gain_apply(m, gain)) and not out[:, 201:].any()

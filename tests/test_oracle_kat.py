@@ -198,3 +198,19 @@ def test_feather_properties(oracle):
     fb.feed(img, full, (0, 0))
     d, m = fb.blend()
     assert np.all(m == 255) and np.abs(d.astype(int) - img).max() <= 1 and (d.astype(int) - img).max() <= 0   # weight 1, -1 truncation bias
+
+
+def test_gain_apply_known_answers(oracle):
+    """GainCompensator::apply = saturate_cast<uchar>(cvRound((double)v * gain)) (W:241-244)."""
+    v = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(oracle.gain_apply(v, 1.0), v)
+    assert np.array_equal(oracle.gain_apply(v, 2.0), np.minimum(v.astype(int) * 2, 255))
+    # ties go to even: 1 * 0.5 = 0.5 -> 0, 3 * 0.5 = 1.5 -> 2, 5 * 0.5 = 2.5 -> 2
+    assert list(oracle.gain_apply(np.array([1, 3, 5, 7], np.uint8), 0.5)) == [0, 2, 2, 4]
+    assert list(oracle.gain_apply(np.array([0, 1, 200], np.uint8), -1.0)) == [0, 0, 0]
+    # cvRound on NaN / beyond int range is INT_MIN -> saturates to 0 (x86 cvtsd2si), not 255
+    assert list(oracle.gain_apply(np.array([0, 1, 200], np.uint8), float("inf"))) == [0, 0, 0]
+    assert list(oracle.gain_apply(np.array([1, 200], np.uint8), 1e8)) == [255, 0]
+    g = 1.0379
+    ref = np.clip(np.rint(v.astype(np.float64) * g), 0, 255).astype(np.uint8)
+    assert np.array_equal(oracle.gain_apply(v, g), ref)
