@@ -37,9 +37,9 @@ def measured_traffic(kernel, args):
         return None
 
 
-def cpu_baseline(width, height, focal, bands, precision):
-    """The CPU oracle (plain C, 1 thread, -O2, no FMA) on ONE pair of the same workload: the
-    reference's call sequence W:229,232 (two warps per tile), W:294, W:281,302,313."""
+def cpu_pair_seconds(width, height, focal, bands, precision):
+    """The CPU oracle (plain C, 1 thread, -O2, no FMA) on ONE pair of the workload: the reference's call
+    sequence W:229,232 (two warps per tile), W:294, W:281,302,313.  Returns (warp seconds, blend seconds)."""
     import numpy as np
     from oracle import capi as O
     from imagestitch_amd import synth
@@ -60,9 +60,45 @@ def cpu_baseline(width, height, focal, bands, precision):
         mb.feed(warped[i].astype(np.int16), seam[i], corners[i])
     mb.blend(False)
     t3 = time.perf_counter()
-    sec = (t1 - t0) + (t3 - t2)
-    return {"value": round(2 * width * height / sec / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "1 pair of %dx%d tiles (oracle/oracle.c, warp %.2fs + blend %.2fs)" % (width, height, t1 - t0, t3 - t2)}
+    return t1 - t0, t3 - t2
+
+
+def cpu_baseline(width, height, focal, bands, precision):
+    """The oracle on the host cores of this box: one independent pair per worker process (the same partitioning as
+    the GPU path, no shared state), as many workers as there are cores, bounded by memory (about 1 GB per 4K pair).
+    value = sum of the workers' rates while they run concurrently; value_1core = one worker alone."""
+    import subprocess
+    one = cpu_pair_seconds(width, height, focal, bands, precision)
+    px = 2.0 * width * height
+    rate1 = px / (one[0] + one[1]) / 1e6
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        per_worker = 1.0e9 * (width * height) / (3840.0 * 2160.0) + 0.2e9
+        cores = int(max(1, min(cores, psutil.virtual_memory().available * 0.25 // per_worker)))
+    except Exception:
+        cores = min(cores, 8)
+    cores = min(cores, 64)
+    out = {"value": round(rate1, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": "1 pair of %dx%d tiles (oracle/oracle.c, warp %.2fs + blend %.2fs)" % (width, height, one[0], one[1])}
+    if cores > 1:
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--width", str(width), "--height", str(height), "--focal", str(focal),
+               "--bands", str(bands), "--precision", {0: "i16", 1: "f32", 2: "f16acc32"}[precision]]
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for _ in range(cores)]
+        rates = []
+        for pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=300)
+                d = json.loads(o.decode().strip().splitlines()[-1])
+                rates.append(px / (d["warp"] + d["blend"]) / 1e6)
+            except Exception:
+                pr.kill()
+        if len(rates) == cores:
+            out = {"value": round(sum(rates), 3), "unit": "Mpix/s", "cores": cores, "kind": "port", "value_1core": round(rate1, 3),
+                   "sample": "%d concurrent worker processes, one %dx%d pair each (oracle/oracle.c: single-threaded C, -O2, no FMA); "
+                             "one worker alone: warp %.2fs + blend %.2fs" % (cores, width, height, one[0], one[1])}
+    return out
 
 
 def main():
@@ -79,8 +115,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sync-roi", action="store_true", help="return every warp's corner to the host (one stream sync per tile) instead of the planned, device-checked ROI")
     args = ap.parse_args()
+    if args.cpu_worker:   # one worker of the cpu_baseline leg: no torch, no GPU
+        prec_w = {"i16": 0, "f32": 1, "f16acc32": 2}[args.precision]
+        tw, tb = cpu_pair_seconds(args.width, args.height, args.focal, args.bands, prec_w)
+        print(json.dumps({"warp": tw, "blend": tb}))
+        return
 
     import numpy as np
     import torch
