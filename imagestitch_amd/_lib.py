@@ -66,6 +66,9 @@ _SIGS = {
     "isx_blender_set_sharpness": [C.c_void_p, C.c_float],
     "isx_mask_dilate_and": [_MP, _MP, C.c_int, C.c_int, _MP, C.c_int, C.c_void_p],
     "isx_gain_apply": [_MP, C.c_double, C.c_int, C.c_void_p],
+    "isx_bmp_size": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "isx_bmp_read": [C.c_char_p, _MP],
+    "isx_bmp_write": [C.c_char_p, _MP],
     "isx_blender_set_overlap": [C.c_void_p, C.c_int],
     "isx_blender_prepare": [C.c_void_p, C.c_int, _IP, _IP],
     "isx_blender_prepare_roi": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],

@@ -1,0 +1,31 @@
+"""cv::imread / cv::imwrite for the .bmp files either side of the hot path (W:166, W:155-156, W:315) — SURVEY §8(f) N4.
+Uncompressed Windows bitmaps only (the reference's committed artefacts); JPEG is not implemented."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_mat, check
+
+
+def imread(path, device=None):
+    """cv::imread(path) (IMREAD_COLOR): HxWx3 uint8 BGR — a numpy array, or a torch CUDA tensor when `device` is given."""
+    lib = _lib.load()
+    rows, cols = C.c_int(), C.c_int()
+    check(lib.isx_bmp_size(os.fsencode(path), C.byref(rows), C.byref(cols)))
+    if device is None:
+        out = np.empty((rows.value, cols.value, 3), np.uint8)
+    else:
+        import torch
+        out = torch.empty((rows.value, cols.value, 3), dtype=torch.uint8, device=torch.device("cuda", device))
+    m = as_mat(out)
+    check(lib.isx_bmp_read(os.fsencode(path), C.byref(m)))
+    return out
+
+
+def imwrite(path, img):
+    """cv::imwrite(path, img) for CV_8UC3 / CV_8UC1 host or device mats."""
+    m = as_mat(img)
+    check(_lib.load().isx_bmp_write(os.fsencode(path), C.byref(m)))
+    return True

@@ -51,3 +51,17 @@ def unpack_blocks(gathered_row, shapes):
         out.append(gathered_row[off:off + n].reshape(shp))
         off += n
     return out
+
+
+def write_mosaics(prefix, gathered, shapes_per_rank):
+    """Tiled-mosaic writer for the gathered batch: one `<prefix>_r<rank>_p<pair>.bmp` per blended
+    pair, from the (world, capacity) uint8 tensor gather_mosaics returns.  shapes_per_rank[r] = the (H, W, 3) shapes
+    of rank r's mosaics in packing order.  Returns the file names (cv::imwrite W:315 per mosaic)."""
+    from .imgio import imwrite
+    names = []
+    for r, shapes in enumerate(shapes_per_rank):
+        for i, m in enumerate(unpack_blocks(gathered[r], shapes)):
+            name = "%s_r%d_p%d.bmp" % (prefix, r, i)
+            imwrite(name, m.contiguous() if hasattr(m, "contiguous") else m)
+            names.append(name)
+    return names

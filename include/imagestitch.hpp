@@ -187,6 +187,17 @@ inline void dilateAnd(const Mat& mask, int kw, int kh, const Mat* other, Mat& ou
     check(isx_mask_dilate_and(mask.c(), other ? other->c() : nullptr, kw, kh, out.c(), device, nullptr));
 }
 
+// cv::imread(path) / cv::imwrite(path, img) for .bmp files (W:166,315)
+inline Mat imread(const char* path) {
+    int rows = 0, cols = 0;
+    check(isx_bmp_size(path, &rows, &cols));
+    Mat m;
+    m.create(rows, cols, ISX_8UC3);
+    check(isx_bmp_read(path, m.c()));
+    return m;
+}
+inline void imwrite(const char* path, const Mat& img) { check(isx_bmp_write(path, img.c())); }
+
 // GainCompensator::apply: multiply(image, gain, image)  (W:241-244)
 inline void gainApply(Mat& image, double gain, int device = 0) { check(isx_gain_apply(image.c(), gain, device, nullptr)); }
 

@@ -218,6 +218,15 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
  * computed by compensator->feed (a small linear solve on the host, not part of this library).              */
 int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream);
 
+/* ---- on-disk format either side of the path: .bmp (W:166 imread, W:155-156,315 imwrite) ----------- */
+/* Uncompressed Windows bitmaps only (the reference's committed artefacts are BMPs; JPEG is not implemented).
+ * isx_bmp_read = cv::imread(path) with IMREAD_COLOR: `out` is a CV_8UC3 mat (host or device) of the size
+ * isx_bmp_size reports; 8-bit paletted files are expanded through their palette.  isx_bmp_write = cv::imwrite
+ * for CV_8UC3 (24-bit) and CV_8UC1 (8-bit, grey palette), host or device mats.                              */
+int isx_bmp_size(const char* path, int* rows, int* cols);
+int isx_bmp_read(const char* path, isx_mat* out);
+int isx_bmp_write(const char* path, const isx_mat* img);
+
 /* ---- the reference's in-tree single-band seam-ramp blend (B:141-717) --------------------- */
 /* images1/images2: CV_32FC3 warped tiles (B:143-145), tl1/tl2 their corners (B:148-149),
  * pano: caller-allocated CV_32FC3 of isx_blend_pair_linear_size().  seam_x (optional, may be

@@ -1,0 +1,102 @@
+"""the .bmp reader / writer either side of the path (cv::imread W:166, cv::imwrite W:155-156,315),
+against Pillow's codec.  Host-only code: runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def isx():
+    import imagestitch_amd
+    imagestitch_amd.load()
+    return imagestitch_amd
+
+
+@pytest.mark.parametrize("shape", [(7, 5), (33, 64), (20, 101), (1, 1), (64, 3)])
+def test_bmp_round_trip_against_pillow(isx, tmp_path, shape):
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    h, w = shape
+    bgr = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    gray = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    p = str(tmp_path / "a.bmp")
+    assert isx.imwrite(p, bgr)
+    assert np.array_equal(np.asarray(PIL.open(p).convert("RGB"))[:, :, ::-1], bgr)           # our writer, Pillow's reader
+    assert np.array_equal(isx.imread(p), bgr)                                                  # our reader
+    PIL.fromarray(bgr[:, :, ::-1].copy()).save(str(tmp_path / "b.bmp"))                        # Pillow's writer, our reader
+    assert np.array_equal(isx.imread(str(tmp_path / "b.bmp")), bgr)
+    # CV_8UC1 -> 8-bit bitmap with a grey palette; imread (IMREAD_COLOR) expands it to 3 equal channels
+    assert isx.imwrite(str(tmp_path / "g.bmp"), gray)
+    im = PIL.open(str(tmp_path / "g.bmp"))
+    assert im.mode in ("L", "P") and np.array_equal(np.asarray(im.convert("L")), gray)
+    assert np.array_equal(isx.imread(str(tmp_path / "g.bmp")), np.repeat(gray[:, :, None], 3, 2))
+    PIL.fromarray(gray).save(str(tmp_path / "h.bmp"))
+    assert np.array_equal(isx.imread(str(tmp_path / "h.bmp")), np.repeat(gray[:, :, None], 3, 2))
+    # a pitched (non-dense) host view is written row by row
+    big = rng.integers(0, 256, (h, w + 5, 3)).astype(np.uint8)
+    assert isx.imwrite(str(tmp_path / "v.bmp"), big[:, 2:2 + w])
+    assert np.array_equal(isx.imread(str(tmp_path / "v.bmp")), big[:, 2:2 + w])
+
+
+def test_bmp_top_down_and_errors(isx, tmp_path):
+    bgr = np.arange(4 * 3 * 3, dtype=np.uint8).reshape(4, 3, 3)
+    p = str(tmp_path / "t.bmp")
+    isx.imwrite(p, bgr)
+    raw = bytearray(open(p, "rb").read())
+    raw[22:26] = (-4 & 0xffffffff).to_bytes(4, "little")          # negative height = top-down rows
+    open(p, "wb").write(bytes(raw))
+    assert np.array_equal(isx.imread(p), bgr[::-1])
+    with pytest.raises(isx.IsxError):
+        isx.imread(str(tmp_path / "missing.bmp"))
+    open(str(tmp_path / "x.bmp"), "wb").write(b"\xff\xd8\xff\xe0" + b"\0" * 100)          # a JPEG signature
+    with pytest.raises(isx.IsxError) as e:
+        isx.imread(str(tmp_path / "x.bmp"))
+    assert e.value.code == 6
+    with pytest.raises(isx.IsxError):
+        isx.imwrite(str(tmp_path / "f.bmp"), np.zeros((4, 4, 3), np.float32))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
+def test_reads_the_references_committed_bitmaps(isx):
+    """The artefacts the reference's imwrite produced (S:1195-1198) decode to what Pillow decodes."""
+    import glob
+    files = sorted(glob.glob("/root/reference/**/*.bmp", recursive=True))
+    assert files
+    for f in files[:6]:
+        ref = np.asarray(PIL.open(f).convert("RGB"))[:, :, ::-1]
+        assert np.array_equal(isx.imread(f), ref), f
+
+
+def test_write_mosaics_of_a_gathered_batch(isx, tmp_path):
+    """The tiled-mosaic writer on the (world, capacity) tensor the all-gather produces (host tensors here)."""
+    import torch
+    from imagestitch_amd import mosaic
+    rng = np.random.default_rng(9)
+    shapes = [[(5, 7, 3), (6, 4, 3)], [(3, 9, 3)]]
+    imgs = [[torch.from_numpy(rng.integers(0, 256, s).astype(np.uint8)) for s in row] for row in shapes]
+    cap = max(sum(t.numel() for t in row) for row in imgs)
+    gathered = torch.stack([mosaic.pack_blocks(row, cap) for row in imgs])
+    names = mosaic.write_mosaics(str(tmp_path / "pano"), gathered, shapes)
+    assert [os.path.basename(n) for n in names] == ["pano_r0_p0.bmp", "pano_r0_p1.bmp", "pano_r1_p0.bmp"]
+    flat = [t for row in imgs for t in row]
+    for n, t in zip(names, flat):
+        assert np.array_equal(isx.imread(n), t.numpy())
+
+
+@pytest.mark.gpu
+def test_bmp_device_mats(isx, tmp_path):
+    import torch
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    t = torch.from_numpy(a).cuda()
+    p = str(tmp_path / "d.bmp")
+    isx.imwrite(p, t)
+    assert np.array_equal(np.asarray(PIL.open(p).convert("RGB"))[:, :, ::-1], a)
+    back = isx.imread(p, device=0)
+    assert back.is_cuda and np.array_equal(back.cpu().numpy(), a)
+    pitched = torch.zeros((37, 64, 3), dtype=torch.uint8, device="cuda")
+    pitched[:, 3:56] = t
+    isx.imwrite(p, pitched[:, 3:56])
+    assert np.array_equal(isx.imread(p), a)
