@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libimagestitch_hip.so")
 
 # ---- enums (numeric values of include/imagestitch_hip.h == OpenCV's) -------------------------
 ISX_8UC1, ISX_8UC3, ISX_16SC3, ISX_32FC1, ISX_32FC3 = 0, 16, 19, 5, 21
+ISX_32SC1 = 4
 INTER_NEAREST, INTER_LINEAR = 0, 1
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
 WARP_CYLINDRICAL, WARP_SPHERICAL = 0, 1
@@ -66,6 +67,8 @@ _SIGS = {
     "isx_blender_set_sharpness": [C.c_void_p, C.c_float],
     "isx_mask_dilate_and": [_MP, _MP, C.c_int, C.c_int, _MP, C.c_int, C.c_void_p],
     "isx_gain_apply": [_MP, C.c_double, C.c_int, C.c_void_p],
+    "isx_seam_estimate": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _MP, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                          C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p],
     "isx_bmp_size": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "isx_bmp_read": [C.c_char_p, _MP],
     "isx_bmp_write": [C.c_char_p, _MP],
@@ -126,7 +129,7 @@ def f9(a):
     return arr, arr.ctypes.data_as(_F9)
 
 
-_NP_TYPES = {("uint8", 1): ISX_8UC1, ("uint8", 3): ISX_8UC3, ("int16", 3): ISX_16SC3, ("float32", 1): ISX_32FC1, ("float32", 3): ISX_32FC3}
+_NP_TYPES = {("uint8", 1): ISX_8UC1, ("uint8", 3): ISX_8UC3, ("int16", 3): ISX_16SC3, ("float32", 1): ISX_32FC1, ("float32", 3): ISX_32FC3, ("int32", 1): ISX_32SC1}
 
 
 def as_mat(a):

@@ -24,6 +24,7 @@ const char* type_name(int type) {
         case ISX_8UC1: return "CV_8UC1";
         case ISX_8UC3: return "CV_8UC3";
         case ISX_16SC3: return "CV_16SC3";
+        case ISX_32SC1: return "CV_32SC1";
         case ISX_32FC1: return "CV_32FC1";
         case ISX_32FC3: return "CV_32FC3";
         default: return "unsupported type";

@@ -49,6 +49,7 @@ enum {
     ISX_8UC1 = 0,   /* CV_8UC1  : masks (W:213-214,232)                                       */
     ISX_8UC3 = 16,  /* CV_8UC3  : source and warped images (W:166-169,229)                    */
     ISX_16SC3 = 19, /* CV_16SC3 : Blender::feed input / blend output (W:294,302,313)          */
+    ISX_32SC1 = 4,  /* CV_32SC1 : the seam finder's label image labels_ (S:83)                    */
     ISX_32FC1 = 5,  /* CV_32FC1 : xmap / ymap (W:128-129)                                     */
     ISX_32FC3 = 21  /* CV_32FC3 : float images (W:261; B:143-145)                             */
 };
@@ -217,6 +218,19 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
  * (W:238-239): multiply(image, gain, image) in place on a CV_8UC3 (or CV_8UC1) image, gain = gains_(i, 0) as
  * computed by compensator->feed (a small linear solve on the host, not part of this library).              */
 int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream);
+
+/* ---- DP seam finder, its data-parallel part (S = 动态规划法寻找最佳缝合线.cpp) ------------------------- */
+/* estimateSeam(image1, image2, tl1, tl2, comp, p1, p2, seam, isHorizontal) S:806-957 incl. computeCosts S:733-803
+ * (costFunc_ COLOR, what `new DpSeamFinder(DpSeamFinder::COLOR)` W:253 / S:71-72 runs): the cost maps and the dynamic
+ * programme run on the GPU, direction choice and backtracking on the host.  The component analysis around it
+ * (findComponents, findEdges, resolveConflicts, getSeamTips, updateLabelsUsingSeam) stays with the caller and supplies
+ * `labels` (labels_, CV_32SC1, union-sized), `label` = comp + 1, roi = {x, y, width, height} of Rect(tls_[comp],
+ * brs_[comp]) and the tips p1, p2 (union coordinates).  Images: both CV_32FC3 (W:261) or both CV_8UC3.
+ * seam_xy receives *seam_len points (x, y), p1 first; *seam_len = 0 when p2 is not reachable (`return false`).   */
+int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, int tl1_y, int tl2_x, int tl2_y,
+                      int union_tl_x, int union_tl_y, const isx_mat* labels, int label, const int roi[4],
+                      int p1_x, int p1_y, int p2_x, int p2_y, int* seam_xy, int cap, int* seam_len,
+                      int* is_horizontal, int device, void* hip_stream);
 
 /* ---- on-disk format either side of the path: .bmp (W:166 imread, W:155-156,315 imwrite) ----------- */
 /* Uncompressed Windows bitmaps only (the reference's committed artefacts are BMPs; JPEG is not implemented).

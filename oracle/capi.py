@@ -329,3 +329,32 @@ def ref_map_backward_n(u, v):
     x, y = np.empty_like(u), np.empty_like(u)
     ref().ref_map_backward_n(C.c_int(u.size), _p(u), _p(v), _p(x), _p(y))
     return x, y
+
+
+def _seam_args(img1, img2, tl1, tl2, union_tl, labels, label, roi):
+    is_u8 = img1.dtype == np.uint8
+    a = _c(img1, np.uint8 if is_u8 else np.float32)
+    b = _c(img2, np.uint8 if is_u8 else np.float32)
+    lab = _c(labels, np.int32)
+    return a, b, lab, [_p(a), a.shape[0], a.shape[1], _p(b), b.shape[0], b.shape[1], int(is_u8), int(tl1[0]), int(tl1[1]), int(tl2[0]), int(tl2[1]),
+                       int(union_tl[0]), int(union_tl[1]), _p(lab), lab.shape[0], lab.shape[1], int(label), int(roi[0]), int(roi[1]), int(roi[2]), int(roi[3])]
+
+
+def seam_costs(img1, img2, tl1, tl2, union_tl, labels, label, roi):
+    """computeCosts S:733-803 -> (costV rh x (rw+1), costH (rh+1) x rw)."""
+    a, b, lab, args = _seam_args(img1, img2, tl1, tl2, union_tl, labels, label, roi)
+    rw, rh = int(roi[2]), int(roi[3])
+    cv, ch = np.empty((rh, rw + 1), np.float32), np.empty((rh + 1, rw), np.float32)
+    lib().orc_seam_costs(*args, _p(cv), _p(ch))
+    return cv, ch
+
+
+def seam_estimate(img1, img2, tl1, tl2, union_tl, labels, label, roi, p1, p2):
+    """estimateSeam S:806-957 -> (seam (N, 2) int32, p1 first; empty = unreachable, is_horizontal)."""
+    a, b, lab, args = _seam_args(img1, img2, tl1, tl2, union_tl, labels, label, roi)
+    cap = int(roi[2]) + int(roi[3]) + 2
+    out = np.zeros((cap, 2), np.int32)
+    horiz = C.c_int(0)
+    lib().orc_seam_estimate.restype = C.c_int
+    n = lib().orc_seam_estimate(*args, int(p1[0]), int(p1[1]), int(p2[0]), int(p2[1]), _p(out), cap, C.byref(horiz))
+    return out[:n].copy(), bool(horiz.value)

@@ -945,3 +945,135 @@ void orc_fb_blend(orc_fb* b, int16_t* dst, uint8_t* dst_mask) {
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N1  DP seam finder, the data-parallel part: computeCosts S:733-803, estimateSeam S:806-957     */
+/* ------------------------------------------------------------------------------------------ */
+/* diffL2Square3<T> S:712-718: static_cast<float>(sqr(a0 - b0) + sqr(a1 - b1) + sqr(a2 - b2)); for uchar the
+ * differences and squares are int, for float every operation is a float operation, left to right */
+static float seam_diff(const void* i1, int cols1, int y1, int x1, const void* i2, int cols2, int y2, int x2, int is_u8) {
+    if (is_u8) {
+        const uint8_t* a = (const uint8_t*)i1 + ((size_t)y1 * cols1 + x1) * 3;
+        const uint8_t* b = (const uint8_t*)i2 + ((size_t)y2 * cols2 + x2) * 3;
+        int d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+        return (float)(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+    const float* a = (const float*)i1 + ((size_t)y1 * cols1 + x1) * 3;
+    const float* b = (const float*)i2 + ((size_t)y2 * cols2 + x2) * 3;
+    float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    float s = d0 * d0;
+    s = s + d1 * d1;
+    s = s + d2 * d2;
+    return s;
+}
+static int seam_label(const int32_t* labels, int uh, int uw, int y, int x) {
+    return ((unsigned)y < (unsigned)uh && (unsigned)x < (unsigned)uw) ? labels[(size_t)y * uw + x] : 0;
+}
+
+void orc_seam_costs(const void* img1, int rows1, int cols1, const void* img2, int rows2, int cols2, int is_u8,
+                    int tl1x, int tl1y, int tl2x, int tl2y, int utlx, int utly,
+                    const int32_t* labels, int uh, int uw, int label, int rx, int ry, int rw, int rh,
+                    float* costV, float* costH) {
+    (void)rows1; (void)rows2;
+    const int dx1 = utlx - tl1x, dy1 = utly - tl1y, dx2 = utlx - tl2x, dy2 = utly - tl2y;      /* S:750-751 */
+    const float bad = 3.f * 255.f * 255.f;   /* normL2(Point3f(255,255,255), Point3f(0,0,0)) = (a-b).dot(a-b), S:754 */
+    for (int y = ry; y < ry + rh; ++y)                                                            /* S:757-779 */
+        for (int x = rx; x < rx + rw + 1; ++x) {
+            float c = bad;
+            if (seam_label(labels, uh, uw, y, x) == label && x > 0 && seam_label(labels, uh, uw, y, x - 1) == label)
+                c = (seam_diff(img1, cols1, y + dy1, x + dx1 - 1, img2, cols2, y + dy2, x + dx2, is_u8) +
+                     seam_diff(img1, cols1, y + dy1, x + dx1, img2, cols2, y + dy2, x + dx2 - 1, is_u8)) / 2;
+            costV[(size_t)(y - ry) * (rw + 1) + (x - rx)] = c;
+        }
+    for (int y = ry; y < ry + rh + 1; ++y)                                                        /* S:784-802 */
+        for (int x = rx; x < rx + rw; ++x) {
+            float c = bad;
+            if (seam_label(labels, uh, uw, y, x) == label && y > 0 && seam_label(labels, uh, uw, y - 1, x) == label)
+                c = (seam_diff(img1, cols1, y + dy1 - 1, x + dx1, img2, cols2, y + dy2, x + dx2, is_u8) +
+                     seam_diff(img1, cols1, y + dy1, x + dx1, img2, cols2, y + dy2 - 1, x + dx2, is_u8)) / 2;
+            costH[(size_t)(y - ry) * rw + (x - rx)] = c;
+        }
+}
+
+int orc_seam_estimate(const void* img1, int rows1, int cols1, const void* img2, int rows2, int cols2, int is_u8,
+                      int tl1x, int tl1y, int tl2x, int tl2y, int utlx, int utly,
+                      const int32_t* labels, int uh, int uw, int label, int rx, int ry, int rw, int rh,
+                      int p1x, int p1y, int p2x, int p2y, int* seam_xy, int cap, int* is_horizontal) {
+    float* costV = (float*)malloc(sizeof(float) * (size_t)rh * (rw + 1));
+    float* costH = (float*)malloc(sizeof(float) * (size_t)(rh + 1) * rw);
+    orc_seam_costs(img1, rows1, cols1, img2, rows2, cols2, is_u8, tl1x, tl1y, tl2x, tl2y, utlx, utly, labels, uh, uw, label, rx, ry, rw, rh,
+                   costV, costH);
+#define CV_(y, x) costV[(size_t)(y) * (rw + 1) + (x)]
+#define CH_(y, x) costH[(size_t)(y) * rw + (x)]
+    int sx = p1x - rx, sy = p1y - ry, dx = p2x - rx, dy = p2y - ry, swapped = 0;                 /* S:816-817 */
+    int horiz = abs(dx - sx) > abs(dy - sy);                                                      /* S:827 */
+    if (horiz ? sx > dx : sy > dy) { int t = sx; sx = dx; dx = t; t = sy; sy = dy; dy = t; swapped = 1; }   /* S:829-842 */
+    uint8_t* control = (uint8_t*)calloc((size_t)rw * rh, 1);
+    uint8_t* reach = (uint8_t*)calloc((size_t)rw * rh, 1);
+    float* cost = (float*)calloc((size_t)rw * rh, sizeof(float));
+#define AT(m, y, x) m[(size_t)(y) * rw + (x)]
+    AT(reach, sy, sx) = 1; AT(cost, sy, sx) = 0.f;                                                /* S:850-851 */
+    if (horiz) {                                                                                  /* S:858-886 */
+        for (int x = sx + 1; x <= dx; ++x)
+            for (int y = 0; y < rh; ++y) {
+                int n = 0; float sc[3]; int sd[3];
+                if (seam_label(labels, uh, uw, y + ry, x + rx) == label) {
+                    if (AT(reach, y, x - 1)) { sc[n] = AT(cost, y, x - 1) + CH_(y, x - 1); sd[n++] = 1; }
+                    if (y > 0 && AT(reach, y - 1, x - 1)) { sc[n] = AT(cost, y - 1, x - 1) + CH_(y - 1, x - 1) + CV_(y - 1, x); sd[n++] = 2; }
+                    if (y < rh - 1 && AT(reach, y + 1, x - 1)) { sc[n] = AT(cost, y + 1, x - 1) + CH_(y + 1, x - 1) + CV_(y, x); sd[n++] = 3; }
+                }
+                if (n) {   /* min_element over pair<float, int>: first minimum, ties broken by the smaller step code */
+                    int b = 0;
+                    for (int k = 1; k < n; ++k) if (sc[k] < sc[b]) b = k;
+                    AT(cost, y, x) = sc[b]; AT(control, y, x) = (uint8_t)sd[b]; AT(reach, y, x) = 255;
+                }
+            }
+    } else {                                                                                      /* S:888-916 */
+        for (int y = sy + 1; y <= dy; ++y)
+            for (int x = 0; x < rw; ++x) {
+                int n = 0; float sc[3]; int sd[3];
+                if (seam_label(labels, uh, uw, y + ry, x + rx) == label) {
+                    if (AT(reach, y - 1, x)) { sc[n] = AT(cost, y - 1, x) + CV_(y - 1, x); sd[n++] = 1; }
+                    if (x > 0 && AT(reach, y - 1, x - 1)) { sc[n] = AT(cost, y - 1, x - 1) + CV_(y - 1, x - 1) + CH_(y, x - 1); sd[n++] = 2; }
+                    if (x < rw - 1 && AT(reach, y - 1, x + 1)) { sc[n] = AT(cost, y - 1, x + 1) + CV_(y - 1, x + 1) + CH_(y, x); sd[n++] = 3; }
+                }
+                if (n) {
+                    int b = 0;
+                    for (int k = 1; k < n; ++k) if (sc[k] < sc[b]) b = k;
+                    AT(cost, y, x) = sc[b]; AT(control, y, x) = (uint8_t)sd[b]; AT(reach, y, x) = 255;
+                }
+            }
+    }
+    int len = 0;
+    if (AT(reach, dy, dx)) {                                                                      /* S:918-953 */
+        int px = dx, py = dy;
+        int* tmp = (int*)malloc(sizeof(int) * 2 * (size_t)(rw + rh + 2));
+        tmp[0] = px + rx; tmp[1] = py + ry; len = 1;
+        if (horiz) {
+            while (px != sx) {
+                int c = AT(control, py, px);
+                if (c == 2) py--; else if (c == 3) py++;
+                px--;
+                tmp[2 * len] = px + rx; tmp[2 * len + 1] = py + ry; ++len;
+            }
+        } else {
+            while (py != sy) {
+                int c = AT(control, py, px);
+                if (c == 2) px--; else if (c == 3) px++;
+                py--;
+                tmp[2 * len] = px + rx; tmp[2 * len + 1] = py + ry; ++len;
+            }
+        }
+        for (int i = 0; i < len && i < cap; ++i) {
+            int j = swapped ? i : len - 1 - i;                                                    /* S:947-948: reverse unless swapped */
+            seam_xy[2 * i] = tmp[2 * j]; seam_xy[2 * i + 1] = tmp[2 * j + 1];
+        }
+        free(tmp);
+    }
+    if (is_horizontal) *is_horizontal = horiz;
+    free(costV); free(costH); free(control); free(reach); free(cost);
+#undef CV_
+#undef CH_
+#undef AT
+    return len;
+}

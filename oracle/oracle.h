@@ -116,6 +116,22 @@ void    orc_fb_result_size(const orc_fb* b, int* w, int* h);
 void    orc_fb_feed(orc_fb* b, const int16_t* img, const uint8_t* mask, int rows, int cols, int tl_x, int tl_y);
 void    orc_fb_blend(orc_fb* b, int16_t* dst, uint8_t* dst_mask);
 
+/* N1, the data-parallel part of the in-tree DP seam finder (S = 动态规划法寻找最佳缝合线.cpp):
+ * computeCosts S:733-803 (costFunc_ COLOR) and estimateSeam S:806-957.  Images are HWC 3-channel float (is_u8 == 0)
+ * or uint8 (is_u8 == 1), contiguous; labels is the union-sized int32 label image (labels_), label = comp + 1,
+ * (rx, ry, rw, rh) = Rect(tls_[comp], brs_[comp]).  A labels_ read outside the union counts as "not label" (the
+ * reference reads past the row there).  costV: rh x (rw + 1), costH: (rh + 1) x rw.
+ * orc_seam_estimate returns the seam length (0: p2 is not reachable from p1, the reference returns false) and
+ * writes the seam points (union coordinates, p1 first) to seam_xy. */
+void orc_seam_costs(const void* img1, int rows1, int cols1, const void* img2, int rows2, int cols2, int is_u8,
+                    int tl1x, int tl1y, int tl2x, int tl2y, int utlx, int utly,
+                    const int32_t* labels, int uh, int uw, int label, int rx, int ry, int rw, int rh,
+                    float* costV, float* costH);
+int  orc_seam_estimate(const void* img1, int rows1, int cols1, const void* img2, int rows2, int cols2, int is_u8,
+                       int tl1x, int tl1y, int tl2x, int tl2y, int utlx, int utly,
+                       const int32_t* labels, int uh, int uw, int label, int rx, int ry, int rw, int rh,
+                       int p1x, int p1y, int p2x, int p2y, int* seam_xy, int cap, int* is_horizontal);
+
 #ifdef __cplusplus
 }
 #endif

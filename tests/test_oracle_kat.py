@@ -214,3 +214,36 @@ def test_gain_apply_known_answers(oracle):
     g = 1.0379
     ref = np.clip(np.rint(v.astype(np.float64) * g), 0, 255).astype(np.uint8)
     assert np.array_equal(oracle.gain_apply(v, g), ref)
+
+
+def test_seam_estimate_known_answers(oracle):
+    """estimateSeam S:806-957 / computeCosts S:733-803 on cases with an obvious answer."""
+    h, w = 40, 30
+    lab = np.full((h, w), 1, np.int32)
+    a = np.zeros((h, w, 3), np.float32)
+    # identical images: every step costs 0, ties keep step 1 (straight), the seam drifts only as far as it must
+    seam, horiz = oracle.seam_estimate(a, a, (0, 0), (0, 0), (0, 0), lab, 1, (0, 0, w, h), (10, 0), (10, h - 1))
+    assert not horiz and len(seam) == h and (seam[:, 0] == 10).all() and (seam[:, 1] == np.arange(h)).all()
+    seam, _ = oracle.seam_estimate(a, a, (0, 0), (0, 0), (0, 0), lab, 1, (0, 0, w, h), (10, 0), (14, h - 1))
+    assert tuple(seam[0]) == (10, 0) and tuple(seam[-1]) == (14, h - 1)
+    assert (np.diff(seam[:, 1]) == 1).all() and (np.abs(np.diff(seam[:, 0])) <= 1).all()
+    # swapped tips: same path, reported from p1 to p2
+    back, _ = oracle.seam_estimate(a, a, (0, 0), (0, 0), (0, 0), lab, 1, (0, 0, w, h), (14, h - 1), (10, 0))
+    assert tuple(back[0]) == (14, h - 1) and tuple(back[-1]) == (10, 0)
+    # a zero-cost valley between columns 19 and 20 (the images differ everywhere else): the seam runs along it
+    b = a.copy()
+    b[:, :, :] = 50.0
+    b[:, 19:21, :] = 0.0
+    seam, _ = oracle.seam_estimate(a, b, (0, 0), (0, 0), (0, 0), lab, 1, (0, 0, w, h), (20, 0), (20, h - 1))
+    assert (seam[:, 0] == 20).all()
+    cv, ch = oracle.seam_costs(a, b, (0, 0), (0, 0), (0, 0), lab, 1, (0, 0, w, h))
+    assert cv.shape == (h, w + 1) and ch.shape == (h + 1, w)
+    assert cv[5, 0] == 3 * 255.0 ** 2 and cv[5, w] == 3 * 255.0 ** 2          # badRegionCost outside the component (x == 0, x == width)
+    assert cv[5, 20] == 0.0 and cv[5, 10] == 3 * 50.0 ** 2                     # (|I1(x-1)-I2(x)|^2 + |I1(x)-I2(x-1)|^2) / 2
+    # horizontal seam when the tips are further apart in x than in y
+    seam, horiz = oracle.seam_estimate(a, a, (0, 0), (0, 0), (0, 0), lab, 1, (0, 0, w, h), (0, 7), (w - 1, 9))
+    assert horiz and len(seam) == w and tuple(seam[0]) == (0, 7) and tuple(seam[-1]) == (w - 1, 9)
+    # a wall of another component between the tips: not reachable -> empty seam (`return false`)
+    lab2 = lab.copy(); lab2[20, :] = 2
+    seam, _ = oracle.seam_estimate(a, a, (0, 0), (0, 0), (0, 0), lab2, 1, (0, 0, w, h), (10, 0), (10, h - 1))
+    assert len(seam) == 0
