@@ -213,6 +213,14 @@ def test_feather_deferred_gather_equals_eager_and_oracle(gpu, oracle, n):
             d, m = fb.blend()
         outs.append((d.cpu().numpy(), m.cpu().numpy()))
         assert np.array_equal(outs[-1][1], om) and np.array_equal(outs[-1][0], od)
+    # host mats in a deferred cycle: every recorded tile is staged into a buffer of its own (CV_16SC3 entry)
+    fb = gpu.FeatherBlender(False, 0.05)
+    fb.set_deferred_level0(True)
+    fb.prepare(corners, sizes)
+    for im, mk, c in zip(imgs, masks, corners):
+        fb.feed(im.astype(np.int16), mk, c)
+    d, m = fb.blend()
+    assert np.array_equal(m, om) and np.array_equal(d, od)
 
 
 def test_feather_deferred_uses_gather_and_flushes(gpu, oracle):
