@@ -58,3 +58,39 @@ def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path):
     got = np.fromfile(str(tmp_path / "o_result.raw"), np.int16).reshape(r, c, 3)
     gm = np.fromfile(str(tmp_path / "o_result_mask.raw"), np.uint8).reshape(r, c)
     assert np.array_equal(got, od) and np.array_equal(gm, om)
+
+
+def test_cpp_mirror_default_demo_stage(gpu, oracle, tmp_path):
+    """tests/cpp/feather_demo.cpp = W:241-244 + W:278-315 (gain apply, FeatherBlender 0.1, dilate 20x20 & mask, feed, blend,
+    imwrite) through include/imagestitch.hpp, .bmp files in and out, on crops of the reference's own warped tiles and
+    DP-seam masks; compared with the oracle step by step."""
+    exe = str(tmp_path / "feather_demo")
+    lib_dir = os.path.join(ROOT, "imagestitch_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "feather_demo.cpp"),
+                           "-o", exe, "-L", lib_dir, "-limagestitch_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    D = np.load(os.path.join(ROOT, "tests", "golden", "ref_inputs.npz"))
+    imgs = [D["img0"], D["img1"]]
+    seam = [D["mask0"], D["mask1"]]
+    warped = [np.where(im.sum(2) > 0, 255, 0).astype(np.uint8) for im in imgs]
+    corners = [tuple(int(v) for v in D["corner0"]), tuple(int(v) for v in D["corner1"])]
+    gains = [1.0379, 0.9624]
+    for i in range(2):
+        gpu.imwrite(str(tmp_path / ("warped%d.bmp" % i)), np.ascontiguousarray(imgs[i]))
+        gpu.imwrite(str(tmp_path / ("mask%d.bmp" % i)), warped[i])
+        gpu.imwrite(str(tmp_path / ("seam%d.bmp" % i)), np.ascontiguousarray(seam[i]))
+    out = subprocess.check_output([exe, str(tmp_path), str(corners[0][0]), str(corners[0][1]), repr(gains[0]), str(corners[1][0]), str(corners[1][1]),
+                                   repr(gains[1])], text=True)
+    assert "throws 1" in out
+    ob = oracle.Feather(0.1)
+    sizes = [(m.shape[1], m.shape[0]) for m in seam]
+    ob.prepare(corners, sizes)
+    for i in range(2):
+        comp = oracle.gain_apply(imgs[i], gains[i])
+        mk = oracle.dilate_rect(seam[i], 20, 20) & warped[i]
+        ob.feed(comp.astype(np.int16), mk, corners[i])
+    od, om = ob.blend()
+    r, c = [int(v) for v in out.split("result")[1].split()[:2]]
+    got = np.fromfile(str(tmp_path / "pano_s16.raw"), np.int16).reshape(r, c, 3)
+    assert np.array_equal(got, od)
+    assert np.array_equal(gpu.imread(str(tmp_path / "pano.bmp")), np.clip(od, 0, 255).astype(np.uint8))
+    assert np.array_equal(gpu.imread(str(tmp_path / "pano_mask.bmp"))[:, :, 0], om)
