@@ -14,7 +14,11 @@
  *     compiled verbatim into oracle/_ref/libref_warp.so (oracle/build.sh) and against the
  *     committed vectors tests/golden/cyl_maps.npz generated from it; ROI width 1086 pinned
  *     against the reference's committed images_warped_f[0].bmp.
- *   - remap, pyrDown/pyrUp, MultiBandBlender, SphericalProjector: the arithmetic lives in
+ *   - warp geometry + remap LINEAR/REFLECT + gain apply: PINNED UP TO THE TIE RULE by the reference's committed
+ *     images_warped_f[0].bmp = gain * warp(src2.bmp) (tests/golden/ref_warp_artifact.npz, tests/test_ref_artifact.py):
+ *     the artefact came from OpenCV's OpenCL remap (float blend, round-half-even); orc_remap_u8 is the CPU fixed-point
+ *     path = the same weighted sum rounded half-up, and differs from the artefact exactly at the ties.
+ *   - remap (other modes), pyrDown/pyrUp, MultiBandBlender, SphericalProjector: the arithmetic lives in
  *     OpenCV 3.4.2 (opencv_world342, README.md:23-24), which is neither vendored in
  *     /root/reference nor installed here.  These functions restate OpenCV 3.4.2's published
  *     algorithm (modules/imgproc/src/imgwarp.cpp, pyramids.cpp, modules/stitching/src/

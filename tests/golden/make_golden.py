@@ -9,6 +9,9 @@
   ref_inputs.npz     data crops of the reference's committed artefacts (mask_seam[0,1].bmp,
                      images_warped_f[0,1].bmp written by S:1195-1198): realistic warped tiles and real
                      DP-seam masks used as blend INPUTS.  Data files, not source.
+  ref_warp_artifact.npz  the one artefact of the reference whose inputs can be reconstructed: images_warped_f[0].bmp
+                     (S:1195) turns out to be warp(src2.bmp) with f = 2707.47 (W:30), c = 550.5, R = I, times the
+                     GainCompensator's gain — a crop of it with the source window it is sampled from.
   oracle_regress.npz seeded inputs -> outputs of oracle/liboracle.so for remap / pyramids /
                      MultiBandBlender / linear blend.  NOT reference-derived (OpenCV 3.4.2 is absent:
                      "parity unpinned"); it freezes the restatement so that drift is caught.
@@ -79,6 +82,29 @@ def ref_inputs():
     print("ref_inputs.npz: crops", i0[c0].shape, i1[c1].shape)
 
 
+def ref_warp_artifact():
+    from PIL import Image
+    src = np.array(Image.open(os.path.join(REF, "特征点检测", "特征点检测", "src2.bmp")).convert("RGB"))[:, :, ::-1]
+    art = np.array(Image.open(os.path.join(REF, "动态规划法寻找最佳缝合线", "动态规划法寻找最佳缝合线", "images_warped_f[0].bmp")).convert("RGB"))[:, :, ::-1]
+    f = np.float32(2707.47)
+    K = np.array([[f, 0, 550.5], [0, f, 550.5], [0, 0, 1]], np.float32)
+    R = np.eye(3, dtype=np.float32)
+    roi, _ = O.detect_roi(O.CYL, float(f), K, R, src.shape[1], src.shape[0])
+    assert (roi[2] - roi[0] + 1, roi[3] - roi[1] + 1) == (art.shape[1], art.shape[0]), (roi, art.shape)
+    oy, ox, oh, ow = 430, 470, 300, 370                     # output crop: the centre band (u = 0 at column 543) and column 799
+    k, rinv, r_kinv, k_rinv = O.camera(K, R)
+    sub = np.array([roi[0] + ox, roi[1] + oy, roi[0] + ox + ow - 1, roi[1] + oy + oh - 1], np.int32)
+    xm, ym = O.build_maps(O.CYL, float(f), k_rinv, sub)
+    sx0, sy0 = int(np.floor(xm.min())) - 2, int(np.floor(ym.min())) - 2
+    sx1, sy1 = int(np.ceil(xm.max())) + 3, int(np.ceil(ym.max())) + 3
+    assert sx0 >= 0 and sy0 >= 0 and sx1 <= src.shape[1] and sy1 <= src.shape[0]
+    np.savez_compressed(os.path.join(HERE, "ref_warp_artifact.npz"), src_window=np.ascontiguousarray(src[sy0:sy1, sx0:sx1]), src_origin=np.array([sx0, sy0]),
+                        src_size=np.array([src.shape[1], src.shape[0]]), artifact_crop=np.ascontiguousarray(art[oy:oy + oh, ox:ox + ow]),
+                        crop_origin=np.array([ox, oy]), artifact_size=np.array([art.shape[1], art.shape[0]]), focal=f, centre=np.float32(550.5),
+                        roi=roi, gain=np.float64(0.988722))
+    print("ref_warp_artifact.npz: source window", (sy1 - sy0, sx1 - sx0), "artefact crop", (oh, ow))
+
+
 def oracle_regress():
     rng = np.random.default_rng(7)
     out = {}
@@ -117,4 +143,5 @@ if __name__ == "__main__":
     cyl_maps()
     if os.path.isdir(REF):
         ref_inputs()
+        ref_warp_artifact()
     oracle_regress()
