@@ -135,6 +135,21 @@ __global__ __launch_bounds__(256) void k_warp(Proj p, MapTabs t, SrcView src, un
     for (int c = 0; c < CN; ++c) q[c] = o[c];
 }
 
+// cv::remap with the caller's CV_32FC1 maps (W:157 as a function of its own: buildMaps once, remap per frame)
+template <class T, int CN>
+__global__ __launch_bounds__(256) void k_remap(SrcView src, const unsigned char* xmap, size_t xstep, const unsigned char* ymap, size_t ystep,
+                                               unsigned char* dst, size_t dstep, int dw, int dh, int interp, int border) {
+    int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const float mx = ((const float*)(xmap + (size_t)dy * xstep))[dx], my = ((const float*)(ymap + (size_t)dy * ystep))[dx];
+    T o[CN];
+    if (interp == ISX_INTER_NEAREST) sample_nearest<T, CN>(src, mx, my, border, o);
+    else sample_linear<T, CN>(src, mx, my, border, o);
+    T* q = (T*)(dst + (size_t)dy * dstep) + (size_t)dx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) q[c] = o[c];
+}
+
 // W:229 + W:232 fused: image LINEAR / REFLECT and mask NEAREST / CONSTANT from one map evaluation.
 // OUT16: write the image as CV_16SC3 (the convertTo(CV_16S) of W:294 folded in; u8 -> s16 is exact).
 //
@@ -868,6 +883,46 @@ int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9],
                (float*)w->st_y.d.data, w->st_y.d.step, dw, dh);
     ISX_TRY(w->st_x.finish_out(st));
     ISX_TRY(w->st_y.finish_out(st));
+    return ISX_OK;
+}
+
+int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int interp, int border, isx_mat* dst, int device, void* hip_stream) {
+    clear_error();
+    ISX_TRY(check_mat(src, "remap: src"));
+    ISX_TRY(check_mat(xmap, "remap: xmap"));
+    ISX_TRY(check_mat(ymap, "remap: ymap"));
+    ISX_TRY(check_mat(dst, "remap: dst"));
+    ISX_CHECK_ARG(xmap->type == ISX_32FC1 && ymap->type == ISX_32FC1, ISX_ERR_TYPE, "remap: maps must be CV_32FC1 (W:128-129)");
+    ISX_CHECK_ARG(xmap->rows == ymap->rows && xmap->cols == ymap->cols, ISX_ERR_SIZE, "remap: xmap and ymap differ in size");
+    ISX_CHECK_ARG(dst->rows == xmap->rows && dst->cols == xmap->cols && dst->type == src->type, ISX_ERR_SIZE, "remap: dst must have the maps' size and the source's type");
+    ISX_CHECK_ARG(src->type == ISX_8UC1 || src->type == ISX_8UC3 || src->type == ISX_32FC1 || src->type == ISX_32FC3, ISX_ERR_TYPE,
+                  "remap: CV_8UC1 / CV_8UC3 / CV_32FC1 / CV_32FC3 sources are supported, got %s", type_name(src->type));
+    ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR, ISX_ERR_UNSUPPORTED, "remap: INTER_NEAREST and INTER_LINEAR are implemented");
+    ISX_CHECK_ARG(border >= ISX_BORDER_CONSTANT && border <= ISX_BORDER_REFLECT_101, ISX_ERR_UNSUPPORTED, "remap: unsupported border mode %d", border);
+    ISX_CHECK_ARG(src->cols <= 32767 && src->rows <= 32767, ISX_ERR_UNSUPPORTED, "remap: source larger than 32767 pixels per side (cv::remap's short coordinates)");
+    ISX_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    MatStage ss, sx, sy, sd;
+    ISX_TRY(ss.use_in(src, st, "remap: src"));
+    ISX_TRY(sx.use_in(xmap, st, "remap: xmap"));
+    ISX_TRY(sy.use_in(ymap, st, "remap: ymap"));
+    ISX_TRY(sd.use_out(dst, st, "remap: dst"));
+    SrcView sv{(const unsigned char*)ss.d.data, ss.d.step, src->rows, src->cols};
+    const int dw = dst->cols, dh = dst->rows;
+    dim3 grid(cdiv(dw, 64), cdiv(dh, 4));
+    const double bytes = (double)dw * dh * (8.0 + 2.0 * mat_elem_size(src->type));
+#define ISX_REMAP(T, CN)                                                                                                                     \
+    ISX_LAUNCH("remap", bytes, st, (k_remap<T, CN>), grid, dim3(256), 0, sv, (const unsigned char*)sx.d.data, sx.d.step, (const unsigned char*)sy.d.data, \
+               sy.d.step, (unsigned char*)sd.d.data, sd.d.step, dw, dh, interp, border)
+    switch (src->type) {
+        case ISX_8UC1: ISX_REMAP(unsigned char, 1); break;
+        case ISX_8UC3: ISX_REMAP(unsigned char, 3); break;
+        case ISX_32FC1: ISX_REMAP(float, 1); break;
+        default: ISX_REMAP(float, 3); break;
+    }
+#undef ISX_REMAP
+    ISX_TRY(sd.finish_out(st));
+    if (src->device < 0 || xmap->device < 0 || ymap->device < 0 || dst->device < 0) ISX_HIP(hipStreamSynchronize(st));   // staging buffers are freed on return
     return ISX_OK;
 }
 

@@ -166,3 +166,13 @@ class CylindricalWarper(_Creator):
 class SphericalWarper(_Creator):
     """cv::SphericalWarper (B:93, commented out in the reference)."""
     kind = WARP_SPHERICAL
+
+
+def remap(src, xmap, ymap, interp_mode=INTER_LINEAR, border_mode=BORDER_REFLECT, device=0, stream=None):
+    """cv::remap(src, dst, xmap, ymap, interp_mode, border_mode) (W:157) with CV_32FC1 maps -> dst (same kind as src)."""
+    shape = tuple(xmap.shape[:2]) + (tuple(src.shape[2:]) if len(src.shape) == 3 else ())
+    dst = _empty_like_kind(src, shape, str(src.dtype).replace("torch.", "") if _is_tensor(src) else src.dtype)
+    ms, mx, my, md = as_mat(src), as_mat(xmap), as_mat(ymap), as_mat(dst)
+    ptr = getattr(stream, "cuda_stream", stream)
+    check(_lib.load().isx_remap(C.byref(ms), C.byref(mx), C.byref(my), int(interp_mode), int(border_mode), C.byref(md), int(device), C.c_void_p(ptr or 0)))
+    return dst

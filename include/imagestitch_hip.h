@@ -148,6 +148,12 @@ int isx_warper_verify(isx_warper* w);
  * isx_blender_set_mark_event during blend()) has completed instead of at the stream's current position.  */
 int isx_warper_verify_after(isx_warper* w, void* hip_event);
 
+/* cv::remap(src, dst, xmap, ymap, interp_mode, border_mode) itself (W:157), for callers that keep the maps of a
+ * fixed rig (isx_warper_build_maps once, isx_remap per frame).  CV_32FC1 maps; src / dst CV_8UC1, CV_8UC3, CV_32FC1 or
+ * CV_32FC3; OpenCV's CPU arithmetic (coordinates quantised to 1/32 pixel, 15-bit fixed-point weights for 8-bit images). */
+int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int interp_mode, int border_mode,
+              isx_mat* dst, int device, void* hip_stream);
+
 /* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
 /* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
  * type: ISX_BLEND_MULTI_BAND (num_bands default in OpenCV: 5) or ISX_BLEND_FEATHER (the blender every

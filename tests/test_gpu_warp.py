@@ -102,3 +102,44 @@ def test_warp_errors(gpu):
         warper.warp(img.astype(np.int16), K, Rs[0], LINEAR, REFLECT, dst=np.zeros((5, 5, 3), np.int16))
     with pytest.raises(gpu.IsxError):
         gpu.CylindricalWarper().create(-1.0)
+
+
+@pytest.mark.parametrize("dtype,cn", [(np.uint8, 3), (np.uint8, 1), (np.float32, 3), (np.float32, 1)])
+@pytest.mark.parametrize("interp,border", [(1, 2), (0, 0), (1, 0), (1, 4), (0, 1), (1, 3)])
+def test_remap_with_caller_maps(gpu, oracle, dtype, cn, interp, border):
+    """isx_remap = cv::remap (W:157) with CV_32FC1 maps, every interpolation / border combination, host and device mats."""
+    import torch
+    rng = np.random.default_rng(cn * 10 + interp * 3 + border)
+    shape = (41, 57, 3) if cn == 3 else (41, 57)
+    src = (rng.random(shape) * 255).astype(dtype)
+    xm = (rng.random((35, 49)) * 75 - 9).astype(np.float32)
+    ym = (rng.random((35, 49)) * 55 - 7).astype(np.float32)
+    xm[0, :5] = [0.0, 56.0, 56.5, -0.5, 1e9]          # exact integers, the last column, ties, far outside
+    ym[0, :5] = [0.0, 40.0, 40.5, -0.5, -1e9]
+    ref = oracle.remap(src, xm, ym, interp, border)
+    got = gpu.remap(src, xm, ym, interp, border)
+    assert got.dtype == src.dtype and np.array_equal(got, ref)
+    got_d = gpu.remap(torch.from_numpy(src).cuda(), torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda(), interp, border)
+    assert np.array_equal(got_d.cpu().numpy(), ref)
+
+
+def test_remap_reproduces_the_references_artifact_crop(gpu, oracle):
+    """tests/golden/ref_warp_artifact.npz (see tests/test_ref_artifact.py): the HIP remap on the crop of src2.bmp equals the
+    exact bilinear sum rounded half-up, i.e. the reference's committed images_warped_f[0].bmp except at the ties."""
+    import os
+    art = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_warp_artifact.npz"))
+    f, c = float(art["focal"]), float(art["centre"])
+    K = np.array([[f, 0, c], [0, f, c], [0, 0, 1]], np.float32)
+    roi = art["roi"]
+    ox, oy = [int(v) for v in art["crop_origin"]]
+    crop = art["artifact_crop"]
+    _, _, _, k_rinv = oracle.camera(K, np.eye(3, dtype=np.float32))
+    sub = np.array([roi[0] + ox, roi[1] + oy, roi[0] + ox + crop.shape[1] - 1, roi[1] + oy + crop.shape[0] - 1], np.int32)
+    xm, ym = oracle.build_maps(oracle.CYL, f, k_rinv, sub)
+    sx0, sy0 = [int(v) for v in art["src_origin"]]
+    xm, ym = xm - np.float32(sx0), ym - np.float32(sy0)
+    got = gpu.remap(art["src_window"], xm, ym, 1, 2)
+    assert np.array_equal(got, oracle.remap(art["src_window"], xm, ym, 1, 2))
+    out = gpu.gain_apply(got.copy(), float(art["gain"]))
+    d = out.astype(int) - crop
+    assert (d != 0).mean() < 0.06 and np.abs(d).max() <= 6      # the ties of the OpenCL remap the artefact came from (4 % in this crop)
