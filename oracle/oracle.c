@@ -999,6 +999,8 @@ int orc_seam_estimate(const void* img1, int rows1, int cols1, const void* img2, 
                       int tl1x, int tl1y, int tl2x, int tl2y, int utlx, int utly,
                       const int32_t* labels, int uh, int uw, int label, int rx, int ry, int rw, int rh,
                       int p1x, int p1y, int p2x, int p2y, int* seam_xy, int cap, int* is_horizontal) {
+    if (is_horizontal) *is_horizontal = 0;
+    if (p1x < rx || p1x >= rx + rw || p1y < ry || p1y >= ry + rh || p2x < rx || p2x >= rx + rw || p2y < ry || p2y >= ry + rh) return 0;   /* tips outside the component rectangle */
     float* costV = (float*)malloc(sizeof(float) * (size_t)rh * (rw + 1));
     float* costH = (float*)malloc(sizeof(float) * (size_t)(rh + 1) * rw);
     orc_seam_costs(img1, rows1, cols1, img2, rows2, cols2, is_u8, tl1x, tl1y, tl2x, tl2y, utlx, utly, labels, uh, uw, label, rx, ry, rw, rh,

@@ -12,6 +12,10 @@
   ref_warp_artifact.npz  the one artefact of the reference whose inputs can be reconstructed: images_warped_f[0].bmp
                      (S:1195) turns out to be warp(src2.bmp) with f = 2707.47 (W:30), c = 550.5, R = I, times the
                      GainCompensator's gain — a crop of it with the source window it is sampled from.
+  ref_seam_artifact.npz  the reference's own DP seam (the boundary between its committed mask_seam[0].bmp and
+                     mask_seam[1].bmp, S:1197-1198) over 801 rows, with the crops of images_warped_f[0,1].bmp the
+                     cost maps are computed from.  The tile offset (799, -5) is the one for which the two seam masks
+                     partition the overlap exactly (and gives pano.jpg's 1895 x 1105 union).
   oracle_regress.npz seeded inputs -> outputs of oracle/liboracle.so for remap / pyramids /
                      MultiBandBlender / linear blend.  NOT reference-derived (OpenCV 3.4.2 is absent:
                      "parity unpinned"); it freezes the restatement so that drift is caught.
@@ -105,6 +109,42 @@ def ref_warp_artifact():
     print("ref_warp_artifact.npz: source window", (sy1 - sy0, sx1 - sx0), "artefact crop", (oh, ow))
 
 
+def ref_seam_artifact():
+    from PIL import Image
+    d = os.path.join(REF, "动态规划法寻找最佳缝合线", "动态规划法寻找最佳缝合线")
+    m0 = np.array(Image.open(os.path.join(d, "mask_seam[0].bmp")).convert("L"))
+    m1 = np.array(Image.open(os.path.join(d, "mask_seam[1].bmp")).convert("L"))
+    i0 = np.array(Image.open(os.path.join(d, "images_warped_f[0].bmp")).convert("RGB"))[:, :, ::-1]
+    i1 = np.array(Image.open(os.path.join(d, "images_warped_f[1].bmp")).convert("RGB"))[:, :, ::-1]
+    tl0, tl1 = (-543, -550), (-543 + 799, -550 - 5)
+    utl = (min(tl0[0], tl1[0]), min(tl0[1], tl1[1]))
+    o0, o1 = (tl0[0] - utl[0], tl0[1] - utl[1]), (tl1[0] - utl[0], tl1[1] - utl[1])
+    uw = max(o0[0] + m0.shape[1], o1[0] + m1.shape[1])
+    uh = max(o0[1] + m0.shape[0], o1[1] + m1.shape[0])
+    U0 = np.zeros((uh, uw), np.uint8); U1 = np.zeros((uh, uw), np.uint8)
+    U0[o0[1]:o0[1] + m0.shape[0], o0[0]:o0[0] + m0.shape[1]] = m0
+    U1[o1[1]:o1[1] + m1.shape[0], o1[0]:o1[0] + m1.shape[1]] = m1
+    assert not ((U0 > 0) & (U1 > 0)).any()                      # the two seam masks never overlap with this offset
+    ya, yb = 150, 950
+    seam = []
+    for y in range(ya, yb + 1):   # vertical seam: the seam pixel is the first pixel of the right-hand tile (S:1045-1052)
+        a = np.nonzero(U0[y, o1[0]:o0[0] + m0.shape[1]])[0]
+        b = np.nonzero(U1[y, o1[0]:o0[0] + m0.shape[1]])[0]
+        assert b.min() == a.max() + 1
+        seam.append((o1[0] + int(b.min()), y))
+    seam = np.array(seam, np.int32)
+    xa, xb = int(seam[:, 0].min()) - 36, int(seam[:, 0].max()) + 36
+    # image crops (union rows ya - 2 .. yb + 2, columns xa - 2 .. xb + 2) and their corners in panorama coordinates
+    cy0, cy1, cx0, cx1 = ya - 2, yb + 3, xa - 2, xb + 3
+    c0 = i0[cy0 - o0[1]:cy1 - o0[1], cx0 - o0[0]:cx1 - o0[0]]
+    c1 = i1[cy0 - o1[1]:cy1 - o1[1], cx0 - o1[0]:cx1 - o1[0]]
+    assert c0.shape == c1.shape == (cy1 - cy0, cx1 - cx0, 3)
+    np.savez_compressed(os.path.join(HERE, "ref_seam_artifact.npz"), img0=np.ascontiguousarray(c0), img1=np.ascontiguousarray(c1),
+                        crop_tl=np.array([utl[0] + cx0, utl[1] + cy0]), union_tl=np.array(utl), roi=np.array([xa, ya, xb - xa, yb - ya + 1]),
+                        seam=seam, tile_offset=np.array([799, -5]), union_size=np.array([uw, uh]))
+    print("ref_seam_artifact.npz: seam rows", ya, yb, "roi x", xa, xb, "crops", c0.shape)
+
+
 def oracle_regress():
     rng = np.random.default_rng(7)
     out = {}
@@ -144,4 +184,5 @@ if __name__ == "__main__":
     if os.path.isdir(REF):
         ref_inputs()
         ref_warp_artifact()
+        ref_seam_artifact()
     oracle_regress()

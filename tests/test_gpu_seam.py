@@ -57,3 +57,17 @@ def test_seam_errors(gpu):
     assert e.value.code == 2                               # both images must have the same supported type (S:745-746)
     with pytest.raises(gpu.IsxError):
         gpu.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], (-5, 0), c["p2"])
+
+
+def test_gpu_reproduces_the_references_dp_seam(gpu, oracle):
+    """tests/golden/ref_seam_artifact.npz: the boundary between the reference's committed mask_seam[0].bmp and
+    mask_seam[1].bmp over 801 rows, with the crops of images_warped_f[0,1].bmp it was computed from — isx_seam_estimate
+    returns exactly the reference's seam (see tests/test_ref_artifact.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ref_artifact import _seam_case
+    art = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_seam_artifact.npz"))
+    c, seam = _seam_case(art)
+    got, horiz = gpu.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p1"], c["p2"])
+    assert not horiz and np.array_equal(got, seam)

@@ -93,3 +93,39 @@ def test_gain_is_a_single_scalar(oracle, art):
     lo, hi = ((ref[m] - 0.5) / w[m]), ((ref[m] + 0.5) / w[m])
     g = float(art["gain"])
     assert (lo <= g).mean() > 0.999 and (hi >= g).mean() > 0.999
+
+
+# ---- the reference's own DP seam -------------------------------------------------------------------------------------
+def _seam_case(art):
+    """Inputs of estimateSeam (S:806-957) for the window of the reference's committed seam: CV_32F images as the demo
+    builds them (convertTo(CV_32F), S:1188-1190 / W:261), the crops standing in for the warped tiles (tile corner =
+    crop corner), a rectangular component around the seam, tips = the seam's own end points."""
+    img0 = art["img0"].astype(np.float32)
+    img1 = art["img1"].astype(np.float32)
+    tl = tuple(int(v) for v in art["crop_tl"])
+    utl = tuple(int(v) for v in art["union_tl"])
+    uw, uh = [int(v) for v in art["union_size"]]
+    roi = tuple(int(v) for v in art["roi"])
+    labels = np.zeros((uh, uw), np.int32)
+    labels[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]] = 1
+    seam = art["seam"]
+    return dict(img1=img0, img2=img1, tl1=tl, tl2=tl, union_tl=utl, labels=labels, label=1, roi=roi,
+                p1=tuple(int(v) for v in seam[0]), p2=tuple(int(v) for v in seam[-1])), seam
+
+
+@pytest.fixture(scope="module")
+def seam_art():
+    return np.load(os.path.join(HERE, "golden", "ref_seam_artifact.npz"))
+
+
+def test_oracle_reproduces_the_references_dp_seam(oracle, seam_art):
+    """mask_seam[0].bmp / mask_seam[1].bmp (S:1197-1198) are the output of the in-tree DP seam finder on
+    images_warped_f[0,1].bmp.  Their common boundary over 801 rows is the optimal path of estimateSeam's dynamic
+    programme between its own end points: computeCosts + the programme + backtracking of the oracle return exactly it."""
+    c, seam = _seam_case(seam_art)
+    got, horiz = oracle.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p1"], c["p2"])
+    assert not horiz and len(seam) == 801
+    assert np.array_equal(got, seam)
+    # the same seam from the other end (S:829-842 swaps the tips, S:947-948 restores the order)
+    back, _ = oracle.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p2"], c["p1"])
+    assert np.array_equal(back, seam[::-1])
