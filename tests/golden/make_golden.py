@@ -102,7 +102,13 @@ def ref_warp_artifact():
     sx0, sy0 = int(np.floor(xm.min())) - 2, int(np.floor(ym.min())) - 2
     sx1, sy1 = int(np.ceil(xm.max())) + 3, int(np.ceil(ym.max())) + 3
     assert sx0 >= 0 and sy0 >= 0 and sx1 <= src.shape[1] and sy1 <= src.shape[0]
-    np.savez_compressed(os.path.join(HERE, "ref_warp_artifact.npz"), src_window=np.ascontiguousarray(src[sy0:sy1, sx0:sx1]), src_origin=np.array([sx0, sy0]),
+    # mask_seam[0].bmp left of the second tile (x < 799) is the untouched warped mask of tile 0 (W:232 / S:1159: all-255 mask,
+    # INTER_NEAREST, BORDER_CONSTANT): its barrel-shaped boundary pins the nearest-neighbour path.  Rows that hold a zero:
+    ms = np.array(Image.open(os.path.join(REF, "动态规划法寻找最佳缝合线", "动态规划法寻找最佳缝合线", "mask_seam[0].bmp")).convert("L"))[:, :799]
+    zrows = np.nonzero((ms == 0).any(1))[0]
+    assert (np.delete(ms, zrows, axis=0) == 255).all()
+    np.savez_compressed(os.path.join(HERE, "ref_warp_artifact.npz"), mask_cols=np.array(799), mask_zero_rows=zrows, mask_rows=np.ascontiguousarray(ms[zrows]),
+                        src_window=np.ascontiguousarray(src[sy0:sy1, sx0:sx1]), src_origin=np.array([sx0, sy0]),
                         src_size=np.array([src.shape[1], src.shape[0]]), artifact_crop=np.ascontiguousarray(art[oy:oy + oh, ox:ox + ow]),
                         crop_origin=np.array([ox, oy]), artifact_size=np.array([art.shape[1], art.shape[0]]), focal=f, centre=np.float32(550.5),
                         roi=roi, gain=np.float64(0.988722))

@@ -143,3 +143,21 @@ def test_remap_reproduces_the_references_artifact_crop(gpu, oracle):
     out = gpu.gain_apply(got.copy(), float(art["gain"]))
     d = out.astype(int) - crop
     assert (d != 0).mean() < 0.06 and np.abs(d).max() <= 6      # the ties of the OpenCL remap the artefact came from (4 % in this crop)
+
+
+def test_warped_mask_equals_the_references_mask_artifact(gpu):
+    """mask_seam[0].bmp left of the second tile = warp(all-255 mask, INTER_NEAREST, BORDER_CONSTANT) of tile 0 (W:232):
+    the HIP warp (generic kernel and the fused image + mask kernel) reproduces its barrel-shaped boundary exactly."""
+    import os
+    art = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_warp_artifact.npz"))
+    f, c = float(art["focal"]), float(art["centre"])
+    K = np.array([[f, 0, c], [0, f, c], [0, 0, 1]], np.float32)
+    R = np.eye(3, dtype=np.float32)
+    w, h = [int(v) for v in art["src_size"]]
+    n, zr = int(art["mask_cols"]), art["mask_zero_rows"]
+    warper = gpu.CylindricalWarper().create(f)
+    corner, mk = warper.warp(np.full((h, w), 255, np.uint8), K, R, gpu.INTER_NEAREST, gpu.BORDER_CONSTANT)
+    assert tuple(corner) == (int(art["roi"][0]), int(art["roi"][1]))
+    assert np.array_equal(mk[zr, :n], art["mask_rows"]) and (np.delete(mk[:, :n], zr, axis=0) == 255).all()
+    _, _, fused = warper.warp_with_mask(np.zeros((h, w, 3), np.uint8), K, R)
+    assert np.array_equal(fused, mk)

@@ -129,3 +129,18 @@ def test_oracle_reproduces_the_references_dp_seam(oracle, seam_art):
     # the same seam from the other end (S:829-842 swaps the tips, S:947-948 restores the order)
     back, _ = oracle.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p2"], c["p1"])
     assert np.array_equal(back, seam[::-1])
+
+
+def test_oracle_reproduces_the_references_warped_mask(oracle, art):
+    """mask_seam[0].bmp left of the second tile is the untouched warp of tile 0's all-255 mask (INTER_NEAREST,
+    BORDER_CONSTANT, W:232 / S:1159): 799 x 1100 pixels, barrel-shaped boundary included, equal to the oracle's."""
+    f, c = float(art["focal"]), float(art["centre"])
+    K = np.array([[f, 0, c], [0, f, c], [0, 0, 1]], np.float32)
+    w, h = [int(v) for v in art["src_size"]]
+    corner, mk, _ = oracle.warp_u8(oracle.CYL, f, K, np.eye(3, dtype=np.float32), np.full((h, w), 255, np.uint8), oracle.NEAREST, oracle.BORDER_CONSTANT)
+    assert corner == (int(art["roi"][0]), int(art["roi"][1]))
+    n = int(art["mask_cols"])
+    zr = art["mask_zero_rows"]
+    assert np.array_equal(mk[zr, :n], art["mask_rows"])
+    assert (np.delete(mk[:, :n], zr, axis=0) == 255).all()
+    assert (art["mask_rows"] == 0).sum() > 3000          # the boundary is not trivial
