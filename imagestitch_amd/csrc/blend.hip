@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
 // ------------------------------------------------------------------------------------------------
 // Deferred mode (opt-in, isx_blender_set_deferred_level0): feed() only records the tile; blend()
 //   1. builds every tile's Gaussian chain, all tiles of a level in one launch   (k_pyr_down_multi)
-//   2. gathers + normalises the top level                                       (k_top_gather)
+//   2. gathers + normalises the top level inside the first collapse step      (top_px, TOP)
 //   3. collapses: out_{k-1} = sat(pyrUp(out_k) + norm(SUM_t cast(lap_{k-1,t} * w_{k-1,t})))
 //      where the sum over the tiles covering a pixel runs IN REGISTERS, in feed order, from
 //      lap = G_{k-1,t} - pyrUp(G_{k,t})                                         (k_collapse_gather)
@@ -627,15 +627,14 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
     pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y);
 }
 
-// top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t}))
+// top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t})) at level-L pixel (x, y); the tile rectangles of
+// ts are those of level L - sh (the first collapse step passes its fine level, sh = 1).
 template <int M>
-__global__ __launch_bounds__(256) void k_top_gather(TileSet ts, LevelBuf out) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= out.cols || y >= out.rows) return;
+__device__ __forceinline__ Px<M> top_px(const TileSet& ts, int x, int y, int sh) {
     Px<M> d; d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f;
     for (int t = 0; t < ts.n; ++t) {
-        const int lx = x - ts.x_tl[t], ly = y - ts.y_tl[t];
-        if ((unsigned)lx < (unsigned)ts.w[t] && (unsigned)ly < (unsigned)ts.h[t]) {
+        const int lx = x - (ts.x_tl[t] >> sh), ly = y - (ts.y_tl[t] >> sh);
+        if ((unsigned)lx < (unsigned)ts.coarse[t].cols && (unsigned)ly < (unsigned)ts.coarse[t].rows) {
             Px<M> g = load_px<M, false>(ts.coarse[t], lx, ly);
             if constexpr (M == M_I16) {
                 d.c0 = wrap_s16(d.c0 + f2s_x86((float)g.c0 * g.w)); d.c1 = wrap_s16(d.c1 + f2s_x86((float)g.c1 * g.w)); d.c2 = wrap_s16(d.c2 + f2s_x86((float)g.c2 * g.w));
@@ -644,13 +643,15 @@ __global__ __launch_bounds__(256) void k_top_gather(TileSet ts, LevelBuf out) {
         }
     }
     normalise<M>(d);
-    store_px<M, true>(out, x, y, d);
+    return d;
 }
 
 // FINE0: the fine level is level 0 = the caller's tiles (read through the copyMakeBorder maps) and the
 // result goes to the caller's mats (crop, mask, zero fill); otherwise fine = G_{k-1,t} and the result is
 // stored as level k-1 of the collapsed pyramid.
-template <int M, int SK, bool FINE0>
+// TOP: this is the first collapse step (k = L): out_L is not read from memory but gathered while its coarse tile is
+// staged (top_px), so the top level of the collapsed pyramid is never materialised and its launch disappears.
+template <int M, int SK, bool FINE0, bool TOP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     using WT = typename WorkT<M>::t;
     // Tiles are taken G at a time: their coarse tiles (and, in the last round, that of out_k) are staged in ONE phase —
@@ -705,7 +706,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                         const LevelBuf& c = ts.coarse[t0 + s];
                         sv[s][it] = load_px<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
                     }
-                if (with_out) sv[G][it] = load_px<M, true>(coarse_out, min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), up_row_map<M>(cy0 - 1 + ry, coarse_out.rows));
+                if (with_out) {
+                    const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
+                    if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
+                    else sv[G][it] = load_px<M, true>(coarse_out, gx, gy);
+                }
             }
         }
         if (t0 > 0) __syncthreads();     // the previous round's readers are done with ct
@@ -1278,37 +1283,31 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         // the full-size level-0 kernel is behind us: from here to the last collapse step the launches are small
         if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
     }
-    // 2. top level: gather + normalise into the collapsed pyramid's level L
+    // 2. the top level out_L = norm(SUM_t cast(G_{L,t} W_{L,t})) is gathered inside the first collapse step (TOP) while it
+    //    stages its coarse tile: no launch, no level-L buffer.
     //    (algorithmic bytes of the launches below = the traffic their own dataflow needs: every input
     //    record read once, every output written once; the destination pyramid of the eager path and of
     //    SURVEY's model does not exist here)
-    {
-        TileSet ts = base(L);
-        double bytes = (double)d[L].rows * d[L].cols * alg_d_rgb(prec);
-        for (int t = 0; t < n; ++t) {
-            ts.coarse[t] = b->tiles[t].g[L];
-            bytes += (double)ts.w[t] * ts.h[t] * alg_g(prec);
-        }
-        dim3 grid(cdiv(d[L].cols, 64), cdiv(d[L].rows, 4));
-        ISX_LAUNCH("top_gather", bytes, st, (k_top_gather<M>), grid, dim3(256), 0, ts, d[L]);
-    }
     // 3. collapse chain; each step gathers the tiles' Laplacians of its fine level in registers
     for (int k = L; k >= 1; --k) {
         TileSet ts = base(k - 1);
-        double bytes = (double)d[k].rows * d[k].cols * alg_d_rgb(prec);                      // out_k as pyrUp source
+        double bytes = k == L ? 0.0 : (double)d[k].rows * d[k].cols * alg_d_rgb(prec);      // out_k as pyrUp source (k = L: gathered from G_L)
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
             ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
+            if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;                        // + the weights of G_L
             bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
                    + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
         }
         dim3 grid(cdiv(d[k].cols, WAVE), cdiv(d[k].rows, UP_TY));
         if (k == 1) {
             bytes += (double)out.rows * out.cols * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));                  // result + mask
-            ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true>), grid, dim3(256), 0, ts, d[1], d[0], out);
+            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], out);
+            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, false>), grid, dim3(256), 0, ts, d[1], d[0], out);
         } else {
             bytes += (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec);                   // out_{k-1}
-            ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
+            if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, true>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
+            else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
         }
     }
     return ISX_OK;

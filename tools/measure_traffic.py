@@ -31,7 +31,7 @@ def short(name):
 
 
 # kernel function name -> the launch name bench.py / the library's profiler reports
-ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_roi_scan": "roi_scan", "k_top_gather": "top_gather",
+ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_roi_scan": "roi_scan",
          "k_lap_acc_all": "lap_acc_all", "k_pyr_down": None, "k_pyr_down_multi": None, "k_collapse": None}
 
 
