@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: HIP path vs the CPU oracle on random geometries (run on the GPU box).
+    python tools/fuzz_parity.py [seconds] [seed]
+Every failure prints the seed of the case so that it can be replayed; exit code = number of failing cases."""
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import imagestitch_amd as G  # noqa: E402
+from oracle import capi as O  # noqa: E402
+
+
+def rot(rng, amp):
+    a, b, c = rng.uniform(-amp, amp, 3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    return (Ry @ Rx @ Rz).astype(np.float32)
+
+
+def case_warp(rng):
+    w, h = int(rng.integers(2, 400)), int(rng.integers(2, 300))
+    f = float(rng.uniform(0.3, 3.0) * max(w, h))
+    K = np.array([[f, 0, w / 2 + rng.uniform(-3, 3)], [0, f * rng.uniform(0.9, 1.1), h / 2 + rng.uniform(-3, 3)], [0, 0, 1]], np.float32)
+    R = rot(rng, 0.5)
+    kind = int(rng.integers(0, 2))
+    cn = int(rng.choice([1, 3]))
+    src = rng.integers(0, 256, (h, w, 3) if cn == 3 else (h, w)).astype(np.uint8)
+    interp, border = int(rng.integers(0, 2)), int(rng.choice([0, 1, 2, 4]))
+    roi, _ = O.detect_roi(kind, f, K, R, w, h)
+    if (roi[2] - roi[0] + 1) * (roi[3] - roi[1] + 1) > 4_000_000 or roi[2] < roi[0] or roi[3] < roi[1]:
+        return "skip"
+    wp = (G.CylindricalWarper() if kind == 0 else G.SphericalWarper()).create(f)
+    c, d = wp.warp(src, K, R, interp, border)
+    oc, od, _ = O.warp_u8(kind, f, K, R, src, interp, border)
+    assert tuple(c) == tuple(oc), (c, oc)
+    assert np.array_equal(d, od), np.argwhere(d != od)[:3]
+    if cn == 3:
+        c2, wi, wm = wp.warp_with_mask(src, K, R)
+        _, oi, _ = O.warp_u8(kind, f, K, R, src, 1, 2)
+        _, om, _ = O.warp_u8(kind, f, K, R, np.full((h, w), 255, np.uint8), 0, 0)
+        assert np.array_equal(wi, oi) and np.array_equal(wm, om)
+
+
+def case_blend(rng):
+    n = int(rng.integers(1, 5))
+    sizes = [(int(rng.integers(1, 180)), int(rng.integers(1, 150))) for _ in range(n)]
+    corners = [(int(rng.integers(-60, 120)), int(rng.integers(-40, 90))) for _ in range(n)]
+    bands, prec = int(rng.integers(0, 7)), int(rng.integers(0, 3))
+    tiles = [(rng.integers(0, 256, (h, w, 3)).astype(np.uint8), (rng.random((h, w)) > rng.uniform(0, 0.6)).astype(np.uint8) * 255) for (w, h) in sizes]
+    deferred = bool(rng.integers(0, 2))
+    u8 = bool(rng.integers(0, 2))
+    mb = G.MultiBandBlender(False, bands, prec)
+    mb.set_deferred_level0(deferred)
+    ob = O.MultiBand(bands, prec)
+    mb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    for (img, mask), c in zip(tiles, corners):
+        if u8:
+            mb.feed_u8(img, mask, c)
+        else:
+            mb.feed(img.astype(np.int16), mask, c)
+        ob.feed(img.astype(np.int16), mask, c)
+    of32 = prec != 0 and bool(rng.integers(0, 2))
+    d, m = mb.blend(out_f32=of32)
+    od, om = ob.blend(of32)
+    assert np.array_equal(m, om)
+    assert np.array_equal(d, od), (bands, prec, deferred, np.argwhere(d != od)[:3])
+
+
+def case_feather(rng):
+    n = int(rng.integers(1, 4))
+    sizes = [(int(rng.integers(1, 200)), int(rng.integers(1, 160))) for _ in range(n)]
+    corners = [(int(rng.integers(-60, 120)), int(rng.integers(-40, 90))) for _ in range(n)]
+    sharp = float(rng.choice([0.02, 0.1, 0.5, 1.7]))
+    fb, ob = G.FeatherBlender(False, sharp), O.Feather(sharp)
+    fb.set_deferred_level0(bool(rng.integers(0, 2)))
+    fb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    keep = []
+    for (w, h), c in zip(sizes, corners):
+        img = rng.integers(-300, 600, (h, w, 3)).astype(np.int16)
+        mask = np.full((h, w), 255, np.uint8)
+        mask[rng.random((h, w)) < rng.choice([0.0, 0.002, 0.3])] = 0
+        keep.append((img, mask))
+        fb.feed(img, mask, c)
+        ob.feed(img, mask, c)
+    d, m = fb.blend()
+    od, om = ob.blend()
+    assert np.array_equal(m, om) and np.array_equal(d, od)
+
+
+def case_prep(rng):
+    h, w = int(rng.integers(1, 300)), int(rng.integers(1, 400))
+    kw, kh = int(rng.integers(1, 45)), int(rng.integers(1, 45))
+    m = (rng.random((h, w)) < rng.choice([0.001, 0.05, 0.5])).astype(np.uint8) * int(rng.integers(1, 256))
+    other = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    assert np.array_equal(G.dilate_and(m, kw, kh, other=other), O.dilate_rect(m, kw, kh) & other)
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    g = float(rng.choice([rng.uniform(0.2, 3.0), 1.0, 0.5, 2.0]))
+    assert np.array_equal(G.gain_apply(img.copy(), g), O.gain_apply(img, g))
+
+
+def case_seam(rng):
+    from seam_cases import make_case
+    try:
+        c = _seam_case(rng, make_case)
+    except AssertionError:
+        return "skip"          # the generator rejects tiles that barely overlap
+    ref, rh = O.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p1"], c["p2"])
+    got, gh = G.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p1"], c["p2"])
+    assert gh == rh and np.array_equal(got, ref)
+
+
+def _seam_case(rng, make_case):
+    return make_case(int(rng.integers(0, 1 << 30)), size1=(int(rng.integers(30, 200)), int(rng.integers(40, 260))), size2=(int(rng.integers(30, 200)), int(rng.integers(40, 260))),
+                  tl1=(int(rng.integers(-40, 0)), int(rng.integers(-10, 10))), tl2=(int(rng.integers(0, 30)), int(rng.integers(-10, 10))), u8=bool(rng.integers(0, 2)),
+                  horizontal=bool(rng.integers(0, 2)), swap=bool(rng.integers(0, 2)), holes=bool(rng.integers(0, 2)))
+
+
+def case_blend_float_and_many(rng):
+    """CV_32FC3 feeds in the float precisions, CV_8UC3 / CV_32FC3 outputs, up to 11 tiles (beyond one Cover / one TileSet)."""
+    n = int(rng.integers(1, 12))
+    sizes = [(int(rng.integers(2, 90)), int(rng.integers(2, 80))) for _ in range(n)]
+    corners = [(int(rng.integers(-30, 200)), int(rng.integers(-30, 120))) for _ in range(n)]
+    bands, prec = int(rng.integers(0, 6)), int(rng.integers(1, 3))
+    mb = G.MultiBandBlender(False, bands, prec)
+    mb.set_deferred_level0(bool(rng.integers(0, 2)))
+    ob = O.MultiBand(bands, prec)
+    mb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    for (w, h), c in zip(sizes, corners):
+        img = (rng.random((h, w, 3)) * 300 - 20).astype(np.float32)
+        mask = (rng.random((h, w)) > 0.2).astype(np.uint8) * 255
+        mb.feed(img, mask, c)
+        ob.feed(img, mask, c)
+    d, m = mb.blend(out_f32=True)
+    od, om = ob.blend(True)
+    assert np.array_equal(m, om) and np.array_equal(d, od), (n, bands, prec, np.argwhere(d != od)[:3])
+
+
+def case_pipeline(rng):
+    """PairStitcher: planned step (ROI verified on the device, scans scheduled inside blend) == host-synchronous step == oracle."""
+    import torch
+    from imagestitch_amd import synth
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H = int(rng.integers(200, 900)), int(rng.integers(150, 600))
+    F = float(rng.uniform(0.6, 1.5) * W)
+    K, Rs = synth.camera_pair(W, H, F, yaw=float(rng.uniform(0.1, 0.35)))
+    imgs = [rng.integers(0, 256, (H, W, 3)).astype(np.uint8) for _ in range(2)]
+    bands, prec = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+    t = [torch.from_numpy(a).cuda() for a in imgs]
+    ps = PairStitcher(t, K, Rs, F, "cylindrical", bands, prec, 0, None, "int16", verify_at=int(rng.integers(-1, 4)))
+    a, am = [x.clone() for x in ps.step()]
+    a2, am2 = [x.clone() for x in ps.step()]
+    b, bm = ps.step_sync()
+    assert ps.check_plan() == 0
+    assert torch.equal(a, b) and torch.equal(am, bm) and torch.equal(a2, b)
+    corners, warped, seam = [], [], [s.cpu().numpy() for s in ps.seam]
+    for i in range(2):
+        c, wi, _ = O.warp_u8(O.CYL, F, K, Rs[i], imgs[i], 1, 2)
+        corners.append(c); warped.append(wi)
+    ob = O.MultiBand(bands, prec)
+    ob.prepare(corners, [(w.shape[1], w.shape[0]) for w in warped])
+    for i in range(2):
+        ob.feed(warped[i].astype(np.int16), seam[i], corners[i])
+    od, om = ob.blend(False)
+    assert np.array_equal(b.cpu().numpy(), od) and np.array_equal(bm.cpu().numpy(), om)
+
+
+CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    G.load()
+    t0, n, bad, skipped = time.time(), 0, 0, 0
+    counts = {f.__name__: 0 for f in CASES}
+    while time.time() - t0 < budget:
+        fn = CASES[n % len(CASES)]
+        seed = seed0 * 1000003 + n
+        try:
+            r = fn(np.random.default_rng(seed))
+            skipped += r == "skip"
+            counts[fn.__name__] += 1
+        except AssertionError:
+            bad += 1
+            print("FAIL", fn.__name__, "seed", seed)
+            traceback.print_exc(limit=2)
+        except Exception as e:   # geometry the reference itself rejects must be rejected the same way on both sides
+            try:
+                code = getattr(e, "code", None)
+            except Exception:
+                code = None
+            print("EXC ", fn.__name__, "seed", seed, type(e).__name__, code, str(e)[:120])
+            bad += 1
+        n += 1
+    print("cases", n, counts, "skipped", skipped, "failures", bad, "in %.0f s" % (time.time() - t0))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(min(main(), 100))
