@@ -5,7 +5,7 @@ The package is a thin host-side mirror of the reference's call surface
 imagestitch_amd/csrc/libimagestitch_hip.so (include/imagestitch_hip.h).  No CPU fallback exists.
 """
 from ._lib import (BORDER_CONSTANT, BORDER_REFLECT, BORDER_REFLECT_101, BORDER_REPLICATE, INTER_LINEAR,  # noqa: F401
-                   INTER_NEAREST, PREC_F16ACC32, PREC_F32, PREC_I16, IsxError, load)
+                   INTER_NEAREST, INTER_TIES_EVEN, PREC_F16ACC32, PREC_F32, PREC_I16, IsxError, load)
 from .blender import Blender, FeatherBlender, MultiBandBlender, dilate_and, gain_apply  # noqa: F401
 from .imgio import imread, imwrite  # noqa: F401
 from .seam import seam_estimate  # noqa: F401

@@ -84,7 +84,7 @@ __device__ __forceinline__ void sample_nearest(const SrcView& s, float mx, float
 // cv::remap, INTER_LINEAR: coordinates quantised to 1/32 px (cvRound(x*32)), taps through
 // borderInterpolate; u8 uses the 15-bit fixed-point table, f32 the float table.
 template <class T, int CN>
-__device__ __forceinline__ void sample_linear(const SrcView& s, float mx, float my, int border, T* out) {
+__device__ __forceinline__ void sample_linear(const SrcView& s, float mx, float my, int border, T* out, bool ties_even = false) {
     int isx = cvround_x86(mx * 32.f), isy = cvround_x86(my * 32.f);
     int fx = isx & 31, fy = isy & 31;
     int sx = clamp_short(isx >> 5), sy = clamp_short(isy >> 5);
@@ -106,7 +106,11 @@ __device__ __forceinline__ void sample_linear(const SrcView& s, float mx, float 
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
             int v0 = ok00 ? r0[o0 + c] : 0, v1 = ok01 ? r0[o1 + c] : 0, v2 = ok10 ? r1[o0 + c] : 0, v3 = ok11 ? r1[o1 + c] : 0;
-            out[c] = (T)sat_u8((v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15);
+            const int sum = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+            int r = (sum + (1 << 14)) >> 15;                               // FixedPtCast: round half up (OpenCV's CPU remap)
+            // ISX_INTER_TIES_EVEN: the same sum as OpenCV's OpenCL (UMat) remap rounds it — half to even
+            if (ties_even) r = (fx | fy) == 0 ? v0 : r - (((sum & 32767) == (1 << 14)) & (r & 1));
+            out[c] = (T)sat_u8(r);
         }
     } else {
         float ax1 = fx * (1.f / 32.f), ax0 = 1.f - ax1, ay1 = fy * (1.f / 32.f), ay0 = 1.f - ay1;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void k_warp(Proj p, MapTabs t, SrcView src, un
     map_backward(p, t, dx, dy, mx, my);
     T o[CN];
     if (interp == ISX_INTER_NEAREST) sample_nearest<T, CN>(src, mx, my, border, o);
-    else sample_linear<T, CN>(src, mx, my, border, o);
+    else sample_linear<T, CN>(src, mx, my, border, o, (interp & ISX_INTER_TIES_EVEN) != 0);
     T* q = (T*)(dst + (size_t)dy * dstep) + (size_t)dx * CN;
 #pragma unroll
     for (int c = 0; c < CN; ++c) q[c] = o[c];
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void k_remap(SrcView src, const unsigned char*
     const float mx = ((const float*)(xmap + (size_t)dy * xstep))[dx], my = ((const float*)(ymap + (size_t)dy * ystep))[dx];
     T o[CN];
     if (interp == ISX_INTER_NEAREST) sample_nearest<T, CN>(src, mx, my, border, o);
-    else sample_linear<T, CN>(src, mx, my, border, o);
+    else sample_linear<T, CN>(src, mx, my, border, o, (interp & ISX_INTER_TIES_EVEN) != 0);
     T* q = (T*)(dst + (size_t)dy * dstep) + (size_t)dx * CN;
 #pragma unroll
     for (int c = 0; c < CN; ++c) q[c] = o[c];
@@ -789,7 +793,8 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         }
     } else {
         ISX_CHECK_ARG(dst->type == src->type, ISX_ERR_TYPE, "warp: dst type %s differs from src type %s", type_name(dst->type), type_name(src->type));
-        ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR, ISX_ERR_UNSUPPORTED, "warp: interpolation %d (only NEAREST and LINEAR)", interp);
+        ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR || interp == (ISX_INTER_LINEAR | ISX_INTER_TIES_EVEN), ISX_ERR_UNSUPPORTED,
+                      "warp: interpolation %d (only NEAREST and LINEAR)", interp);
         ISX_CHECK_ARG(border >= ISX_BORDER_CONSTANT && border <= ISX_BORDER_REFLECT_101, ISX_ERR_UNSUPPORTED, "warp: border mode %d", border);
         double bytes = (spx + dpx) * mat_elem_size(src->type);
         unsigned char* dp = (unsigned char*)w->st_dst.d.data;
@@ -897,7 +902,8 @@ int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int 
     ISX_CHECK_ARG(dst->rows == xmap->rows && dst->cols == xmap->cols && dst->type == src->type, ISX_ERR_SIZE, "remap: dst must have the maps' size and the source's type");
     ISX_CHECK_ARG(src->type == ISX_8UC1 || src->type == ISX_8UC3 || src->type == ISX_32FC1 || src->type == ISX_32FC3, ISX_ERR_TYPE,
                   "remap: CV_8UC1 / CV_8UC3 / CV_32FC1 / CV_32FC3 sources are supported, got %s", type_name(src->type));
-    ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR, ISX_ERR_UNSUPPORTED, "remap: INTER_NEAREST and INTER_LINEAR are implemented");
+    ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR || interp == (ISX_INTER_LINEAR | ISX_INTER_TIES_EVEN), ISX_ERR_UNSUPPORTED,
+                  "remap: INTER_NEAREST and INTER_LINEAR are implemented");
     ISX_CHECK_ARG(border >= ISX_BORDER_CONSTANT && border <= ISX_BORDER_REFLECT_101, ISX_ERR_UNSUPPORTED, "remap: unsupported border mode %d", border);
     ISX_CHECK_ARG(src->cols <= 32767 && src->rows <= 32767, ISX_ERR_UNSUPPORTED, "remap: source larger than 32767 pixels per side (cv::remap's short coordinates)");
     ISX_HIP(hipSetDevice(device));

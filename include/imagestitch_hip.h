@@ -55,7 +55,11 @@ enum {
 };
 
 /* cv::InterpolationFlags / cv::BorderTypes values used by W:229,232 */
-enum { ISX_INTER_NEAREST = 0, ISX_INTER_LINEAR = 1 };
+enum { ISX_INTER_NEAREST = 0, ISX_INTER_LINEAR = 1,
+       /* not an OpenCV flag: OR it to ISX_INTER_LINEAR in isx_warper_warp / isx_remap to round the 8-bit bilinear sum half to
+        * EVEN, as OpenCV's OpenCL (UMat / T-API) remap does — the arithmetic the reference's committed images_warped_f[0].bmp
+        * was produced with.  Default (OpenCV's CPU remap, the reference CPU path): half up.                         */
+       ISX_INTER_TIES_EVEN = 0x100 };
 enum { ISX_BORDER_CONSTANT = 0, ISX_BORDER_REPLICATE = 1, ISX_BORDER_REFLECT = 2,
        ISX_BORDER_WRAP = 3, ISX_BORDER_REFLECT_101 = 4 };
 

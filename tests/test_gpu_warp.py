@@ -161,3 +161,44 @@ def test_warped_mask_equals_the_references_mask_artifact(gpu):
     assert np.array_equal(mk[zr, :n], art["mask_rows"]) and (np.delete(mk[:, :n], zr, axis=0) == 255).all()
     _, _, fused = warper.warp_with_mask(np.zeros((h, w, 3), np.uint8), K, R)
     assert np.array_equal(fused, mk)
+
+
+def _exact_bilinear(src, xm, ym):
+    x0, y0 = np.floor(xm).astype(np.int64), np.floor(ym).astype(np.int64)
+    ux = (np.rint((xm - np.floor(xm)) * np.float32(32)) / 32.0).astype(np.float64)[..., None]
+    uy = (np.rint((ym - np.floor(ym)) * np.float32(32)) / 32.0).astype(np.float64)[..., None]
+    p = lambda yy, xx: src[yy, xx].astype(np.float64)
+    return p(y0, x0) * (1 - ux) * (1 - uy) + p(y0, x0 + 1) * ux * (1 - uy) + p(y0 + 1, x0) * (1 - ux) * uy + p(y0 + 1, x0 + 1) * ux * uy
+
+
+def test_remap_ties_even_is_the_opencl_variant_and_matches_the_artifact(gpu):
+    """ISX_INTER_LINEAR | ISX_INTER_TIES_EVEN rounds the same bilinear sum half to even — OpenCV's OpenCL (UMat) remap, the
+    arithmetic the reference's committed images_warped_f[0].bmp was produced with: on the artefact crop warp + gain then
+    agree with the bitmap except for 0.05 % of the values (device sin / cos ulps of the author's GPU)."""
+    import os
+    rng = np.random.default_rng(77)
+    src = rng.integers(0, 256, (60, 80, 3)).astype(np.uint8)
+    xm = (rng.random((50, 70)) * 76 + 1).astype(np.float32)
+    ym = (rng.random((50, 70)) * 56 + 1).astype(np.float32)
+    xm[:10] = np.floor(xm[:10]) + np.float32(0.5)          # plenty of exact ties
+    ym[:10] = np.floor(ym[:10]) + np.float32(0.5)
+    exact = _exact_bilinear(src, xm, ym)
+    even = gpu.remap(src, xm, ym, gpu.INTER_LINEAR | gpu.INTER_TIES_EVEN, gpu.BORDER_REFLECT)
+    up = gpu.remap(src, xm, ym, gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
+    assert np.array_equal(even, np.rint(exact).astype(np.uint8)) and np.array_equal(up, np.floor(exact + 0.5).astype(np.uint8))
+    assert (even != up).mean() > 0.01
+    art = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_warp_artifact.npz"))
+    # maps of the crop from the HIP buildMaps of the reference geometry (f = 2707.47, c = 550.5, R = I)
+    f, c = float(art["focal"]), float(art["centre"])
+    K = np.array([[f, 0, c], [0, f, c], [0, 0, 1]], np.float32)
+    w, h = [int(v) for v in art["src_size"]]
+    roi, xmap, ymap = gpu.CylindricalWarper().create(f).buildMaps((w, h), K, np.eye(3, dtype=np.float32))
+    ox, oy = [int(v) for v in art["crop_origin"]]
+    crop = art["artifact_crop"]
+    sx0, sy0 = [int(v) for v in art["src_origin"]]
+    xm = np.ascontiguousarray(xmap[oy:oy + crop.shape[0], ox:ox + crop.shape[1]]) - np.float32(sx0)
+    ym = np.ascontiguousarray(ymap[oy:oy + crop.shape[0], ox:ox + crop.shape[1]]) - np.float32(sy0)
+    got = gpu.remap(art["src_window"], xm, ym, gpu.INTER_LINEAR | gpu.INTER_TIES_EVEN, gpu.BORDER_REFLECT)
+    out = gpu.gain_apply(got, float(art["gain"]))
+    d = out.astype(int) - crop
+    assert (d != 0).mean() < 1e-3 and np.abs(d).max() <= 6
