@@ -16,6 +16,11 @@
                      mask_seam[1].bmp, S:1197-1198) over 801 rows, with the crops of images_warped_f[0,1].bmp the
                      cost maps are computed from.  The tile offset (799, -5) is the one for which the two seam masks
                      partition the overlap exactly (and gives pano.jpg's 1895 x 1105 union).
+  ref_dpseam_artifact.npz  inputs and outputs of the reference's whole DP seam finder run (S:1192 `find`): the overlap strips of
+                     images_warped_f[0,1].bmp (the only pixels its cost maps read), the warped masks that went in (tile 0:
+                     the warp of an all-255 mask; tile 1: reconstructed — its part outside the overlap is untouched in
+                     mask_seam[1].bmp, inside the overlap every pixel ended up in one of the two seam masks) and the
+                     committed mask_seam[0,1].bmp that came out.
   oracle_regress.npz seeded inputs -> outputs of oracle/liboracle.so for remap / pyramids /
                      MultiBandBlender / linear blend.  NOT reference-derived (OpenCV 3.4.2 is absent:
                      "parity unpinned"); it freezes the restatement so that drift is caught.
@@ -151,6 +156,30 @@ def ref_seam_artifact():
     print("ref_seam_artifact.npz: seam rows", ya, yb, "roi x", xa, xb, "crops", c0.shape)
 
 
+def ref_dpseam_artifact():
+    from PIL import Image
+    d = os.path.join(REF, "动态规划法寻找最佳缝合线", "动态规划法寻找最佳缝合线")
+    m0 = np.array(Image.open(os.path.join(d, "mask_seam[0].bmp")).convert("L"))
+    m1 = np.array(Image.open(os.path.join(d, "mask_seam[1].bmp")).convert("L"))
+    i0 = np.array(Image.open(os.path.join(d, "images_warped_f[0].bmp")).convert("RGB"))[:, :, ::-1]
+    i1 = np.array(Image.open(os.path.join(d, "images_warped_f[1].bmp")).convert("RGB"))[:, :, ::-1]
+    dx, dy = 799, -5
+    f = np.float32(2707.47)
+    K = np.array([[f, 0, 550.5], [0, f, 550.5], [0, 0, 1]], np.float32)
+    _, mk0, _ = O.warp_u8(O.CYL, float(f), K, np.eye(3, dtype=np.float32), np.full((1101, 1101), 255, np.uint8), O.NEAREST, O.BORDER_CONSTANT)
+    ow = m0.shape[1] - dx                                       # overlap width: tile-0 columns [dx, W0) = tile-1 columns [0, ow)
+    mk1 = m1.copy()
+    for y1 in range(m1.shape[0]):
+        y0 = y1 + dy
+        if 0 <= y0 < m0.shape[0]:
+            mk1[y1, :ow] = np.where((m0[y0, dx:] > 0) | (m1[y1, :ow] > 0), 255, 0)
+    np.savez_compressed(os.path.join(HERE, "ref_dpseam_artifact.npz"), strip0=np.ascontiguousarray(i0[:, dx:]), strip1=np.ascontiguousarray(i1[:, :ow]),
+                        shape0=np.array(i0.shape), shape1=np.array(i1.shape), tl0=np.array([-543, -550]), tl1=np.array([-543 + dx, -550 + dy]),
+                        mask_in0=np.packbits(mk0 > 0, axis=1), mask_in1=np.packbits(mk1 > 0, axis=1),
+                        mask_out0=np.packbits(m0 > 0, axis=1), mask_out1=np.packbits(m1 > 0, axis=1))
+    print("ref_dpseam_artifact.npz: overlap strips", i0[:, dx:].shape, i1[:, :ow].shape)
+
+
 def oracle_regress():
     rng = np.random.default_rng(7)
     out = {}
@@ -191,4 +220,5 @@ if __name__ == "__main__":
         ref_inputs()
         ref_warp_artifact()
         ref_seam_artifact()
+        ref_dpseam_artifact()
     oracle_regress()

@@ -144,3 +144,31 @@ def test_oracle_reproduces_the_references_warped_mask(oracle, art):
     assert np.array_equal(mk[zr, :n], art["mask_rows"])
     assert (np.delete(mk[:, :n], zr, axis=0) == 255).all()
     assert (art["mask_rows"] == 0).sum() > 3000          # the boundary is not trivial
+
+
+# ---- the reference's whole DP seam finder run ------------------------------------------------------------------------
+def dpseam_case(path=None):
+    """Inputs / outputs of the reference's `find(images_warped_f, corners, masks_seam)` (S:1192) from
+    tests/golden/ref_dpseam_artifact.npz: full-size CV_32FC3 images (zero outside the overlap strips — nothing else is
+    read), corners, the masks that went in and the committed mask_seam[0,1].bmp that came out."""
+    a = np.load(path or os.path.join(HERE, "golden", "ref_dpseam_artifact.npz"))
+    s0, s1 = tuple(int(v) for v in a["shape0"]), tuple(int(v) for v in a["shape1"])
+    i0, i1 = np.zeros(s0, np.float32), np.zeros(s1, np.float32)
+    ow = a["strip0"].shape[1]
+    i0[:, s0[1] - ow:] = a["strip0"]
+    i1[:, :ow] = a["strip1"]
+    unpack = lambda k, s: (np.unpackbits(a[k], axis=1)[:, :s[1]] * 255).astype(np.uint8)
+    return dict(images=[i0, i1], corners=[tuple(int(v) for v in a["tl0"]), tuple(int(v) for v in a["tl1"])],
+                masks_in=[unpack("mask_in0", s0), unpack("mask_in1", s1)], masks_out=[unpack("mask_out0", s0), unpack("mask_out1", s1)])
+
+
+def test_oracle_reproduces_the_references_seam_masks():
+    """The whole in-tree DP seam finder (S:87-1093) restated in oracle/dpseam_np.py turns the masks that went in into
+    exactly the reference's committed mask_seam[0].bmp and mask_seam[1].bmp — every one of the 1086 x 1100 and
+    1096 x 1102 pixels."""
+    from oracle.dpseam_np import DpSeamFinder
+    c = dpseam_case()
+    masks = [m.copy() for m in c["masks_in"]]
+    DpSeamFinder().find(c["images"], c["corners"], masks)
+    assert np.array_equal(masks[0], c["masks_out"][0]) and np.array_equal(masks[1], c["masks_out"][1])
+    assert (masks[0] != c["masks_in"][0]).sum() > 100000 and (masks[1] != c["masks_in"][1]).sum() > 50000      # it did cut both
