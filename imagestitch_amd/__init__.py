@@ -8,7 +8,7 @@ from ._lib import (BORDER_CONSTANT, BORDER_REFLECT, BORDER_REFLECT_101, BORDER_R
                    INTER_NEAREST, INTER_TIES_EVEN, PREC_F16ACC32, PREC_F32, PREC_I16, IsxError, load)
 from .blender import Blender, FeatherBlender, MultiBandBlender, dilate_and, gain_apply  # noqa: F401
 from .imgio import imread, imwrite  # noqa: F401
-from .seam import seam_estimate  # noqa: F401
+from .seam import DpSeamFinder, seam_estimate  # noqa: F401
 from .warper import CylindricalWarper, RotationWarper, SphericalWarper, remap  # noqa: F401
 
-__all__ = ["Blender", "MultiBandBlender", "FeatherBlender", "dilate_and", "gain_apply", "imread", "imwrite", "seam_estimate", "remap", "CylindricalWarper", "SphericalWarper", "RotationWarper", "IsxError", "load"]
+__all__ = ["Blender", "MultiBandBlender", "FeatherBlender", "dilate_and", "gain_apply", "imread", "imwrite", "seam_estimate", "DpSeamFinder", "remap", "CylindricalWarper", "SphericalWarper", "RotationWarper", "IsxError", "load"]

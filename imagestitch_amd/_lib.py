@@ -72,6 +72,7 @@ _SIGS = {
     "isx_gain_apply": [_MP, C.c_double, C.c_int, C.c_void_p],
     "isx_seam_estimate": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _MP, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                           C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p],
+    "isx_dp_seam_find": [C.c_int, _MP, C.POINTER(C.c_int), _MP, C.c_int, C.c_void_p],
     "isx_bmp_size": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "isx_bmp_read": [C.c_char_p, _MP],
     "isx_bmp_write": [C.c_char_p, _MP],

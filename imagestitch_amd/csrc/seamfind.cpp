@@ -1,0 +1,385 @@
+// seamfind.cpp — SURVEY §8(f) N1: the reference's in-tree DP seam finder as a whole
+// (S = 动态规划法寻找最佳缝合线/.../动态规划法寻找最佳缝合线.cpp, itself a restatement of cv::detail::DpSeamFinder, costFunc_ COLOR):
+//   find S:87-124 -> process S:127-193 -> findComponents S:196-308, findEdges S:311-392, resolveConflicts S:395-546
+//   (hasOnlyOneNeighbor S:574-582, getSeamTips S:607-706 with closeToContour S:585-604 and cv::partition,
+//   estimateSeam S:806-957, updateLabelsUsingSeam S:960-1093).
+// The component / contour / graph logic is sequential host code over union-sized label images (a few MB); the cost
+// maps and the dynamic programme of every estimateSeam call run on the GPU (isx_seam_estimate, seam.hip) straight from
+// the caller's images — device-resident images are never copied.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "isx_internal.hpp"
+
+using namespace isx;
+
+namespace {
+
+struct Pt { int x, y; };
+enum { FIRST = 1, SECOND = 2, INTERS = 4 };
+
+// cv::floodFill(image, seed, newVal) with the default flags: 4-connectivity, zero tolerance
+void flood_fill(std::vector<int>& img, int w, int h, int sx, int sy, int newval) {
+    const int old = img[(size_t)sy * w + sx];
+    if (old == newval) return;
+    std::vector<Pt> stack;
+    stack.push_back({sx, sy});
+    img[(size_t)sy * w + sx] = newval;
+    while (!stack.empty()) {
+        const Pt p = stack.back();
+        stack.pop_back();
+        const int nx[4] = {p.x - 1, p.x + 1, p.x, p.x}, ny[4] = {p.y, p.y, p.y - 1, p.y + 1};
+        for (int k = 0; k < 4; ++k)
+            if (nx[k] >= 0 && nx[k] < w && ny[k] >= 0 && ny[k] < h && img[(size_t)ny[k] * w + nx[k]] == old) {
+                img[(size_t)ny[k] * w + nx[k]] = newval;
+                stack.push_back({nx[k], ny[k]});
+            }
+    }
+}
+
+struct Finder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int utlx = 0, utly = 0, uw = 0, uh = 0;
+    std::vector<unsigned char> mask1_, mask2_, contour1mask_, contour2mask_;
+    int ncomps = 0;
+    std::vector<int> labels;
+    std::vector<int> states;
+    std::vector<Pt> tls, brs;
+    std::vector<std::vector<Pt>> contours;
+    std::set<std::pair<int, int>> edges;
+
+    int L(int y, int x) const { return labels[(size_t)y * uw + x]; }
+    bool on_contour(int y, int x, int l) const {   // S:249-253
+        return (x == 0 || L(y, x - 1) != l) || (x == uw - 1 || L(y, x + 1) != l) || (y == 0 || L(y - 1, x) != l) || (y == uh - 1 || L(y + 1, x) != l);
+    }
+
+    void contour_mask(const std::vector<unsigned char>& m, std::vector<unsigned char>& c) const {   // S:168-186
+        c.assign((size_t)uw * uh, 0);
+        for (int y = 0; y < uh; ++y)
+            for (int x = 0; x < uw; ++x)
+                if (m[(size_t)y * uw + x] && ((x == 0 || !m[(size_t)y * uw + x - 1]) || (x == uw - 1 || !m[(size_t)y * uw + x + 1]) ||
+                                              (y == 0 || !m[(size_t)(y - 1) * uw + x]) || (y == uh - 1 || !m[(size_t)(y + 1) * uw + x])))
+                    c[(size_t)y * uw + x] = 255;
+    }
+
+    void find_components() {   // S:196-308
+        ncomps = 0;
+        labels.assign((size_t)uw * uh, 0);
+        states.clear(); tls.clear(); brs.clear(); contours.clear();
+        for (size_t i = 0; i < labels.size(); ++i)
+            labels[i] = (mask1_[i] && mask2_[i]) ? INT_MAX : (mask1_[i] ? INT_MAX - 1 : (mask2_[i] ? INT_MAX - 2 : 0));
+        for (int y = 0; y < uh; ++y)
+            for (int x = 0; x < uw; ++x) {
+                const int v = L(y, x);
+                if (v >= INT_MAX - 2) {
+                    states.push_back(v == INT_MAX ? INTERS : (v == INT_MAX - 1 ? FIRST : SECOND));
+                    flood_fill(labels, uw, uh, x, y, ++ncomps);
+                    tls.push_back({x, y}); brs.push_back({x + 1, y + 1});
+                    contours.emplace_back();
+                }
+                const int l = L(y, x);
+                if (l) {
+                    const int ci = l - 1;
+                    tls[ci].x = std::min(tls[ci].x, x); tls[ci].y = std::min(tls[ci].y, y);
+                    brs[ci].x = std::max(brs[ci].x, x + 1); brs[ci].y = std::max(brs[ci].y, y + 1);
+                    // the reference tests the neighbours while later components still carry their class codes: a neighbour
+                    // "!= l" either way
+                    if (on_contour(y, x, l)) contours[ci].push_back({x, y});
+                }
+            }
+    }
+
+    void find_edges() {   // S:311-392
+        std::map<std::pair<int, int>, int> wedges;
+        for (int ci = 0; ci < ncomps; ++ci)
+            for (const Pt& p : contours[ci]) {
+                const int x = p.x, y = p.y, l = ci + 1;
+                const int nb[4] = {x > 0 ? L(y, x - 1) : 0, y > 0 ? L(y - 1, x) : 0, x < uw - 1 ? L(y, x + 1) : 0, y < uh - 1 ? L(y + 1, x) : 0};
+                for (int k = 0; k < 4; ++k)
+                    if (nb[k] && nb[k] != l) { wedges[{ci, nb[k] - 1}]++; wedges[{nb[k] - 1, ci}]++; }
+            }
+        edges.clear();
+        for (const auto& e : wedges)
+            if (e.second > 0) edges.insert(e.first);
+    }
+
+    bool has_only_one_neighbor(int comp) const {   // S:574-582
+        auto b = edges.lower_bound({comp, INT_MIN});
+        auto e = edges.upper_bound({comp, INT_MAX});
+        return b != e && std::next(b) == e;
+    }
+
+    bool close_to_contour(int y, int x, const std::vector<unsigned char>& cm) const {   // S:585-604
+        for (int dy = -2; dy <= 2; ++dy)
+            if (y + dy >= 0 && y + dy < uh)
+                for (int dx = -2; dx <= 2; ++dx)
+                    if (x + dx >= 0 && x + dx < uw && cm[(size_t)(y + dy) * uw + x + dx]) return true;
+        return false;
+    }
+
+    // cv::partition(points, labels, ClosePoints(10)) S:44-57,629: classes numbered by their first member
+    static std::vector<int> partition(const std::vector<Pt>& pts, int min_dist) {
+        const int n = (int)pts.size();
+        std::vector<int> parent(n), out(n), cls(n, -1);
+        for (int i = 0; i < n; ++i) parent[i] = i;
+        auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const int d2 = (pts[i].x - pts[j].x) * (pts[i].x - pts[j].x) + (pts[i].y - pts[j].y) * (pts[i].y - pts[j].y);
+                if (d2 < min_dist * min_dist) { const int a = find(i), b = find(j); if (a != b) parent[b] = a; }
+            }
+        int nc = 0;
+        for (int i = 0; i < n; ++i) { const int r = find(i); if (cls[r] < 0) cls[r] = nc++; out[i] = cls[r]; }
+        return out;
+    }
+
+    bool get_seam_tips(int comp1, int comp2, Pt& p1, Pt& p2) const {   // S:607-706
+        const int l2 = comp2 + 1;
+        std::vector<Pt> special;
+        for (const Pt& p : contours[comp1]) {
+            const int x = p.x, y = p.y;
+            if (close_to_contour(y, x, contour1mask_) && close_to_contour(y, x, contour2mask_) &&
+                ((x > 0 && L(y, x - 1) == l2) || (y > 0 && L(y - 1, x) == l2) || (x < uw - 1 && L(y, x + 1) == l2) || (y < uh - 1 && L(y + 1, x) == l2)))
+                special.push_back(p);
+        }
+        if (special.size() < 2) return false;
+        const std::vector<int> lab = partition(special, 10);
+        const int nlabels = *std::max_element(lab.begin(), lab.end()) + 1;
+        if (nlabels < 2) return false;
+        std::vector<long long> sx(nlabels, 0), sy(nlabels, 0);
+        std::vector<std::vector<Pt>> pts(nlabels);
+        for (size_t i = 0; i < special.size(); ++i) { sx[lab[i]] += special[i].x; sy[lab[i]] += special[i].y; pts[lab[i]].push_back(special[i]); }
+        auto rnd = [](double v) { return std::nearbyint(v); };   // cvRound(double)
+        int idx[2] = {-1, -1};
+        double max_dist = -1.7976931348623157e308;
+        for (int i = 0; i < nlabels - 1; ++i)
+            for (int j = i + 1; j < nlabels; ++j) {
+                const double s1 = (double)pts[i].size(), s2 = (double)pts[j].size();
+                const double cx1 = rnd(sx[i] / s1), cy1 = rnd(sy[i] / s1), cx2 = rnd(sx[j] / s2), cy2 = rnd(sy[j] / s2);
+                const double dist = (cx1 - cx2) * (cx1 - cx2) + (cy1 - cy2) * (cy1 - cy2);
+                if (dist > max_dist) { max_dist = dist; idx[0] = i; idx[1] = j; }
+            }
+        Pt p[2];
+        for (int i = 0; i < 2; ++i) {
+            const std::vector<Pt>& g = pts[idx[i]];
+            const double size = (double)g.size(), cx = rnd(sx[idx[i]] / size), cy = rnd(sy[idx[i]] / size);
+            size_t closest = g.size();
+            double min_dist = 1.7976931348623157e308;
+            for (size_t j = 0; j < g.size(); ++j) {
+                const double dist = (g[j].x - cx) * (g[j].x - cx) + (g[j].y - cy) * (g[j].y - cy);
+                if (dist < min_dist) { min_dist = dist; closest = j; }
+            }
+            p[i] = g[closest];
+        }
+        p1 = p[0]; p2 = p[1];
+        return true;
+    }
+
+    // estimateSeam S:806-957 on the GPU
+    int estimate_seam(const isx_mat* image1, const isx_mat* image2, Pt tl1, Pt tl2, int comp, Pt p1, Pt p2, std::vector<Pt>& seam, bool& horiz, bool& found) {
+        const int roi[4] = {tls[comp].x, tls[comp].y, brs[comp].x - tls[comp].x, brs[comp].y - tls[comp].y};
+        isx_mat lab;
+        lab.data = labels.data(); lab.rows = uh; lab.cols = uw; lab.type = ISX_32SC1; lab.step = (size_t)uw * 4; lab.device = -1;
+        std::vector<int> xy((size_t)2 * (roi[2] + roi[3] + 2));
+        int len = 0, h = 0;
+        ISX_TRY(isx_seam_estimate(image1, image2, tl1.x, tl1.y, tl2.x, tl2.y, utlx, utly, &lab, comp + 1, roi, p1.x, p1.y, p2.x, p2.y, xy.data(),
+                                  roi[2] + roi[3] + 2, &len, &h, device, stream));
+        seam.resize(len);
+        for (int i = 0; i < len; ++i) seam[i] = {xy[2 * i], xy[2 * i + 1]};
+        horiz = h != 0;
+        found = len > 0;
+        return ISX_OK;
+    }
+
+    void update_labels_using_seam(int comp1, int comp2, const std::vector<Pt>& seam, bool horiz) {   // S:960-1093
+        const Pt tl = tls[comp1], br = brs[comp1];
+        const int h = br.y - tl.y, w = br.x - tl.x;
+        std::vector<int> mask((size_t)h * w, 0);
+        auto M = [&](int y, int x) -> int& { return mask[(size_t)y * w + x]; };
+        for (const Pt& p : contours[comp1]) M(p.y - tl.y, p.x - tl.x) = 255;
+        for (const Pt& p : seam) M(p.y - tl.y, p.x - tl.x) = 255;
+        const int l1 = comp1 + 1, l2 = comp2 + 1;
+        int nc = 0;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+                if (!M(y, x) && L(y + tl.y, x + tl.x) == l1) flood_fill(mask, w, h, x, y, ++nc);
+        static const int dx[] = {-1, +1, 0, 0, -1, +1, -1, +1}, dy[] = {0, 0, -1, +1, -1, -1, +1, +1};
+        for (const Pt& p : contours[comp1]) {
+            const int x = p.x - tl.x, y = p.y - tl.y;
+            bool ok = false;
+            for (int j = 0; j < 8; ++j) {
+                const int c = x + dx[j], r = y + dy[j];
+                if (c >= 0 && c < w && r >= 0 && r < h && M(r, c) && M(r, c) != 255) { ok = true; M(y, x) = M(r, c); }
+            }
+            if (!ok) M(y, x) = 0;
+        }
+        for (const Pt& p : seam) {
+            const int x = p.x - tl.x, y = p.y - tl.y;
+            if (horiz) M(y, x) = (y < h - 1 && M(y + 1, x) && M(y + 1, x) != 255) ? M(y + 1, x) : 0;
+            else M(y, x) = (x < w - 1 && M(y, x + 1) && M(y, x + 1) != 255) ? M(y, x + 1) : 0;
+        }
+        std::map<int, int> connect2, connect_other;
+        for (int i = 1; i <= nc; ++i) { connect2[i] = 0; connect_other[i] = 0; }
+        for (const Pt& p : contours[comp1]) {
+            const int x = p.x, y = p.y;
+            if ((x > 0 && L(y, x - 1) == l2) || (y > 0 && L(y - 1, x) == l2) || (x < uw - 1 && L(y, x + 1) == l2) || (y < uh - 1 && L(y + 1, x) == l2))
+                connect2[M(y - tl.y, x - tl.x)]++;
+            if ((x > 0 && L(y, x - 1) != l1 && L(y, x - 1) != l2) || (y > 0 && L(y - 1, x) != l1 && L(y - 1, x) != l2) ||
+                (x < uw - 1 && L(y, x + 1) != l1 && L(y, x + 1) != l2) || (y < uh - 1 && L(y + 1, x) != l1 && L(y + 1, x) != l2))
+                connect_other[M(y - tl.y, x - tl.x)]++;
+        }
+        // the reference indexes isAdjComp(ncomps + 1) with every key of connect2, which may hold 0 (a contour pixel that lost
+        // its region): sized to hold all keys here
+        int maxkey = nc;
+        for (const auto& kv : connect2) maxkey = std::max(maxkey, kv.first);
+        std::vector<int> is_adj((size_t)maxkey + 1, 0);
+        const double len = (double)contours[comp1].size();
+        for (const auto& kv : connect2) {
+            int res = 0;
+            if (kv.second / len > 0.05) {
+                auto sub = connect_other.find(kv.first);
+                if (sub != connect_other.end() && (sub->second / len < 0.1)) res = 1;
+            }
+            if (kv.first >= 0) is_adj[kv.first] = res;
+        }
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int m = M(y, x);
+                if (m && m <= maxkey && is_adj[m]) labels[(size_t)(y + tl.y) * uw + x + tl.x] = l2;
+            }
+    }
+
+    int resolve_conflicts(const isx_mat* image1, const isx_mat* image2, Pt tl1, Pt tl2, unsigned char* mask1, size_t step1, int rows1, int cols1,
+                          unsigned char* mask2, size_t step2, int rows2, int cols2) {   // S:395-546
+        bool has_conflict = true;
+        while (has_conflict) {
+            int c1 = 0, c2 = 0;
+            has_conflict = false;
+            for (const auto& e : edges) {
+                c1 = e.first; c2 = e.second;
+                if ((states[c1] & INTERS) && (states[c1] & (~INTERS)) != states[c2]) { has_conflict = true; break; }
+            }
+            if (!has_conflict) break;
+            const int l1 = c1 + 1, l2 = c2 + 1;
+            if (has_only_one_neighbor(c1)) {
+                for (int y = tls[c1].y; y < brs[c1].y; ++y)
+                    for (int x = tls[c1].x; x < brs[c1].x; ++x)
+                        if (L(y, x) == l1) labels[(size_t)y * uw + x] = l2;
+                states[c1] = states[c2] == FIRST ? SECOND : FIRST;
+            } else {
+                Pt p1, p2;
+                if (get_seam_tips(c1, c2, p1, p2)) {
+                    std::vector<Pt> seam;
+                    bool horiz = false, found = false;
+                    ISX_TRY(estimate_seam(image1, image2, tl1, tl2, c1, p1, p2, seam, horiz, found));
+                    if (found) update_labels_using_seam(c1, c2, seam, horiz);
+                }
+                states[c1] = states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
+            }
+            const int c[2] = {c1, c2}, l[2] = {l1, l2};
+            for (int i = 0; i < 2; ++i) {
+                const int x0 = tls[c[i]].x, x1 = brs[c[i]].x, y0 = tls[c[i]].y, y1 = brs[c[i]].y;
+                tls[c[i]] = {INT_MAX, INT_MAX};
+                brs[c[i]] = {INT_MIN, INT_MIN};
+                contours[c[i]].clear();
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x)
+                        if (L(y, x) == l[i]) {
+                            tls[c[i]].x = std::min(tls[c[i]].x, x); tls[c[i]].y = std::min(tls[c[i]].y, y);
+                            brs[c[i]].x = std::max(brs[c[i]].x, x + 1); brs[c[i]].y = std::max(brs[c[i]].y, y + 1);
+                            if (on_contour(y, x, l[i])) contours[c[i]].push_back({x, y});
+                        }
+            }
+            edges.erase({c1, c2});
+            edges.erase({c2, c1});
+        }
+        const int dx1 = utlx - tl1.x, dy1 = utly - tl1.y, dx2 = utlx - tl2.x, dy2 = utly - tl2.y;   // S:495-523
+        for (int y = 0; y < rows2; ++y)
+            for (int x = 0; x < cols2; ++x) {
+                const int l = L(y - dy2, x - dx2);
+                if (l > 0 && (states[l - 1] & FIRST) && mask1[(size_t)(y - dy2 + dy1) * step1 + (x - dx2 + dx1)]) mask2[(size_t)y * step2 + x] = 0;
+            }
+        for (int y = 0; y < rows1; ++y)
+            for (int x = 0; x < cols1; ++x) {
+                const int l = L(y - dy1, x - dx1);
+                if (l > 0 && (states[l - 1] & SECOND) && mask2[(size_t)(y - dy1 + dy2) * step2 + (x - dx1 + dx2)]) mask1[(size_t)y * step1 + x] = 0;
+            }
+        (void)rows1; (void)cols1;
+        return ISX_OK;
+    }
+
+    int process(const isx_mat* image1, const isx_mat* image2, Pt tl1, Pt tl2, unsigned char* mask1, size_t step1, unsigned char* mask2, size_t step2) {   // S:127-193
+        const int r1 = image1->rows, c1 = image1->cols, r2 = image2->rows, c2 = image2->cols;
+        const int itlx = std::max(tl1.x, tl2.x), itly = std::max(tl1.y, tl2.y);
+        const int ibrx = std::min(tl1.x + c1, tl2.x + c2), ibry = std::min(tl1.y + r1, tl2.y + r2);
+        if (itlx >= ibrx || itly >= ibry) return ISX_OK;   // there are no conflicts
+        utlx = std::min(tl1.x, tl2.x); utly = std::min(tl1.y, tl2.y);
+        uw = std::max(tl1.x + c1, tl2.x + c2) - utlx;
+        uh = std::max(tl1.y + r1, tl2.y + r2) - utly;
+        mask1_.assign((size_t)uw * uh, 0);
+        mask2_.assign((size_t)uw * uh, 0);
+        for (int y = 0; y < r1; ++y) memcpy(&mask1_[(size_t)(y + tl1.y - utly) * uw + (tl1.x - utlx)], mask1 + (size_t)y * step1, (size_t)c1);
+        for (int y = 0; y < r2; ++y) memcpy(&mask2_[(size_t)(y + tl2.y - utly) * uw + (tl2.x - utlx)], mask2 + (size_t)y * step2, (size_t)c2);
+        contour_mask(mask1_, contour1mask_);
+        contour_mask(mask2_, contour2mask_);
+        find_components();
+        find_edges();
+        return resolve_conflicts(image1, image2, tl1, tl2, mask1, step1, r1, c1, mask2, step2, r2, c2);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_xy, isx_mat* masks, int device, void* hip_stream) {
+    clear_error();
+    ISX_CHECK_ARG(num_images >= 0 && (num_images == 0 || (images && corners_xy && masks)), ISX_ERR_INVALID, "dp_seam_find: null argument");
+    if (num_images == 0) return ISX_OK;   // S:95-96
+    for (int i = 0; i < num_images; ++i) {
+        ISX_TRY(check_mat(&images[i], "dp_seam_find: image"));
+        ISX_TRY(check_mat(&masks[i], "dp_seam_find: mask"));
+        ISX_CHECK_ARG(images[i].type == images[0].type && (images[i].type == ISX_32FC3 || images[i].type == ISX_8UC3), ISX_ERR_TYPE,
+                      "dp_seam_find: all images must have CV_32FC3 or CV_8UC3 type (S:745-746)");
+        ISX_CHECK_ARG(masks[i].type == ISX_8UC1, ISX_ERR_TYPE, "dp_seam_find: masks must be CV_8U");
+        ISX_CHECK_ARG(masks[i].rows == images[i].rows && masks[i].cols == images[i].cols, ISX_ERR_SIZE, "dp_seam_find: image %d and its mask differ in size (S:133-134)", i);
+    }
+    ISX_HIP(hipSetDevice(device));
+    // the logic below edits the masks on the host: device masks are brought down and written back
+    std::vector<std::vector<unsigned char>> hostm(num_images);
+    std::vector<unsigned char*> mp(num_images);
+    std::vector<size_t> ms(num_images);
+    for (int i = 0; i < num_images; ++i) {
+        if (masks[i].device >= 0) {
+            hostm[i].resize((size_t)masks[i].rows * masks[i].cols);
+            ISX_HIP(hipMemcpy2D(hostm[i].data(), masks[i].cols, masks[i].data, masks[i].step, masks[i].cols, masks[i].rows, hipMemcpyDeviceToHost));
+            mp[i] = hostm[i].data(); ms[i] = (size_t)masks[i].cols;
+        } else { mp[i] = (unsigned char*)masks[i].data; ms[i] = masks[i].step; }
+    }
+    Finder f;
+    f.device = device;
+    f.stream = (hipStream_t)hip_stream;
+    std::vector<std::pair<int, int>> pairs;   // S:98-113
+    for (int i = 0; i + 1 < num_images; ++i)
+        for (int j = i + 1; j < num_images; ++j) pairs.push_back({i, j});
+    std::reverse(pairs.begin(), pairs.end());
+    for (const auto& pr : pairs) {
+        const int i0 = pr.first, i1 = pr.second;
+        ISX_TRY(f.process(&images[i0], &images[i1], {corners_xy[2 * i0], corners_xy[2 * i0 + 1]}, {corners_xy[2 * i1], corners_xy[2 * i1 + 1]}, mp[i0], ms[i0], mp[i1], ms[i1]));
+    }
+    for (int i = 0; i < num_images; ++i)
+        if (masks[i].device >= 0)
+            ISX_HIP(hipMemcpy2D(masks[i].data, masks[i].step, hostm[i].data(), masks[i].cols, masks[i].cols, masks[i].rows, hipMemcpyHostToDevice));
+    return ISX_OK;
+}
+
+}  // extern "C"

@@ -22,3 +22,20 @@ def seam_estimate(image1, image2, tl1, tl2, union_tl, labels, label, roi, p1, p2
                                         C.byref(ml), int(label), r, int(p1[0]), int(p1[1]), int(p2[0]), int(p2[1]),
                                         out.ctypes.data_as(C.POINTER(C.c_int)), cap, C.byref(n), C.byref(horiz), int(device), C.c_void_p(ptr or 0)))
     return out[: n.value].copy(), bool(horiz.value)
+
+
+class DpSeamFinder:
+    """The reference's in-tree DP seam finder (S:60-1093, `find` as called at S:1192; costFunc_ COLOR)."""
+
+    def __init__(self, device=0, stream=None):
+        self.device, self.stream = device, stream
+
+    def find(self, src, corners, masks):
+        """find(src, corners, masks): src = CV_32FC3 (or CV_8UC3) images, masks = CV_8U arrays / tensors edited in place."""
+        n = len(src)
+        mats_i = (_lib.IsxMat * n)(*[as_mat(a) for a in src])
+        mats_m = (_lib.IsxMat * n)(*[as_mat(m) for m in masks])
+        c = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+        ptr = getattr(self.stream, "cuda_stream", self.stream)
+        check(_lib.load().isx_dp_seam_find(n, mats_i, c, mats_m, int(self.device), C.c_void_p(ptr or 0)))
+        return masks

@@ -187,6 +187,21 @@ inline void dilateAnd(const Mat& mask, int kw, int kh, const Mat* other, Mat& ou
     check(isx_mask_dilate_and(mask.c(), other ? other->c() : nullptr, kw, kh, out.c(), device, nullptr));
 }
 
+// cv::detail::DpSeamFinder as the reference restates it in-tree (S:60-1093): seam_finder->find(images_warped_f, corners, masks_seam)
+class DpSeamFinder {
+public:
+    explicit DpSeamFinder(int device = 0) : device_(device) {}
+    void find(const std::vector<Mat>& src, const std::vector<Point>& corners, std::vector<Mat>& masks) {   // S:87, called at S:1192
+        if (src.size() != corners.size() || src.size() != masks.size()) throw Exception(ISX_ERR_INVALID, "find: src, corners and masks differ in length");
+        std::vector<isx_mat> im(src.size()), mk(src.size());
+        std::vector<int> c;
+        for (size_t i = 0; i < src.size(); ++i) { im[i] = *src[i].c(); mk[i] = *masks[i].c(); c.push_back(corners[i].x); c.push_back(corners[i].y); }
+        check(isx_dp_seam_find((int)src.size(), im.data(), c.data(), mk.data(), device_, nullptr));
+    }
+private:
+    int device_;
+};
+
 // cv::imread(path) / cv::imwrite(path, img) for .bmp files (W:166,315)
 inline Mat imread(const char* path) {
     int rows = 0, cols = 0;

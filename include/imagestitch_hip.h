@@ -242,6 +242,14 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
                       int p1_x, int p1_y, int p2_x, int p2_y, int* seam_xy, int cap, int* seam_len,
                       int* is_horizontal, int device, void* hip_stream);
 
+/* seam_finder->find(images_warped_f, corners, masks_seam) of the in-tree DP seam finder as a whole (S:87-124 `find`, as
+ * the S demo calls it at S:1192; W:253 is the stock `DpSeamFinder(DpSeamFinder::COLOR)` it restates): every pair of
+ * images, last pair first; component / contour / graph logic on the host, the cost maps and the dynamic programme of every
+ * estimateSeam on the GPU.  images: n mats, all CV_32FC3 (W:261) or all CV_8UC3, host or device; masks: n CV_8UC1 mats
+ * of the images' sizes, edited in place.                                                                            */
+int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_xy, isx_mat* masks, int device,
+                     void* hip_stream);
+
 /* ---- on-disk format either side of the path: .bmp (W:166 imread, W:155-156,315 imwrite) ----------- */
 /* Uncompressed Windows bitmaps only (the reference's committed artefacts are BMPs; JPEG is not implemented).
  * isx_bmp_read = cv::imread(path) with IMREAD_COLOR: `out` is a CV_8UC3 mat (host or device) of the size

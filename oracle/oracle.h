@@ -18,8 +18,9 @@
  *     images_warped_f[0].bmp = gain * warp(src2.bmp) (tests/golden/ref_warp_artifact.npz, tests/test_ref_artifact.py):
  *     the artefact came from OpenCV's OpenCL remap (float blend, round-half-even); orc_remap_u8 is the CPU fixed-point
  *     path = the same weighted sum rounded half-up, and differs from the artefact exactly at the ties.
- *   - orc_seam_costs / orc_seam_estimate: PINNED by the reference's committed mask_seam[0,1].bmp: 801 rows of their common
- *     boundary are reproduced exactly from images_warped_f[0,1].bmp (tests/golden/ref_seam_artifact.npz).
+ *   - orc_seam_costs / orc_seam_estimate (+ oracle/dpseam_np.py, the whole finder S:87-1093): PINNED by the reference's
+ *     committed mask_seam[0,1].bmp, which the restatement reproduces exactly from the reconstructed inputs
+ *     (tests/golden/ref_dpseam_artifact.npz, ref_seam_artifact.npz).
  *   - remap (other modes), pyrDown/pyrUp, MultiBandBlender, SphericalProjector: the arithmetic lives in
  *     OpenCV 3.4.2 (opencv_world342, README.md:23-24), which is neither vendored in
  *     /root/reference nor installed here.  These functions restate OpenCV 3.4.2's published

@@ -43,3 +43,31 @@ def make_case(seed, size1=(90, 120), size2=(100, 110), tl1=(-30, 5), tl2=(40, -8
         yy, xx = np.mgrid[0:h2, 0:w2]
         img2 = (128 + 60 * np.sin((xx + tl2[0] - tl1[0]) / 9.0)[..., None] * np.cos((yy + tl2[1] - tl1[1]) / 7.0)[..., None] + rng.normal(0, 8, (h2, w2, 3))).astype(np.float32)
     return dict(img1=img1, img2=img2, tl1=tl1, tl2=tl2, union_tl=utl, labels=labels, label=label, roi=roi, p1=p1, p2=p2)
+
+
+def make_find_case(seed, n_images=2, u8=False, holes=True, size=(110, 140)):
+    """Inputs of DpSeamFinder::find (S:87-124): n overlapping tiles in a row with barrel-shaped masks (as a cylindrical warp
+    leaves them), optional holes (extra components), smooth + noisy CV_32FC3 (or CV_8UC3) content."""
+    rng = np.random.default_rng(seed)
+    h0, w0 = size
+    images, masks, corners = [], [], []
+    x = 0
+    for i in range(n_images):
+        h, w = h0 + int(rng.integers(-8, 9)), w0 + int(rng.integers(-10, 11))
+        tl = (x + int(rng.integers(-3, 4)), int(rng.integers(-6, 7)))
+        x += int(w * rng.uniform(0.45, 0.7))
+        yy, xx = np.mgrid[0:h, 0:w]
+        bulge = 0.00035 * rng.uniform(0.5, 1.5) * (xx - w / 2.0) ** 2
+        m = ((yy >= bulge) & (yy <= h - 1 - bulge)).astype(np.uint8) * 255
+        if holes:
+            for _ in range(int(rng.integers(0, 4))):
+                cy, cx = int(rng.integers(0, h)), int(rng.integers(0, w))
+                m[cy:cy + int(rng.integers(1, 9)), cx:cx + int(rng.integers(1, 12))] = 0
+        gx, gy = xx + tl[0], yy + tl[1]
+        base = 128 + 55 * np.sin(gx / 11.0)[..., None] * np.cos(gy / 8.0)[..., None] + np.stack([gx * 0.1, gy * 0.2, (gx + gy) * 0.05], -1)
+        img = base + rng.normal(0, 9 + 3 * i, (h, w, 3))
+        img = np.clip(img, 0, 255)
+        images.append(np.rint(img).astype(np.uint8) if u8 else np.rint(img).astype(np.float32))
+        masks.append(m)
+        corners.append(tl)
+    return images, corners, masks

@@ -71,3 +71,37 @@ def test_gpu_reproduces_the_references_dp_seam(gpu, oracle):
     c, seam = _seam_case(art)
     got, horiz = gpu.seam_estimate(c["img1"], c["img2"], c["tl1"], c["tl2"], c["union_tl"], c["labels"], c["label"], c["roi"], c["p1"], c["p2"])
     assert not horiz and np.array_equal(got, seam)
+
+
+# ---- the whole DP seam finder ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("n_images,u8", [(2, False), (2, True), (3, False)])
+def test_dp_seam_find_matches_oracle(gpu, seed, n_images, u8):
+    """isx_dp_seam_find (host component logic + GPU estimateSeam) against the Python restatement of S:87-1093."""
+    from oracle.dpseam_np import DpSeamFinder as OracleFinder
+    from seam_cases import make_find_case
+    images, corners, masks = make_find_case(1000 * n_images + seed, n_images, u8, holes=seed % 2 == 0)
+    ref = [m.copy() for m in masks]
+    OracleFinder().find([im.astype(np.float32) if not u8 else im for im in images], corners, ref)
+    got = [m.copy() for m in masks]
+    gpu.DpSeamFinder().find(images, corners, got)
+    for a, b, m in zip(got, ref, masks):
+        assert np.array_equal(a, b), np.argwhere(a != b)[:4]
+    assert any((a != m).any() for a, m in zip(got, masks))       # the finder did cut something
+
+
+def test_dp_seam_find_reproduces_the_references_seam_masks(gpu):
+    """tests/golden/ref_dpseam_artifact.npz: the masks that went into the reference's `find` (S:1192) come out of
+    isx_dp_seam_find as exactly its committed mask_seam[0].bmp and mask_seam[1].bmp; images resident on the device."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ref_artifact import dpseam_case
+    c = dpseam_case()
+    masks = [m.copy() for m in c["masks_in"]]
+    gpu.DpSeamFinder().find([torch.from_numpy(im).cuda() for im in c["images"]], c["corners"], masks)
+    assert np.array_equal(masks[0], c["masks_out"][0]) and np.array_equal(masks[1], c["masks_out"][1])
+    dm = [torch.from_numpy(m.copy()).cuda() for m in c["masks_in"]]          # device masks are edited in place too
+    gpu.DpSeamFinder().find([torch.from_numpy(im).cuda() for im in c["images"]], c["corners"], dm)
+    assert np.array_equal(dm[0].cpu().numpy(), c["masks_out"][0]) and np.array_equal(dm[1].cpu().numpy(), c["masks_out"][1])
