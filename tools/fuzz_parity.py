@@ -174,7 +174,22 @@ def case_pipeline(rng):
     assert np.array_equal(b.cpu().numpy(), od) and np.array_equal(bm.cpu().numpy(), om)
 
 
-CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline]
+def case_find(rng):
+    """The whole DP seam finder: isx_dp_seam_find vs oracle/dpseam_np.py on 2-4 tiles with barrel-shaped, holed masks."""
+    from oracle.dpseam_np import DpSeamFinder as OracleFinder
+    from seam_cases import make_find_case
+    n, u8 = int(rng.integers(2, 5)), bool(rng.integers(0, 2))
+    images, corners, masks = make_find_case(int(rng.integers(0, 1 << 30)), n, u8, holes=bool(rng.integers(0, 2)),
+                                            size=(int(rng.integers(20, 160)), int(rng.integers(30, 200))))
+    ref = [m.copy() for m in masks]
+    OracleFinder().find(images, corners, ref)
+    got = [m.copy() for m in masks]
+    G.DpSeamFinder().find(images, corners, got)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b), np.argwhere(a != b)[:3]
+
+
+CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find]
 
 
 def main():
