@@ -235,7 +235,9 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
 
     ISX_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
-    MatStage s1, s2, sl;
+    // staging and scratch persist per host thread (grow-only, never freed: a finder calls this once per conflict)
+    static thread_local MatStage* stages = new MatStage[3];
+    MatStage &s1 = stages[0], &s2 = stages[1], &sl = stages[2];
     ISX_TRY(s1.use_in(image1, st, "seam_estimate: image1"));
     ISX_TRY(s2.use_in(image2, st, "seam_estimate: image2"));
     ISX_TRY(sl.use_in(labels, st, "seam_estimate: labels"));
@@ -245,7 +247,8 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
     g.labels = (const unsigned char*)sl.d.data; g.lstep = sl.d.step;
     g.uh = labels->rows; g.uw = labels->cols; g.label = label;
     g.rx = rx; g.ry = ry; g.rw = rw; g.rh = rh; g.dx1 = dx1; g.dy1 = dy1; g.dx2 = dx2; g.dy2 = dy2;
-    DevBuf scratch;
+    static thread_local DevBuf* scratch_p = new DevBuf();
+    DevBuf& scratch = *scratch_p;
     const size_t cv_b = ((size_t)rh * (rw + 1) * 4 + 255) & ~(size_t)255, ch_b = ((size_t)(rh + 1) * rw * 4 + 255) & ~(size_t)255,
                  ct_b = ((size_t)rh * rw + 255) & ~(size_t)255;
     const int first = (horiz ? sx : sy) + 1, nsteps = std::max((horiz ? dx : dy) - first + 1, 0);

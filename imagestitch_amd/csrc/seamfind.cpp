@@ -9,7 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -26,30 +29,11 @@ namespace {
 struct Pt { int x, y; };
 enum { FIRST = 1, SECOND = 2, INTERS = 4 };
 
-// cv::floodFill(image, seed, newVal) with the default flags: 4-connectivity, zero tolerance
-void flood_fill(std::vector<int>& img, int w, int h, int sx, int sy, int newval) {
-    const int old = img[(size_t)sy * w + sx];
-    if (old == newval) return;
-    std::vector<Pt> stack;
-    stack.push_back({sx, sy});
-    img[(size_t)sy * w + sx] = newval;
-    while (!stack.empty()) {
-        const Pt p = stack.back();
-        stack.pop_back();
-        const int nx[4] = {p.x - 1, p.x + 1, p.x, p.x}, ny[4] = {p.y, p.y, p.y - 1, p.y + 1};
-        for (int k = 0; k < 4; ++k)
-            if (nx[k] >= 0 && nx[k] < w && ny[k] >= 0 && ny[k] < h && img[(size_t)ny[k] * w + nx[k]] == old) {
-                img[(size_t)ny[k] * w + nx[k]] = newval;
-                stack.push_back({nx[k], ny[k]});
-            }
-    }
-}
-
 struct Finder {
     int device = 0;
     hipStream_t stream = nullptr;
     int utlx = 0, utly = 0, uw = 0, uh = 0;
-    std::vector<unsigned char> mask1_, mask2_, contour1mask_, contour2mask_;
+    std::vector<unsigned char> mask1_, mask2_;
     int ncomps = 0;
     std::vector<int> labels;
     std::vector<int> states;
@@ -62,39 +46,99 @@ struct Finder {
         return (x == 0 || L(y, x - 1) != l) || (x == uw - 1 || L(y, x + 1) != l) || (y == 0 || L(y - 1, x) != l) || (y == uh - 1 || L(y + 1, x) != l);
     }
 
-    void contour_mask(const std::vector<unsigned char>& m, std::vector<unsigned char>& c) const {   // S:168-186
-        c.assign((size_t)uw * uh, 0);
-        for (int y = 0; y < uh; ++y)
-            for (int x = 0; x < uw; ++x)
-                if (m[(size_t)y * uw + x] && ((x == 0 || !m[(size_t)y * uw + x - 1]) || (x == uw - 1 || !m[(size_t)y * uw + x + 1]) ||
-                                              (y == 0 || !m[(size_t)(y - 1) * uw + x]) || (y == uh - 1 || !m[(size_t)(y + 1) * uw + x])))
-                    c[(size_t)y * uw + x] = 255;
+    // contour1mask_ / contour2mask_ (S:168-186) are only ever read through closeToContour (S:585-604) at the contour pixels
+    // of one component: evaluated on demand from the masks instead of being materialised for the whole union
+    bool is_mask_contour(const std::vector<unsigned char>& m, int y, int x) const {
+        const size_t i = (size_t)y * uw + x;
+        return m[i] && ((x == 0 || !m[i - 1]) || (x == uw - 1 || !m[i + 1]) || (y == 0 || !m[i - uw]) || (y == uh - 1 || !m[i + uw]));
     }
 
-    void find_components() {   // S:196-308
-        ncomps = 0;
+    // S:196-308.  The reference scans the union in raster order and flood-fills (4-connectivity, equal class) from the
+    // first pixel of every component it meets.  Same numbering without touching every pixel: row runs of equal class,
+    // union-find over vertically overlapping runs of the same class, components numbered by their first run in raster
+    // order (= their first pixel); bounding boxes from the runs; contour pixels = run ends plus the interior pixels not
+    // covered by the same component in the row above or below (interval arithmetic on the sorted run lists).
+    struct Run { int x0, x1, cls, id; };
+    void find_components() {
         labels.assign((size_t)uw * uh, 0);
         states.clear(); tls.clear(); brs.clear(); contours.clear();
-        for (size_t i = 0; i < labels.size(); ++i)
-            labels[i] = (mask1_[i] && mask2_[i]) ? INT_MAX : (mask1_[i] ? INT_MAX - 1 : (mask2_[i] ? INT_MAX - 2 : 0));
+        std::vector<Run> runs;
+        std::vector<int> row_start((size_t)uh + 1, 0);
+        for (int y = 0; y < uh; ++y) {
+            row_start[y] = (int)runs.size();
+            const unsigned char* a = &mask1_[(size_t)y * uw];
+            const unsigned char* b = &mask2_[(size_t)y * uw];
+            int x = 0;
+            while (x < uw) {
+                const int cls = (a[x] && b[x]) ? INTERS : (a[x] ? FIRST : (b[x] ? SECOND : 0));
+                int e = x + 1;
+                if (cls == 0) { while (e < uw && !a[e] && !b[e]) ++e; }
+                else { while (e < uw && ((a[e] && b[e]) ? INTERS : (a[e] ? FIRST : (b[e] ? SECOND : 0))) == cls) ++e; }
+                if (cls) runs.push_back({x, e, cls, 0});
+                x = e;
+            }
+        }
+        row_start[uh] = (int)runs.size();
+        std::vector<int> parent(runs.size());
+        for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+        auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+        for (int y = 1; y < uh; ++y) {   // runs of the same class that overlap in x are 4-connected
+            int i = row_start[y - 1], j = row_start[y];
+            const int ie = row_start[y], je = row_start[y + 1];
+            while (i < ie && j < je) {
+                if (runs[i].cls == runs[j].cls && runs[i].x0 < runs[j].x1 && runs[j].x0 < runs[i].x1) {
+                    const int ra = find(i), rb = find(j);
+                    if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+                }
+                if (runs[i].x1 <= runs[j].x1) ++i; else ++j;
+            }
+        }
+        std::vector<int> comp_of(runs.size(), 0);
+        ncomps = 0;
         for (int y = 0; y < uh; ++y)
-            for (int x = 0; x < uw; ++x) {
-                const int v = L(y, x);
-                if (v >= INT_MAX - 2) {
-                    states.push_back(v == INT_MAX ? INTERS : (v == INT_MAX - 1 ? FIRST : SECOND));
-                    flood_fill(labels, uw, uh, x, y, ++ncomps);
-                    tls.push_back({x, y}); brs.push_back({x + 1, y + 1});
+            for (int k = row_start[y]; k < row_start[y + 1]; ++k) {
+                const int r = find(k);
+                if (!comp_of[r]) {   // first run of the component in raster order: its first pixel is the flood-fill seed
+                    comp_of[r] = ++ncomps;
+                    states.push_back(runs[k].cls);
+                    tls.push_back({runs[k].x0, y});
+                    brs.push_back({runs[k].x0 + 1, y + 1});
                     contours.emplace_back();
                 }
-                const int l = L(y, x);
-                if (l) {
-                    const int ci = l - 1;
-                    tls[ci].x = std::min(tls[ci].x, x); tls[ci].y = std::min(tls[ci].y, y);
-                    brs[ci].x = std::max(brs[ci].x, x + 1); brs[ci].y = std::max(brs[ci].y, y + 1);
-                    // the reference tests the neighbours while later components still carry their class codes: a neighbour
-                    // "!= l" either way
-                    if (on_contour(y, x, l)) contours[ci].push_back({x, y});
+                const int l = comp_of[r];
+                runs[k].id = l;
+                std::fill(labels.begin() + (size_t)y * uw + runs[k].x0, labels.begin() + (size_t)y * uw + runs[k].x1, l);
+                Pt& tl = tls[l - 1]; Pt& br = brs[l - 1];
+                tl.x = std::min(tl.x, runs[k].x0); tl.y = std::min(tl.y, y);
+                br.x = std::max(br.x, runs[k].x1); br.y = std::max(br.y, y + 1);
+            }
+        // contour pixels, per component in raster order (S:249-253)
+        std::vector<std::pair<int, int>> cov;   // pixels of the run covered by the same component above AND below
+        for (int y = 0; y < uh; ++y)
+            for (int k = row_start[y]; k < row_start[y + 1]; ++k) {
+                const Run& r = runs[k];
+                cov.clear();
+                if (y > 0 && y < uh - 1) {
+                    int i = row_start[y - 1], j = row_start[y + 1];
+                    const int ie = row_start[y], je = row_start[y + 2 <= uh ? y + 2 : uh];
+                    while (i < ie && j < je) {
+                        if (runs[i].id != r.id || runs[i].x1 <= r.x0) { ++i; continue; }
+                        if (runs[j].id != r.id || runs[j].x1 <= r.x0) { ++j; continue; }
+                        if (runs[i].x0 >= r.x1 || runs[j].x0 >= r.x1) break;
+                        const int lo = std::max(std::max(runs[i].x0, runs[j].x0), r.x0), hi = std::min(std::min(runs[i].x1, runs[j].x1), r.x1);
+                        if (lo < hi) cov.push_back({lo, hi});
+                        if (runs[i].x1 <= runs[j].x1) ++i; else ++j;
+                    }
                 }
+                std::vector<Pt>& out = contours[r.id - 1];
+                int x = r.x0;
+                for (const auto& c : cov) {   // covered interior pixels are not contour pixels — except the two run ends
+                    const int lo = std::max(c.first, r.x0 + 1), hi = std::min(c.second, r.x1 - 1);
+                    if (lo >= hi) continue;
+                    for (; x < lo; ++x) out.push_back({x, y});
+                    x = hi;
+                }
+                for (; x < r.x1; ++x) out.push_back({x, y});
             }
     }
 
@@ -118,11 +162,11 @@ struct Finder {
         return b != e && std::next(b) == e;
     }
 
-    bool close_to_contour(int y, int x, const std::vector<unsigned char>& cm) const {   // S:585-604
+    bool close_to_contour(int y, int x, const std::vector<unsigned char>& m) const {   // S:585-604 on the contour mask of m
         for (int dy = -2; dy <= 2; ++dy)
             if (y + dy >= 0 && y + dy < uh)
                 for (int dx = -2; dx <= 2; ++dx)
-                    if (x + dx >= 0 && x + dx < uw && cm[(size_t)(y + dy) * uw + x + dx]) return true;
+                    if (x + dx >= 0 && x + dx < uw && is_mask_contour(m, y + dy, x + dx)) return true;
         return false;
     }
 
@@ -147,7 +191,7 @@ struct Finder {
         std::vector<Pt> special;
         for (const Pt& p : contours[comp1]) {
             const int x = p.x, y = p.y;
-            if (close_to_contour(y, x, contour1mask_) && close_to_contour(y, x, contour2mask_) &&
+            if (close_to_contour(y, x, mask1_) && close_to_contour(y, x, mask2_) &&
                 ((x > 0 && L(y, x - 1) == l2) || (y > 0 && L(y - 1, x) == l2) || (x < uw - 1 && L(y, x + 1) == l2) || (y < uh - 1 && L(y + 1, x) == l2)))
                 special.push_back(p);
         }
@@ -184,17 +228,20 @@ struct Finder {
         return true;
     }
 
-    // estimateSeam S:806-957 on the GPU
+    // estimateSeam S:806-957 on the GPU.  Only the component's rectangle of labels_ is handed over (a view into the label
+    // image with the union origin shifted accordingly): every labels_ read outside Rect(tls_, brs_) is "not this
+    // component" anyway, and the rectangle is a fraction of the union.
     int estimate_seam(const isx_mat* image1, const isx_mat* image2, Pt tl1, Pt tl2, int comp, Pt p1, Pt p2, std::vector<Pt>& seam, bool& horiz, bool& found) {
-        const int roi[4] = {tls[comp].x, tls[comp].y, brs[comp].x - tls[comp].x, brs[comp].y - tls[comp].y};
+        const int rx = tls[comp].x, ry = tls[comp].y, rw = brs[comp].x - rx, rh = brs[comp].y - ry;
+        const int roi[4] = {0, 0, rw, rh};
         isx_mat lab;
-        lab.data = labels.data(); lab.rows = uh; lab.cols = uw; lab.type = ISX_32SC1; lab.step = (size_t)uw * 4; lab.device = -1;
-        std::vector<int> xy((size_t)2 * (roi[2] + roi[3] + 2));
+        lab.data = labels.data() + (size_t)ry * uw + rx; lab.rows = rh; lab.cols = rw; lab.type = ISX_32SC1; lab.step = (size_t)uw * 4; lab.device = -1;
+        std::vector<int> xy((size_t)2 * (rw + rh + 2));
         int len = 0, h = 0;
-        ISX_TRY(isx_seam_estimate(image1, image2, tl1.x, tl1.y, tl2.x, tl2.y, utlx, utly, &lab, comp + 1, roi, p1.x, p1.y, p2.x, p2.y, xy.data(),
-                                  roi[2] + roi[3] + 2, &len, &h, device, stream));
+        ISX_TRY(isx_seam_estimate(image1, image2, tl1.x, tl1.y, tl2.x, tl2.y, utlx + rx, utly + ry, &lab, comp + 1, roi, p1.x - rx, p1.y - ry, p2.x - rx, p2.y - ry,
+                                  xy.data(), rw + rh + 2, &len, &h, device, stream));
         seam.resize(len);
-        for (int i = 0; i < len; ++i) seam[i] = {xy[2 * i], xy[2 * i + 1]};
+        for (int i = 0; i < len; ++i) seam[i] = {xy[2 * i] + rx, xy[2 * i + 1] + ry};
         horiz = h != 0;
         found = len > 0;
         return ISX_OK;
@@ -208,10 +255,52 @@ struct Finder {
         for (const Pt& p : contours[comp1]) M(p.y - tl.y, p.x - tl.x) = 255;
         for (const Pt& p : seam) M(p.y - tl.y, p.x - tl.x) = 255;
         const int l1 = comp1 + 1, l2 = comp2 + 1;
+        // S:976-981: flood fills of the zero pixels of `mask`, seeded in raster order at zero pixels that carry label l1 —
+        // done on row runs of zeros (union-find over vertically overlapping runs); a zero region without any l1 pixel is
+        // never seeded and stays 0
         int nc = 0;
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x)
-                if (!M(y, x) && L(y + tl.y, x + tl.x) == l1) flood_fill(mask, w, h, x, y, ++nc);
+        {
+            struct ZRun { int y, x0, x1; };
+            std::vector<ZRun> zr;
+            std::vector<int> rs((size_t)h + 1, 0);
+            for (int y = 0; y < h; ++y) {
+                rs[y] = (int)zr.size();
+                const int* row = &mask[(size_t)y * w];
+                int x = 0;
+                while (x < w) {
+                    while (x < w && row[x]) ++x;
+                    if (x >= w) break;
+                    int e = x + 1;
+                    while (e < w && !row[e]) ++e;
+                    zr.push_back({y, x, e});
+                    x = e;
+                }
+            }
+            rs[h] = (int)zr.size();
+            std::vector<int> parent(zr.size());
+            for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+            auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+            for (int y = 1; y < h; ++y) {
+                int i = rs[y - 1], j = rs[y];
+                const int ie = rs[y], je = rs[y + 1];
+                while (i < ie && j < je) {
+                    if (zr[i].x0 < zr[j].x1 && zr[j].x0 < zr[i].x1) { const int a = find(i), b = find(j); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+                    if (zr[i].x1 <= zr[j].x1) ++i; else ++j;
+                }
+            }
+            std::vector<int> number(zr.size(), 0);
+            for (size_t k = 0; k < zr.size(); ++k) {   // raster order of the runs = raster order of their first l1 pixels
+                const int r = find((int)k);
+                if (number[r]) continue;
+                const int* lrow = &labels[(size_t)(zr[k].y + tl.y) * uw + tl.x];
+                for (int x = zr[k].x0; x < zr[k].x1; ++x)
+                    if (lrow[x] == l1) { number[r] = ++nc; break; }
+            }
+            for (size_t k = 0; k < zr.size(); ++k) {
+                const int v = number[find((int)k)];
+                if (v) std::fill(mask.begin() + (size_t)zr[k].y * w + zr[k].x0, mask.begin() + (size_t)zr[k].y * w + zr[k].x1, v);
+            }
+        }
         static const int dx[] = {-1, +1, 0, 0, -1, +1, -1, +1}, dy[] = {0, 0, -1, +1, -1, -1, +1, +1};
         for (const Pt& p : contours[comp1]) {
             const int x = p.x - tl.x, y = p.y - tl.y;
@@ -258,6 +347,60 @@ struct Finder {
             }
     }
 
+    // S:457-487: bounding box and contour pixels of label l, scanning the component's OLD rectangle only (pixels of l
+    // outside it are ignored, as in the reference) while the neighbour tests look at the whole label image.  Row runs of
+    // `== l` over the full width, contour pixels = true run ends + interior pixels not covered by l above and below.
+    void recompute_region(int c, int l) {
+        const int x0 = tls[c].x, x1 = brs[c].x, y0 = tls[c].y, y1 = brs[c].y;
+        tls[c] = {INT_MAX, INT_MAX};
+        brs[c] = {INT_MIN, INT_MIN};
+        contours[c].clear();
+        if (x0 >= x1 || y0 >= y1) return;
+        auto runs_of = [&](int y, std::vector<std::pair<int, int>>& out) {
+            out.clear();
+            if (y < 0 || y >= uh) return;
+            const int* row = &labels[(size_t)y * uw];
+            int x = 0;
+            while (x < uw) {
+                while (x < uw && row[x] != l) ++x;
+                if (x >= uw) break;
+                int e = x + 1;
+                while (e < uw && row[e] == l) ++e;
+                out.push_back({x, e});
+                x = e;
+            }
+        };
+        std::vector<std::pair<int, int>> up, cur, dn, cov;
+        runs_of(y0 - 1, up);
+        runs_of(y0, cur);
+        for (int y = y0; y < y1; ++y) {
+            runs_of(y + 1, dn);
+            for (const auto& r : cur) {
+                const int a = std::max(r.first, x0), b = std::min(r.second, x1);   // the part of the run inside the old rectangle
+                if (a >= b) continue;
+                tls[c].x = std::min(tls[c].x, a); tls[c].y = std::min(tls[c].y, y);
+                brs[c].x = std::max(brs[c].x, b); brs[c].y = std::max(brs[c].y, y + 1);
+                cov.clear();
+                size_t i = 0, j = 0;
+                while (i < up.size() && j < dn.size()) {
+                    const int lo = std::max(std::max(up[i].first, dn[j].first), r.first), hi = std::min(std::min(up[i].second, dn[j].second), r.second);
+                    if (lo < hi) cov.push_back({lo, hi});
+                    if (up[i].second <= dn[j].second) ++i; else ++j;
+                }
+                int x = a;
+                for (const auto& cv : cov) {   // covered pixels that are not a true run end (image border included) are interior
+                    const int lo = std::max(std::max(cv.first, r.first + 1), a), hi = std::min(std::min(cv.second, r.second - 1), b);
+                    if (lo >= hi) continue;
+                    for (; x < lo; ++x) contours[c].push_back({x, y});
+                    x = hi;
+                }
+                for (; x < b; ++x) contours[c].push_back({x, y});
+            }
+            up.swap(cur);
+            cur.swap(dn);
+        }
+    }
+
     int resolve_conflicts(const isx_mat* image1, const isx_mat* image2, Pt tl1, Pt tl2, unsigned char* mask1, size_t step1, int rows1, int cols1,
                           unsigned char* mask2, size_t step2, int rows2, int cols2) {   // S:395-546
         bool has_conflict = true;
@@ -285,20 +428,8 @@ struct Finder {
                 }
                 states[c1] = states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
             }
-            const int c[2] = {c1, c2}, l[2] = {l1, l2};
-            for (int i = 0; i < 2; ++i) {
-                const int x0 = tls[c[i]].x, x1 = brs[c[i]].x, y0 = tls[c[i]].y, y1 = brs[c[i]].y;
-                tls[c[i]] = {INT_MAX, INT_MAX};
-                brs[c[i]] = {INT_MIN, INT_MIN};
-                contours[c[i]].clear();
-                for (int y = y0; y < y1; ++y)
-                    for (int x = x0; x < x1; ++x)
-                        if (L(y, x) == l[i]) {
-                            tls[c[i]].x = std::min(tls[c[i]].x, x); tls[c[i]].y = std::min(tls[c[i]].y, y);
-                            brs[c[i]].x = std::max(brs[c[i]].x, x + 1); brs[c[i]].y = std::max(brs[c[i]].y, y + 1);
-                            if (on_contour(y, x, l[i])) contours[c[i]].push_back({x, y});
-                        }
-            }
+            recompute_region(c1, l1);
+            recompute_region(c2, l2);
             edges.erase({c1, c2});
             edges.erase({c2, c1});
         }
@@ -329,11 +460,17 @@ struct Finder {
         mask2_.assign((size_t)uw * uh, 0);
         for (int y = 0; y < r1; ++y) memcpy(&mask1_[(size_t)(y + tl1.y - utly) * uw + (tl1.x - utlx)], mask1 + (size_t)y * step1, (size_t)c1);
         for (int y = 0; y < r2; ++y) memcpy(&mask2_[(size_t)(y + tl2.y - utly) * uw + (tl2.x - utlx)], mask2 + (size_t)y * step2, (size_t)c2);
-        contour_mask(mask1_, contour1mask_);
-        contour_mask(mask2_, contour2mask_);
+        const bool tm = getenv("ISX_SEAMFIND_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
+        double t1 = now();
         find_components();
+        double t2 = now();
         find_edges();
-        return resolve_conflicts(image1, image2, tl1, tl2, mask1, step1, r1, c1, mask2, step2, r2, c2);
+        double t3 = now();
+        int rc = resolve_conflicts(image1, image2, tl1, tl2, mask1, step1, r1, c1, mask2, step2, r2, c2);
+        if (tm) fprintf(stderr, "seamfind: (contour masks on demand) %.1f ms, components %.1f ms, edges %.1f ms, resolve %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
+        return rc;
     }
 };
 
