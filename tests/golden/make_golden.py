@@ -173,7 +173,11 @@ def ref_dpseam_artifact():
         y0 = y1 + dy
         if 0 <= y0 < m0.shape[0]:
             mk1[y1, :ow] = np.where((m0[y0, dx:] > 0) | (m1[y1, :ow] > 0), 255, 0)
-    np.savez_compressed(os.path.join(HERE, "ref_dpseam_artifact.npz"), strip0=np.ascontiguousarray(i0[:, dx:]), strip1=np.ascontiguousarray(i1[:, :ow]),
+    # the seam band of the demo's final result, pano.jpg (S:1283: FeatherBlender 0.1 on these very inputs, JPEG-compressed)
+    pano = np.array(Image.open(os.path.join(d, "pano.jpg")).convert("RGB"))[:, :, ::-1]
+    assert pano.shape[:2] == (1105, 1895)
+    zx0, zx1 = 880, 1010
+    np.savez_compressed(os.path.join(HERE, "ref_dpseam_artifact.npz"), pano_zone=np.ascontiguousarray(pano[:, zx0:zx1]), pano_zone_x=np.array([zx0, zx1]), strip0=np.ascontiguousarray(i0[:, dx:]), strip1=np.ascontiguousarray(i1[:, :ow]),
                         shape0=np.array(i0.shape), shape1=np.array(i1.shape), tl0=np.array([-543, -550]), tl1=np.array([-543 + dx, -550 + dy]),
                         mask_in0=np.packbits(mk0 > 0, axis=1), mask_in1=np.packbits(mk1 > 0, axis=1),
                         mask_out0=np.packbits(m0 > 0, axis=1), mask_out1=np.packbits(m1 > 0, axis=1))

@@ -283,3 +283,17 @@ def test_gain_apply(gpu, oracle, gain):
     gpu.gain_apply(pitched[:, :201], gain)
     out = pitched.cpu().numpy()
     assert np.array_equal(out[:, :201], oracle.gain_apply(m, gain)) and not out[:, 201:].any()
+
+
+def test_feather_stage_agrees_with_the_references_pano(gpu, oracle):
+    """The demo's final stage (S:1236-1283) through the HIP library on the reference's own artefacts: identical to the oracle's
+    result, and as close to the committed pano.jpg in the seam band as JPEG noise allows (see tests/test_ref_artifact.py)."""
+    import sys
+    sys.path.insert(0, HERE)
+    from test_ref_artifact import _demo_blend, _psnr_in_zone, dpseam_case
+    a = np.load(os.path.join(HERE, "golden", "ref_dpseam_artifact.npz"))
+    c = dpseam_case()
+    got = _demo_blend(lambda s: gpu.FeatherBlender(False, s), lambda m, kw, kh: gpu.dilate_and(m, kw, kh), None, c, 0.1, True)
+    ref = _demo_blend(lambda s: oracle.Feather(s), oracle.dilate_rect, None, c, 0.1, True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert _psnr_in_zone(got[0], got[1], a) > 42.0

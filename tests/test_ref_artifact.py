@@ -172,3 +172,37 @@ def test_oracle_reproduces_the_references_seam_masks():
     DpSeamFinder().find(c["images"], c["corners"], masks)
     assert np.array_equal(masks[0], c["masks_out"][0]) and np.array_equal(masks[1], c["masks_out"][1])
     assert (masks[0] != c["masks_in"][0]).sum() > 100000 and (masks[1] != c["masks_in"][1]).sum() > 50000      # it did cut both
+
+
+def _demo_blend(feather, dilate_rect, gain_unused, c, sharpness, dilate):
+    """S:1236-1283: FeatherBlender(sharpness), dilate(masks_seam, 20x20) & masks_warped, convertTo(CV_16S), feed, blend."""
+    sizes = [(im.shape[1], im.shape[0]) for im in c["images"]]
+    fb = feather(sharpness)
+    fb.prepare(c["corners"], sizes)
+    for img, ms, mw, tl in zip(c["images"], c["masks_out"], c["masks_in"], c["corners"]):
+        mk = (dilate_rect(ms, 20, 20) & mw) if dilate else ms
+        fb.feed(img.astype(np.int16), mk, tl)
+    res, rm = fb.blend()
+    return np.clip(np.asarray(res), 0, 255).astype(np.int32), np.asarray(rm)
+
+
+def _psnr_in_zone(res, rm, a):
+    x0, x1 = [int(v) for v in a["pano_zone_x"]]
+    err = (res[:, x0:x1] - a["pano_zone"].astype(np.int32)).astype(np.float64)
+    valid = rm[:, x0:x1] > 0
+    return 10 * np.log10(255.0 ** 2 / (err[valid] ** 2).mean())
+
+
+def test_feather_stage_agrees_with_the_references_pano(oracle):
+    """pano.jpg (S:1283) is the FeatherBlender(0.1) result of exactly the artefacts above.  It is JPEG-compressed, so the
+    comparison is a PSNR — but a discriminating one: in the 130-column band around the seam, where the output is all blend,
+    the oracle's stage (dilate 20x20 & mask, distance-transform weights with sharpness 0.1, normalise) is as close to the
+    JPEG as JPEG noise allows (> 42 dB, like the untouched areas), while leaving out the dilation or using OpenCV's
+    default sharpness 0.02 is off by 6-13 dB."""
+    a = np.load(os.path.join(HERE, "golden", "ref_dpseam_artifact.npz"))
+    c = dpseam_case()
+    feather = lambda s: oracle.Feather(s)
+    ref = _psnr_in_zone(*_demo_blend(feather, oracle.dilate_rect, None, c, 0.1, True), a)
+    no_dilate = _psnr_in_zone(*_demo_blend(feather, oracle.dilate_rect, None, c, 0.1, False), a)
+    soft = _psnr_in_zone(*_demo_blend(feather, oracle.dilate_rect, None, c, 0.02, True), a)
+    assert ref > 42.0 and no_dilate < ref - 8.0 and soft < ref - 4.0, (ref, no_dilate, soft)
