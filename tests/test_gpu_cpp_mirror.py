@@ -94,3 +94,27 @@ def test_cpp_mirror_default_demo_stage(gpu, oracle, tmp_path):
     assert np.array_equal(got, od)
     assert np.array_equal(gpu.imread(str(tmp_path / "pano.bmp")), np.clip(od, 0, 255).astype(np.uint8))
     assert np.array_equal(gpu.imread(str(tmp_path / "pano_mask.bmp"))[:, :, 0], om)
+
+
+def test_cpp_mirror_seam_demo_reproduces_the_references_bitmaps(gpu, oracle, tmp_path):
+    """tests/cpp/seam_demo.cpp = the second half of the reference's DP-seam demo main() (S:1173-1283) through
+    include/imagestitch.hpp, fed with the reference's own artefacts as .bmp files: the mask_seam[0].bmp / mask_seam[1].bmp it
+    writes are byte-for-byte the reference's committed ones, its panorama is the oracle's FeatherBlender result."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ref_artifact import _demo_blend, dpseam_case
+    exe = str(tmp_path / "seam_demo")
+    lib_dir = os.path.join(ROOT, "imagestitch_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "seam_demo.cpp"),
+                           "-o", exe, "-L", lib_dir, "-limagestitch_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    c = dpseam_case()
+    for k in range(2):
+        gpu.imwrite(str(tmp_path / ("images_warped[%d].bmp" % k)), c["images"][k].astype(np.uint8))
+        gpu.imwrite(str(tmp_path / ("mask_warped[%d].bmp" % k)), c["masks_in"][k])
+    out = subprocess.check_output([exe, str(tmp_path)] + [str(v) for p in c["corners"] for v in p], text=True)
+    for k in range(2):
+        assert np.array_equal(gpu.imread(str(tmp_path / ("mask_seam[%d].bmp" % k)))[:, :, 0], c["masks_out"][k])
+    res, _ = _demo_blend(lambda s: oracle.Feather(s), oracle.dilate_rect, None, c, 0.1, True)
+    r, cc = [int(v) for v in out.split("result")[1].split()[:2]]
+    assert (r, cc) == res.shape[:2]
+    assert np.array_equal(gpu.imread(str(tmp_path / "pano.bmp")), res.astype(np.uint8))
