@@ -237,6 +237,13 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
     hipStream_t st = (hipStream_t)hip_stream;
     // staging and scratch persist per host thread (grow-only, never freed: a finder calls this once per conflict)
     static thread_local MatStage* stages = new MatStage[3];
+    static thread_local DevBuf* scratch_p = new DevBuf();
+    static thread_local int scratch_device = -1;
+    if (scratch_device != device) {   // the buffers live on one device: a call for another one starts afresh
+        for (int i = 0; i < 3; ++i) stages[i].buf.release();
+        scratch_p->release();
+        scratch_device = device;
+    }
     MatStage &s1 = stages[0], &s2 = stages[1], &sl = stages[2];
     ISX_TRY(s1.use_in(image1, st, "seam_estimate: image1"));
     ISX_TRY(s2.use_in(image2, st, "seam_estimate: image2"));
@@ -247,7 +254,6 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
     g.labels = (const unsigned char*)sl.d.data; g.lstep = sl.d.step;
     g.uh = labels->rows; g.uw = labels->cols; g.label = label;
     g.rx = rx; g.ry = ry; g.rw = rw; g.rh = rh; g.dx1 = dx1; g.dy1 = dy1; g.dx2 = dx2; g.dy2 = dy2;
-    static thread_local DevBuf* scratch_p = new DevBuf();
     DevBuf& scratch = *scratch_p;
     const size_t cv_b = ((size_t)rh * (rw + 1) * 4 + 255) & ~(size_t)255, ch_b = ((size_t)(rh + 1) * rw * 4 + 255) & ~(size_t)255,
                  ct_b = ((size_t)rh * rw + 255) & ~(size_t)255;
