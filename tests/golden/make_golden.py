@@ -77,7 +77,8 @@ def ref_inputs():
     i0 = np.array(Image.open(os.path.join(d, "images_warped_f[0].bmp")).convert("RGB"))[:, :, ::-1]  # BGR as imread gives
     i1 = np.array(Image.open(os.path.join(d, "images_warped_f[1].bmp")).convert("RGB"))[:, :, ::-1]
     print("reference artefact shapes:", m0.shape, m1.shape, i0.shape, i1.shape)
-    # corners are not recorded by the reference; pano.jpg's union 1895 x 1105 implies dx = 799, dy = 3
+    # blend INPUTS only: any offset gives a valid pair of overlapping crops.  (The offset of the reference's own run is
+    # (799, -5): see ref_seam_artifact / ref_dpseam_artifact below.)
     dx, dy = 799, 3
     # crop a 448 x 320 window of each tile around the seam (panorama x in [760, 1208), y in [400, 720))
     px0, py0, cw, ch = 760, 400, 448, 320
