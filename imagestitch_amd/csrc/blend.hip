@@ -1,6 +1,6 @@
 // blend.hip — multi-band Laplacian blender for MI355X (gfx950): Gaussian/Laplacian pyramid build,
-// per-band weighted accumulation, normalise + collapse.  Replaces OpenCV 3.4.2
-// cv::detail::MultiBandBlender as the reference calls it (W:271-273,281,302,313; spec of the
+// per-band weighted accumulation, normalise + collapse — and the FeatherBlender.  Replaces OpenCV 3.4.2
+// cv::detail::MultiBandBlender / FeatherBlender as the reference calls them (W:271-281,302,313; spec of the
 // arithmetic: SURVEY.md §8(a) A9-A12).  HBM-bound stencil work: no MFMA, 16-byte pixel records,
 // coalesced row-major access, LDS tiles with halo, wavefront shuffles for the horizontal 5-tap.
 //
@@ -11,11 +11,18 @@
 // Level 0 of a fed tile is never materialised: the level-0 kernels read the caller's image + mask
 // through the copyMakeBorder index maps (BORDER_REFLECT image, BORDER_CONSTANT weight).
 //
-// Kernels (one launch per level):
-//   k_pyr_down  : G_{k+1} = pyrDown(G_k)           (image + weight in one pass)
-//   k_lap_acc   : dst_k[rc] += cast((G_k - pyrUp(G_{k+1})) * W_k), dstW_k[rc] += W_k
-//   k_top_acc   : dst_L[rc] += cast(G_L * W_L), dstW_L[rc] += W_L
-//   k_collapse  : out_{k-1} = sat(pyrUp(out_k) + norm(dst_{k-1})); last level writes the caller's mat
+// Kernels:
+//   eager cycle (OpenCV's contract, feed() consumes its inputs)
+//     k_pyr_down      : G_{k+1} = pyrDown(G_k)           (image + weight in one pass)
+//     k_lap_acc(_all) : dst_k[rc] += cast((G_k - pyrUp(G_{k+1})) * W_k), dstW_k[rc] += W_k   (all levels of a feed in one launch)
+//     k_top_acc       : dst_L[rc] += cast(G_L * W_L), dstW_L[rc] += W_L
+//     k_collapse      : out_{k-1} = sat(pyrUp(out_k) + norm(dst_{k-1})); last level writes the caller's mat
+//   deferred cycle (isx_blender_set_deferred_level0; the measured path)
+//     k_pyr_down_multi  : the Gaussian chains of all recorded tiles, one launch per level
+//     k_collapse_gather : one collapse step that gathers the tiles' Laplacians in registers (the destination pyramid
+//                         never exists); the first step also gathers the top level, the last writes the caller's mats
+//   FeatherBlender (W:278-281,302,313): k_dt_rows / k_dt_seg_min / k_dt_cols_weight (createWeightMap),
+//     k_feather_acc + k_feather_blend (eager), k_feather_gather (deferred)
 #include "isx_device.hpp"
 #include "isx_internal.hpp"
 

@@ -2,8 +2,8 @@
 // Replaces the reference's in-tree warper (W:30-161: mapForward, mapBackward, detectResultRoi,
 // setCameraParams, buildMaps, warp) and the cv::remap call it ends in (W:157; arithmetic spec:
 // SURVEY.md §8(a) A8).  buildMaps + remap are fused: the back-projection is evaluated per
-// destination pixel in registers and the maps are never written to HBM (isx_warper_build_maps
-// exists for API parity only).
+// destination pixel in registers and the maps are never written to HBM (isx_warper_build_maps +
+// isx_remap exist for callers that keep the maps of a fixed rig).
 //
 // Transcendentals: mapBackward's sinf/cosf depend only on the destination COLUMN (u) and, for the
 // spherical projector, on the destination ROW (v), so the host evaluates them once per column /
