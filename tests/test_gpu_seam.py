@@ -105,3 +105,22 @@ def test_dp_seam_find_reproduces_the_references_seam_masks(gpu):
     dm = [torch.from_numpy(m.copy()).cuda() for m in c["masks_in"]]          # device masks are edited in place too
     gpu.DpSeamFinder().find([torch.from_numpy(im).cuda() for im in c["images"]], c["corners"], dm)
     assert np.array_equal(dm[0].cpu().numpy(), c["masks_out"][0]) and np.array_equal(dm[1].cpu().numpy(), c["masks_out"][1])
+
+
+def test_dp_seam_find_trivial_cases_and_errors(gpu):
+    from seam_cases import make_find_case
+    images, corners, masks = make_find_case(3, 2)
+    far = [corners[0], (corners[0][0] + 5000, corners[0][1])]                       # no overlap: `return; // there are no conflicts` S:142-143
+    got = [m.copy() for m in masks]
+    gpu.DpSeamFinder().find(images, far, got)
+    assert all(np.array_equal(a, b) for a, b in zip(got, masks))
+    one = [masks[0].copy()]
+    gpu.DpSeamFinder().find(images[:1], corners[:1], one)                            # a single image has no pair
+    assert np.array_equal(one[0], masks[0])
+    assert gpu.DpSeamFinder().find([], [], []) == []                                 # S:95-96
+    with pytest.raises(gpu.IsxError) as e:
+        gpu.DpSeamFinder().find([images[0], images[1].astype(np.uint8)], corners, [m.copy() for m in masks])
+    assert e.value.code == 2                                                         # both images must have the same type (S:745-746)
+    with pytest.raises(gpu.IsxError) as e:
+        gpu.DpSeamFinder().find(images, corners, [masks[0].copy(), masks[1][:-1].copy()])
+    assert e.value.code == 7                                                         # CV_Assert(image.size() == mask.size()), S:133-134
