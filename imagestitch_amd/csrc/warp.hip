@@ -359,7 +359,8 @@ __device__ __forceinline__ void forward_proxy(const Proj& p, float x, float y, f
 // keys[0..3] = min d, min q, max d, max q (as fkey).  One block scans a band of ROI_ROWS rows, reduces
 // through shuffles + LDS and touches the four global keys only when it improves them (520 K contended
 // atomics cost 3 ms on this part; a few hundred cost nothing).
-constexpr int ROI_ROWS = 16;
+constexpr int ROI_ROWS = 128;    // rows per block of k_roi_scan (few long-lived waves: see DESIGN.md §6)
+constexpr int CAND_ROWS = 16;    // rows per block of k_roi_candidates
 __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsigned* keys) {
     __shared__ float red[4][4];
     float tl_u = 3.402823466e+38f, tl_v = 3.402823466e+38f, br_u = -3.402823466e+38f, br_v = -3.402823466e+38f;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsign
 __global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, float tol_d, float tol_q,
                                                         int* cand_xy, int cap, int* count) {
     const float dmin = fkey_inv(keys[0]), qmin = fkey_inv(keys[1]), dmax = fkey_inv(keys[2]), qmax = fkey_inv(keys[3]);
-    const int y0 = blockIdx.y * ROI_ROWS, y1 = min(y0 + ROI_ROWS, sh);
+    const int y0 = blockIdx.y * CAND_ROWS, y1 = min(y0 + CAND_ROWS, sh);
     for (int y = y0; y < y1; ++y)
         for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
             float d, q;
@@ -654,7 +655,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     const float qmin = fkey_inv(hk[1]), qmax = fkey_inv(hk[3]);
     const float tol_d = 7.62939453125e-06f;                                   // 2^-17 of a (-2, 2] range
     const float tol_q = 4e-6f * std::max(std::fabs(qmin), std::fabs(qmax)) + 1e-9f;
-    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, grid, dim3(256), 0, w->proj, sw, sh, keys, tol_d, tol_q, cand, CAND_CAP, count);
+    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(cdiv(sw, 256), cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, keys, tol_d, tol_q, cand, CAND_CAP, count);
     int n = 0;
     ISX_HIP(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, st));
     ISX_HIP(hipStreamSynchronize(st));
