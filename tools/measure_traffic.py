@@ -37,7 +37,7 @@ ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_roi_s
 
 def launch_name(kname, full):
     if kname == "k_collapse_gather":
-        return "collapse_gather_final" if re.search(r"k_collapse_gather<\d+, -?\d+, true>", full) else "collapse_gather"
+        return "collapse_gather_final" if re.search(r"k_collapse_gather<\d+, -?\d+, true", full) else "collapse_gather"
     if kname in ("k_pyr_down", "k_pyr_down_multi"):
         return "pyr_down" if re.search(r"<\d+, -1>", full) else "pyr_down_l0"
     if kname == "k_collapse":
