@@ -274,13 +274,21 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
             const unsigned s0 = o0[k] & 3, s1 = o1[k] & 3;
             const unsigned l0 = __builtin_amdgcn_alignbyte(v0[k].y, v0[k].x, s0), h0 = __builtin_amdgcn_alignbyte(v0[k].z, v0[k].y, s0);
             const unsigned l1 = __builtin_amdgcn_alignbyte(v1[k].y, v1[k].x, s1), h1 = __builtin_amdgcn_alignbyte(v1[k].z, v1[k].y, s1);
-            const unsigned fx = wq[k] & 255, fy = wq[k] >> 8;
-            unsigned w0 = __umul24(32 - fx, 32 - fy) << 5, w1 = __umul24(fx, 32 - fy) << 5, w2 = __umul24(32 - fx, fy) << 5, w3 = __umul24(fx, fy) << 5;
-            if (wq[k] == 0) { w0 = 32767; w3 = 1; }   // BilinearTab_i entry (0,0) after saturate_cast<short> + fix-up
-            // p00 = l0 bytes 0..2, p01 = l0 byte 3, h0 bytes 0..1 (same for row 1)
-            const unsigned c0 = fix15(l0 & 255, l0 >> 24, l1 & 255, l1 >> 24, w0, w1, w2, w3);
-            const unsigned c1 = fix15((l0 >> 8) & 255, h0 & 255, (l1 >> 8) & 255, h1 & 255, w0, w1, w2, w3);
-            const unsigned c2 = fix15((l0 >> 16) & 255, (h0 >> 8) & 255, (l1 >> 16) & 255, (h1 >> 8) & 255, w0, w1, w2, w3);
+            const unsigned fx = wq[k] & 255, fy = wq[k] >> 8, gx = 32u - fx;
+            // BilinearTab_i weights are 32 * wx * wy with wx in {32 - fx, fx}, wy in {32 - fy, fy} (entry (0,0) = {32767, 0, 0, 1}
+            // gives p00 like everything else here), so (sum + 2^14) >> 15 == (S + 512) >> 10 with S = SUM p * wx * wy evaluated
+            // separably in exact integers: the horizontal blends are byte dot products straight on the aligned windows
+            // (l = b0 g0 r0 b1, h = g1 r1 . .), one v_dot4_u32_u8 for blue, two chained ones for green and red
+            const unsigned wb = gx | (fx << 24), wgl = gx << 8, wgh = fx, wrl = gx << 16, wrh = fx << 8;
+            const unsigned t0b = __builtin_amdgcn_udot4(l0, wb, 0u, false), t1b = __builtin_amdgcn_udot4(l1, wb, 0u, false);
+            const unsigned t0g = __builtin_amdgcn_udot4(h0, wgh, __builtin_amdgcn_udot4(l0, wgl, 0u, false), false);
+            const unsigned t1g = __builtin_amdgcn_udot4(h1, wgh, __builtin_amdgcn_udot4(l1, wgl, 0u, false), false);
+            const unsigned t0r = __builtin_amdgcn_udot4(h0, wrh, __builtin_amdgcn_udot4(l0, wrl, 0u, false), false);
+            const unsigned t1r = __builtin_amdgcn_udot4(h1, wrh, __builtin_amdgcn_udot4(l1, wrl, 0u, false), false);
+            const unsigned gy = 32u - fy;
+            const unsigned c0 = (__umul24(t0b, gy) + __umul24(t1b, fy) + 512u) >> 10;
+            const unsigned c1 = (__umul24(t0g, gy) + __umul24(t1g, fy) + 512u) >> 10;
+            const unsigned c2 = (__umul24(t0r, gy) + __umul24(t1r, fy) + 512u) >> 10;
             px[k] = c0 | (c1 << 8) | (c2 << 16);   // each c <= 255: the weights sum to 2^15
         } else if (k < n) {
             px[k] = slow_bilinear_u8x3(base, step, img.rows, img.cols, mx[k], my[k]);
