@@ -264,10 +264,29 @@ def main():
     lib.isx_profile_enable(0)
     for p in pairs:
         p.check_plan()   # raises if any planned step saw a ROI that differs from the plan
+    split = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # outside the timed region ("report Mpix/s with and without the gather"): the same K steps
+        # without the all-gather, then K all-gathers alone, so that the scaling file shows which of the two bounds N > 1
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            for p in pairs:
+                p.replay() if args.graph else p.step()
+        if args.graph:
+            for p in pairs:
+                torch.cuda.current_stream().wait_stream(p.gstream)
+        fence()
+        dt_c = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mosaic.gather_mosaics(send[0], gather_buf)
+        fence()
+        dt_g = time.perf_counter() - t1
+        t = torch.tensor([dt, dt_c, dt_g], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_c, dt_g = (float(v) for v in t.tolist())
+        split = (dt_c, dt_g, int(send[0].numel()))
 
     if rank == 0:
         mpix_step = world * args.pairs * 2 * W * H / 1e6
@@ -295,6 +314,13 @@ def main():
             "roofline": roof,
             "kernels_ms_one_step": per_kernel,
         }
+        if split:
+            dt_c, dt_g, nsend = split
+            out["multi_gpu"] = {"without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),
+                                "gather_alone_ms": round(dt_g / args.steps * 1e3, 4), "send_bytes_per_rank": nsend,
+                                "gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1),
+                                "note": "value = steps with the gather of step i overlapped with step i+1; the two legs here are timed after it, "
+                                        "each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, F, args.bands, prec)
         print(json.dumps(out))
