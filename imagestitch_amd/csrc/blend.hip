@@ -198,8 +198,8 @@ __device__ __forceinline__ Px<M> load_any(const Src0& s0, const LevelBuf& L, int
 // (wave_shr:1 / wave_shl:1, plain VALU instructions) instead of __shfl_up/__shfl_down, which compile to
 // ds_bpermute_b32 and made the LDS pipe the bottleneck of k_pyr_down (12 per input row; PMC:
 // SQ_ACTIVE_INST_LDS ~ 85 % of the kernel).  Lanes 0 / 63 receive 0 (they are halo lanes, unused).
-__device__ __forceinline__ int dpp_from_lower_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
-__device__ __forceinline__ int dpp_from_upper_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+__device__ __forceinline__ int dpp_from_lower_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // wave_shr:1
+__device__ __forceinline__ int dpp_from_upper_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }   // wave_shl:1
 __device__ __forceinline__ float dpp_from_lower_lane(float v) { return __int_as_float(dpp_from_lower_lane(__float_as_int(v))); }
 __device__ __forceinline__ float dpp_from_upper_lane(float v) { return __int_as_float(dpp_from_upper_lane(__float_as_int(v))); }
 
