@@ -216,6 +216,13 @@ __device__ __forceinline__ Px<M> shfl_down1(const Px<M>& p) {   // lane i <- lan
     return r;
 }
 
+// LDS-DMA: 16 bytes per lane from each lane's own global address to lds_wave_base + lane * 16 (gfx950
+// global_load_lds_dwordx4; counted by vmcnt, the compiler drains it before the next barrier)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // the [1 4 6 4 1] tap in the association pyramids.cpp uses: c*6 + (l1 + r1)*4 + l2 + r2
 template <class T>
 __device__ __forceinline__ T tap5(T c, T l1, T r1, T l2, T r2) { return c * 6 + (l1 + r1) * 4 + l2 + r2; }
@@ -666,7 +673,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     // instead of one per source.  G = 2 (a pair of tiles = a single round) for the upper steps; the last step keeps
     // G = 1: its level-0 decode needs the registers (152 VGPRs = 3 waves per SIMD with G = 2, measured slower).
     constexpr int G = FINE0 ? 1 : 2;
-    __shared__ Px<M> ct[G + 1][UP_TY + 2][WAVE + 2];
+    // fp32 pyramids hold 16-byte records: their coarse tiles go from HBM to LDS by LDS-DMA (global_load_lds_dwordx4: lane i
+    // of a wave fills entry base + i, which is exactly the flat staging index below) - no staging registers, no ds_write
+    // pass.  The DMA lands asynchronously, so a buffer must not be re-staged while a slower wave still reads it: the tiles'
+    // buffers alternate between rounds (a wave that issues round r has passed the barrier of round r - 1, which every wave
+    // reaches only after its reads of round r - 2).
+    constexpr bool DMA = (M == M_F32) && !TOP;
+    constexpr int NB = DMA ? 2 * G + 1 : G + 1;     // the last buffer is out_k's
+    __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
     WT acc[2][2][3];
@@ -701,34 +715,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 }
             }
         }
-        Px<M> sv[G + 1][2];
+        const int b0 = DMA ? ((t0 / G) & 1) * G : 0;     // this round's tile buffers
+        if constexpr (DMA) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = threadIdx.x + 256 * it;
-            if (i < NCT) {
-                const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+            for (int it = 0; it < 2; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                if (i < NCT) {
+                    const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
 #pragma unroll
-                for (int s = 0; s < G; ++s)
-                    if (touch[s]) {
-                        const LevelBuf& c = ts.coarse[t0 + s];
-                        sv[s][it] = load_px<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
+                    for (int s = 0; s < G; ++s)
+                        if (touch[s]) {
+                            const LevelBuf& c = ts.coarse[t0 + s];
+                            const unsigned idx = __umul24((unsigned)up_row_map<M>(ly0[s] - 1 + ry, c.rows), (unsigned)c.cols) + (unsigned)min(max(lx0[s] - 1 + rx, 0), c.cols - 1);
+                            glds16((const float4*)c.img + idx, &ct[b0 + s][0][0] + (i - lane));
+                        }
+                    if (with_out) {
+                        const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
+                        glds16((const float4*)coarse_out.img + (__umul24((unsigned)gy, (unsigned)coarse_out.cols) + (unsigned)gx), &ct[NB - 1][0][0] + (i - lane));
                     }
-                if (with_out) {
-                    const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
-                    if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
-                    else sv[G][it] = load_px<M, true>(coarse_out, gx, gy);
                 }
             }
-        }
-        if (t0 > 0) __syncthreads();     // the previous round's readers are done with ct
+        } else {
+            Px<M> sv[G + 1][2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = threadIdx.x + 256 * it;
-            if (i < NCT) {
-                const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+            for (int it = 0; it < 2; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                if (i < NCT) {
+                    const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
 #pragma unroll
-                for (int s = 0; s < G; ++s) if (touch[s]) ct[s][ry][rx] = sv[s][it];
-                if (with_out) ct[G][ry][rx] = sv[G][it];
+                    for (int s = 0; s < G; ++s)
+                        if (touch[s]) {
+                            const LevelBuf& c = ts.coarse[t0 + s];
+                            sv[s][it] = load_px<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
+                        }
+                    if (with_out) {
+                        const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
+                        if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
+                        else sv[G][it] = load_px<M, true>(coarse_out, gx, gy);
+                    }
+                }
+            }
+            if (t0 > 0) __syncthreads();     // the previous round's readers are done with ct
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                if (i < NCT) {
+                    const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+#pragma unroll
+                    for (int s = 0; s < G; ++s) if (touch[s]) ct[s][ry][rx] = sv[s][it];
+                    if (with_out) ct[G][ry][rx] = sv[G][it];
+                }
             }
         }
         __syncthreads();
@@ -736,7 +772,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
         for (int s = 0; s < G; ++s) {
             if (!mine[s]) continue;
             const int t = t0 + s;
-            Up4<M> u = pyr_up_2x2<M>(ct[s], lane, wv, lx0[s] + lane, ts.coarse[t].cols);
+            Up4<M> u = pyr_up_2x2<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ts.coarse[t].cols);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -757,7 +793,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     }
     const int cx = cx0 + lane, cy = cy0 + wv;
     if (cx >= coarse_out.cols || cy >= coarse_out.rows) return;
-    Up4<M> u = pyr_up_2x2<M>(ct[G], lane, wv, cx, coarse_out.cols);
+    Up4<M> u = pyr_up_2x2<M>(ct[NB - 1], lane, wv, cx, coarse_out.cols);
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         const int fy = 2 * cy + dy;
