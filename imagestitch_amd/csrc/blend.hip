@@ -188,6 +188,48 @@ __device__ __forceinline__ void load_src0_pair(const Src0& s, int x, int y, Px<M
     b = load_src0<M, SK>(s, x + 1, y);
 }
 
+// The same pair in two steps, for kernels that want several rows' windows (and other loads) in flight before the first
+// one is decoded: src0_pair_issue only issues the two window loads (raw.fast says whether the fast path applies),
+// src0_pair_finish decodes them - or takes load_src0's path when it does not.
+struct RawPair { U3 v; U2 q; unsigned sh; bool fast; };   // sh = (io & 3) | (mo & 3) << 2
+
+template <int SK>
+__device__ __forceinline__ RawPair src0_pair_issue(const Src0& s, int x, int y) {
+    RawPair r;
+    r.v = U3{0u, 0u, 0u}; r.q = U2{0u, 0u}; r.sh = 0u; r.fast = false;
+    if constexpr (SK == SK_U8) {
+        const int yr = y - s.top, xr = x - s.left;
+        if ((unsigned)yr < (unsigned)s.rows && xr >= 0 && xr + 1 < s.cols) {
+            const unsigned io = __umul24((unsigned)yr, (unsigned)s.img_step) + __umul24((unsigned)xr, 3u) + s.imis;
+            const unsigned mo = __umul24((unsigned)yr, (unsigned)s.mask_step) + (unsigned)xr + s.mmis;
+            if ((io & ~3u) + 12u <= s.iend && (mo & ~3u) + 8u <= s.mend) {
+                r.v = *(const U3*)(s.img_al + (io & ~3u));
+                r.q = *(const U2*)(s.mask_al + (mo & ~3u));
+                r.sh = (io & 3u) | ((mo & 3u) << 2);
+                r.fast = true;
+            }
+        }
+    }
+    return r;
+}
+
+template <int M, int SK>
+__device__ __forceinline__ void src0_pair_finish(const Src0& s, int x, int y, const RawPair& r, Px<M>& a, Px<M>& b) {
+    if (r.fast) {
+        const unsigned lo = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh & 3u), hi = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh & 3u);
+        const unsigned mk = __builtin_amdgcn_alignbyte(r.q.y, r.q.x, r.sh >> 2);
+        const float inv255 = (float)(1. / 255.);
+        const int a0 = lo & 255, a1 = (lo >> 8) & 255, a2 = (lo >> 16) & 255, b0 = lo >> 24, b1 = hi & 255, b2 = (hi >> 8) & 255;
+        if constexpr (M == M_I16) { a.c0 = a0; a.c1 = a1; a.c2 = a2; b.c0 = b0; b.c1 = b1; b.c2 = b2; }
+        else { a.c0 = (float)a0; a.c1 = (float)a1; a.c2 = (float)a2; b.c0 = (float)b0; b.c1 = (float)b1; b.c2 = (float)b2; }
+        a.w = (float)(mk & 255) * inv255;
+        b.w = (float)((mk >> 8) & 255) * inv255;
+    } else {
+        a = load_src0<M, SK>(s, x, y);
+        b = load_src0<M, SK>(s, x + 1, y);
+    }
+}
+
 template <int M, int SK>
 __device__ __forceinline__ Px<M> load_any(const Src0& s0, const LevelBuf& L, int x, int y) {
     if constexpr (SK == SK_LEVEL) return load_px<M, false>(L, x, y);
@@ -693,29 +735,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     for (int t0 = 0; t0 < max(ts.n, 1); t0 += G) {
         const bool with_out = t0 + G >= ts.n;
         bool touch[G], mine[G];
-        int lx0[G], ly0[G];
+        int lx0[G], ly0[G], ccl[G], crw[G];
+        const void* cimg[G];
         Px<M> gg[G][2][2];
+        RawPair rw[FINE0 ? G : 1][2];     // FINE0: the level-0 windows, decoded after the barrier
+        // The order below is the order of the wave's latency chain (measured with s_memtime per phase: two thirds of a
+        // wave's life used to be spent getting its loads issued): 1. the round's tile descriptors, every scalar load
+        // up front in one batch (they used to be fetched one dependent s_load at a time, ten round trips per tile);
+        // 2. the coarse tiles' staging, in flight under 3. the fine pixels' loads, all rows' windows issued before any is
+        // decoded (level 0: decoded after the barrier, so that the round waits for memory once).
 #pragma unroll
         for (int s = 0; s < G; ++s) {
-            const int t = t0 + s;
-            touch[s] = false; mine[s] = false; lx0[s] = 0; ly0[s] = 0;
-            if (t < ts.n) {
+            const int t = min(t0 + s, ts.n - 1);
+            touch[s] = false; mine[s] = false; lx0[s] = 0; ly0[s] = 0; ccl[s] = 1; crw[s] = 1; cimg[s] = nullptr;
+            if (ts.n > 0) {
                 // block-uniform: does the block's fine region touch the tile's rectangle?
-                const int tx = ts.x_tl[t], ty = ts.y_tl[t];
-                touch[s] = !(2 * cx0 >= tx + ts.w[t] || 2 * cx0 + 2 * WAVE <= tx || 2 * cy0 >= ty + ts.h[t] || 2 * cy0 + 2 * UP_TY <= ty);
+                const int tx = ts.x_tl[t], ty = ts.y_tl[t], tw = ts.w[t], th = ts.h[t], ccols = ts.coarse[t].cols, crows = ts.coarse[t].rows;
+                cimg[s] = ts.coarse[t].img; ccl[s] = ccols; crw[s] = crows;
+                asm volatile("" ::"s"(tx), "s"(ty), "s"(tw), "s"(th), "s"(ccols), "s"(crows), "s"(cimg[s]));   // one batch of s_loads, one wait
+                touch[s] = (t0 + s < ts.n) & !((2 * cx0 >= tx + tw) | (2 * cx0 + 2 * WAVE <= tx) | (2 * cy0 >= ty + th) | (2 * cy0 + 2 * UP_TY <= ty));
                 lx0[s] = cx0 - (tx >> 1); ly0[s] = cy0 - (ty >> 1);      // block origin in the tile's coarse coordinates
                 const int lcx = lx0[s] + lane, lcy = ly0[s] + wv;
-                mine[s] = touch[s] && (unsigned)lcx < (unsigned)ts.coarse[t].cols && (unsigned)lcy < (unsigned)ts.coarse[t].rows;
-                if (mine[s]) {   // the thread's 2x2 fine pixels of this tile: issued before anything waits
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        if constexpr (FINE0) load_src0_pair<M, SK>(ts.s0[t], 2 * lcx, 2 * lcy + dy, gg[s][dy][0], gg[s][dy][1]);
-                        else { gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
-                    }
-                }
+                mine[s] = touch[s] & ((unsigned)lcx < (unsigned)ccols) & ((unsigned)lcy < (unsigned)crows);
             }
         }
         const int b0 = DMA ? ((t0 / G) & 1) * G : 0;     // this round's tile buffers
+        Px<M> sv[DMA ? 1 : G + 1][2];                    // staging registers of the non-DMA path
         if constexpr (DMA) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -725,9 +770,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
 #pragma unroll
                     for (int s = 0; s < G; ++s)
                         if (touch[s]) {
-                            const LevelBuf& c = ts.coarse[t0 + s];
-                            const unsigned idx = __umul24((unsigned)up_row_map<M>(ly0[s] - 1 + ry, c.rows), (unsigned)c.cols) + (unsigned)min(max(lx0[s] - 1 + rx, 0), c.cols - 1);
-                            glds16((const float4*)c.img + idx, &ct[b0 + s][0][0] + (i - lane));
+                            const unsigned idx = __umul24((unsigned)up_row_map<M>(ly0[s] - 1 + ry, crw[s]), (unsigned)ccl[s]) + (unsigned)min(max(lx0[s] - 1 + rx, 0), ccl[s] - 1);
+                            glds16((const float4*)cimg[s] + idx, &ct[b0 + s][0][0] + (i - lane));
                         }
                     if (with_out) {
                         const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
@@ -736,7 +780,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 }
             }
         } else {
-            Px<M> sv[G + 1][2];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int i = threadIdx.x + 256 * it;
@@ -755,6 +798,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int s = 0; s < G; ++s)
+            if (mine[s]) {   // the thread's 2x2 fine pixels of this tile
+                const int t = t0 + s, lcx = lx0[s] + lane, lcy = ly0[s] + wv;
+                Src0 s0;
+                if constexpr (FINE0) {
+                    s0 = ts.s0[t];
+                    asm volatile("" ::"s"(s0.top), "s"(s0.left), "s"(s0.rows), "s"(s0.cols), "s"((unsigned)s0.img_step), "s"((unsigned)s0.mask_step),
+                                 "s"(s0.imis), "s"(s0.mmis), "s"(s0.iend), "s"(s0.mend), "s"(s0.img_al), "s"(s0.mask_al));   // the descriptor in one batch
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    if constexpr (FINE0) rw[s][dy] = src0_pair_issue<SK>(s0, 2 * lcx, 2 * lcy + dy);
+                    else { gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
+                }
+            }
+        if constexpr (!DMA) {
             if (t0 > 0) __syncthreads();     // the previous round's readers are done with ct
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -772,6 +833,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
         for (int s = 0; s < G; ++s) {
             if (!mine[s]) continue;
             const int t = t0 + s;
+            if constexpr (FINE0) {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+                    src0_pair_finish<M, SK>(ts.s0[t], 2 * (lx0[s] + lane), 2 * (ly0[s] + wv) + dy, rw[s][dy], gg[s][dy][0], gg[s][dy][1]);
+            }
             Up4<M> u = pyr_up_2x2<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ts.coarse[t].cols);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
