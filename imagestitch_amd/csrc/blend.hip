@@ -295,15 +295,18 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
     const int cA = reflect101(2 * ox, sw), cB = reflect101(2 * ox + 1, sw);
+    // Level 0: every row's two windows are issued before the first one is decoded (RawPair) - decoding inside the
+    // loading loop made each of the wave's rows wait for its own loads, five memory latencies in a row.
     Px<M> A[PD_RPW], B[PD_RPW];
+    RawPair rw[SK != SK_LEVEL ? PD_RPW : 1];
 #pragma unroll
     for (int i = 0; i < PD_RPW; ++i) {
         int r = wv + PD_WAVES * i;
         if (r < PD_NR) {
             int iy = reflect101(2 * oy0 - 2 + r, sh);
             if constexpr (SK != SK_LEVEL) {
-                if (cB == cA + 1) load_src0_pair<M, SK>(s0, cA, iy, A[i], B[i]);
-                else { A[i] = load_src0<M, SK>(s0, cA, iy); B[i] = load_src0<M, SK>(s0, cB, iy); }
+                if (cB == cA + 1) rw[i] = src0_pair_issue<SK>(s0, cA, iy);
+                else rw[i].fast = false;
             } else {
                 A[i] = load_px<M, false>(src, cA, iy);
                 B[i] = load_px<M, false>(src, cB, iy);
@@ -314,6 +317,11 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
     for (int i = 0; i < PD_RPW; ++i) {
         int r = wv + PD_WAVES * i;
         if (r < PD_NR) {
+            if constexpr (SK != SK_LEVEL) {
+                int iy = reflect101(2 * oy0 - 2 + r, sh);
+                if (rw[i].fast) src0_pair_finish<M, SK>(s0, cA, iy, rw[i], A[i], B[i]);
+                else { A[i] = load_src0<M, SK>(s0, cA, iy); B[i] = load_src0<M, SK>(s0, cB, iy); }
+            }
             Px<M> Am = shfl_up1<M>(A[i]), Bm = shfl_up1<M>(B[i]), Ap = shfl_down1<M>(A[i]);
             Px<M> h;
             h.c0 = tap5<WT>(A[i].c0, Bm.c0, B[i].c0, Am.c0, Ap.c0);
@@ -838,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 for (int dy = 0; dy < 2; ++dy)
                     src0_pair_finish<M, SK>(ts.s0[t], 2 * (lx0[s] + lane), 2 * (ly0[s] + wv) + dy, rw[s][dy], gg[s][dy][0], gg[s][dy][1]);
             }
-            Up4<M> u = pyr_up_2x2<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ts.coarse[t].cols);
+            Up4<M> u = pyr_up_2x2<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ccl[s]);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
