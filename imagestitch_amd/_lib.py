@@ -89,6 +89,7 @@ _SIGS = {
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],
     "isx_profile_filter": [C.c_char_p],
+    "isx_profile_sample": [C.c_int],
     "isx_profile_collect": [],
     "isx_profile_count": [_IP],
     "isx_profile_entry": [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],

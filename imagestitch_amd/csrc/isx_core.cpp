@@ -96,6 +96,8 @@ struct ProfEntry {
 static std::mutex g_pm;
 static bool g_prof = false;
 static std::string g_filter;   // empty = every kernel
+static int g_every = 1;        // bracket every g_every-th matching launch
+static long long g_seen = 0;
 static std::vector<ProfEntry> g_entries;
 static std::map<std::string, int> g_index;
 static std::vector<hipEvent_t> g_pool;
@@ -113,6 +115,7 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double alg_bytes) : stream
     if (!g_prof) return;
     std::lock_guard<std::mutex> lk(g_pm);
     if (!g_filter.empty() && g_filter != name) return;
+    if (g_every > 1 && (g_seen++ % g_every) != 0) return;
     auto it = g_index.find(name);
     if (it == g_index.end()) {
         g_entries.emplace_back();
@@ -153,6 +156,14 @@ int isx_profile_enable(int on) { g_prof = on != 0; return ISX_OK; }
 int isx_profile_filter(const char* kernel_name) {
     std::lock_guard<std::mutex> lk(g_pm);
     g_filter = kernel_name ? kernel_name : "";
+    return ISX_OK;
+}
+
+int isx_profile_sample(int every) {
+    ISX_CHECK_ARG(every >= 1, ISX_ERR_INVALID, "isx_profile_sample: every = %d", every);
+    std::lock_guard<std::mutex> lk(g_pm);
+    g_every = every;
+    g_seen = 0;
     return ISX_OK;
 }
 
