@@ -715,6 +715,20 @@ __device__ __forceinline__ Px<M> top_px(const TileSet& ts, int x, int y, int sh)
 // stored as level k-1 of the collapsed pyramid.
 // TOP: this is the first collapse step (k = L): out_L is not read from memory but gathered while its coarse tile is
 // staged (top_px), so the top level of the collapsed pyramid is never materialised and its launch disappears.
+// Optional instrumentation (-DISX_PHASE_TIMING, tools/phase_probe.sh): s_memtime stamps at the phase boundaries of the last
+// collapse step, summed per wave in registers and flushed with one set of atomics at exit (spread over 1024 slots) - the
+// measurement that showed a wave spending half its life getting its loads issued.  Compiles to nothing otherwise.
+#ifdef ISX_PHASE_TIMING
+__device__ unsigned long long g_phase[1024][12];
+#define PT_DECL unsigned long long ph__[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tprev__ = __builtin_amdgcn_s_memtime()
+#define PT(k) do { if (FINE0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); ph__[k] += now__ - tprev__; tprev__ = now__; } } while (0)
+#define PT_FLUSH do { if (FINE0 && (threadIdx.x & 63) == 0) { const int slot__ = (blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y * 37) & 1023; \
+        for (int k__ = 0; k__ < 11; ++k__) atomicAdd(&g_phase[slot__][k__], ph__[k__]); atomicAdd(&g_phase[slot__][11], 1ull); } } while (0)
+#else
+#define PT_DECL do { } while (0)
+#define PT(k) do { } while (0)
+#define PT_FLUSH do { } while (0)
+#endif
 template <int M, int SK, bool FINE0, bool TOP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     using WT = typename WorkT<M>::t;
@@ -733,6 +747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
+    PT_DECL;
     WT acc[2][2][3];
     float accw[2][2];
 #pragma unroll
@@ -767,6 +782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 mine[s] = touch[s] & ((unsigned)lcx < (unsigned)ccols) & ((unsigned)lcy < (unsigned)crows);
             }
         }
+        PT(t0 == 0 ? 0 : 4);    // descriptors
         const int b0 = DMA ? ((t0 / G) & 1) * G : 0;     // this round's tile buffers
         Px<M> sv[DMA ? 1 : G + 1][2];                    // staging registers of the non-DMA path
         if constexpr (DMA) {
@@ -807,6 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 }
             }
         }
+        PT(t0 == 0 ? 1 : 5);    // coarse tiles issued
 #pragma unroll
         for (int s = 0; s < G; ++s)
             if (mine[s]) {   // the thread's 2x2 fine pixels of this tile
@@ -836,7 +853,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 }
             }
         }
+        PT(t0 == 0 ? 2 : 6);    // fine pixels issued
         __syncthreads();
+        PT(t0 == 0 ? 3 : 7);    // memory + barrier wait
 #pragma unroll
         for (int s = 0; s < G; ++s) {
             if (!mine[s]) continue;
@@ -864,9 +883,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                     accw[dy][dx] = accw[dy][dx] + g.w;
                 }
         }
+        PT(t0 == 0 ? 8 : 9);    // decode + pyrUp + accumulate
     }
     const int cx = cx0 + lane, cy = cy0 + wv;
-    if (cx >= coarse_out.cols || cy >= coarse_out.rows) return;
+    if (cx >= coarse_out.cols || cy >= coarse_out.rows) { PT_FLUSH; return; }
     Up4<M> u = pyr_up_2x2<M>(ct[NB - 1], lane, wv, cx, coarse_out.cols);
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
@@ -887,6 +907,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
         if constexpr (FINE0) write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
         else { store_px<M, true>(fine_out, 2 * cx, fy, dd[0]); store_px<M, true>(fine_out, 2 * cx + 1, fy, dd[1]); }
     }
+    PT(10);                     // epilogue: normalise, pyrUp of out, convert, stores issued
+    PT_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1760,6 +1782,17 @@ int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level)
     b->mark_level = after_level;
     return ISX_OK;
 }
+
+#ifdef ISX_PHASE_TIMING
+// instrumented builds only (not declared in the header): sums of the 11 phases + the wave count; reset != 0 clears them
+int isx_debug_phase(unsigned long long* out12, int reset) {
+    static unsigned long long h[1024][12];
+    ISX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
+    for (int k = 0; k < 12; ++k) { out12[k] = 0; for (int i = 0; i < 1024; ++i) out12[k] += h[i][k]; }
+    if (reset) { memset(h, 0, sizeof(h)); ISX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h))); }
+    return ISX_OK;
+}
+#endif
 
 int isx_blender_set_sharpness(isx_blender* b, float sharpness) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_sharpness: null blender");

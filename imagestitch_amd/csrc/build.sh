@@ -10,7 +10,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function ${ISX_EXTRA_FLAGS:-}"
 mkdir -p build
 pids=()
 for f in isx_core.cpp imgio.cpp seamfind.cpp warp.hip blend.hip prep.hip linear_blend.hip seam.hip; do
