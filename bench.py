@@ -98,7 +98,22 @@ def cpu_baseline(width, height, focal, bands, precision):
             out = {"value": round(sum(rates), 3), "unit": "Mpix/s", "cores": cores, "kind": "port", "value_1core": round(rate1, 3),
                    "sample": "%d concurrent worker processes, one %dx%d pair each (oracle/oracle.c: single-threaded C, -O2, no FMA); "
                              "one worker alone: warp %.2fs + blend %.2fs" % (cores, width, height, one[0], one[1])}
+    out["host"] = host_cpu()
     return out
+
+
+def host_cpu():
+    """CPU model and logical CPU count of the box the baseline ran on (state nproc and the CPU model)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count() or 1}
 
 
 def main():
