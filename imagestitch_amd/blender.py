@@ -38,8 +38,10 @@ class MultiBandBlender:
         check(self._lib.isx_blender_set_stream(self._h, C.c_void_p(ptr or 0)))
 
     def set_deferred_level0(self, on=True):
-        """Opt-in (see include/imagestitch_hip.h): fed device mats must then stay valid until blend() returns."""
-        check(self._lib.isx_blender_set_deferred_level0(self._h, int(bool(on))))
+        """Opt-in (see include/imagestitch_hip.h): True / 1 = fed device mats must stay valid until blend() returns;
+        "copy" / 2 = feed() takes private copies of them (OpenCV's contract: feed consumes its inputs)."""
+        mode = 2 if on in ("copy", 2) else int(bool(on))
+        check(self._lib.isx_blender_set_deferred_level0(self._h, mode))
 
     def set_mark_event(self, event, after_level=0):
         """A deferred blend() records `event` (torch.cuda.Event / hipEvent_t / None) right after its pyrDown launch of

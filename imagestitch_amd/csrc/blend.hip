@@ -458,32 +458,53 @@ __device__ __forceinline__ void lap_acc_block(Px<M> (*ct)[WAVE + 2], const Src0&
                                               const LevelBuf& dst, int x_tl, int y_tl, const Cover& cov, int bx, int by, int ck = 0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = bx * WAVE, cy0 = by * UP_TY;
-    stage_coarse<M, false>(ct, coarse, cx0, cy0);
-    __syncthreads();
     const int cx = cx0 + lane, cy = cy0 + wv;
-    if (cx >= coarse.cols || cy >= coarse.rows) return;
-    Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse.cols);
+    const bool mine = cx < coarse.cols && cy < coarse.rows;
     // rectangle corners are even at every level below the top, so the 2x2 block is covered as a whole
-    const bool have = covered(cov, x_tl + 2 * cx, y_tl + 2 * cy, ck);
-    Px<M> gg[2][2];
+    const bool have = mine && covered(cov, x_tl + 2 * cx, y_tl + 2 * cy, ck);
+    // every load of the block is issued before its one barrier (the order used to be: stage the coarse tile, barrier,
+    // then each fine row loaded and decoded in turn, then the destination records read one by one inside the
+    // accumulate - four memory latencies in a row per wave): the thread's fine pixels (level 0: raw windows), its four
+    // destination records, then the coarse tile
+    Px<M> gg[2][2], dd[2][2];
+    RawPair rw[SK != SK_LEVEL ? 2 : 1];
+    if (mine) {
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-        if constexpr (SK != SK_LEVEL) load_src0_pair<M, SK>(s0, 2 * cx, 2 * cy + dy, gg[dy][0], gg[dy][1]);
-        else { gg[dy][0] = load_px<M, false>(fine, 2 * cx, 2 * cy + dy); gg[dy][1] = load_px<M, false>(fine, 2 * cx + 1, 2 * cy + dy); }
+        for (int dy = 0; dy < 2; ++dy) {
+            if constexpr (SK != SK_LEVEL) rw[dy] = src0_pair_issue<SK>(s0, 2 * cx, 2 * cy + dy);
+            else { gg[dy][0] = load_px<M, false>(fine, 2 * cx, 2 * cy + dy); gg[dy][1] = load_px<M, false>(fine, 2 * cx + 1, 2 * cy + dy); }
+        }
     }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            int fx = 2 * cx + dx, fy = 2 * cy + dy;
+            if (have) dd[dy][dx] = load_px<M, true>(dst, x_tl + 2 * cx + dx, y_tl + 2 * cy + dy);
+            else { dd[dy][dx].c0 = 0; dd[dy][dx].c1 = 0; dd[dy][dx].c2 = 0; dd[dy][dx].w = 0.f; }
+        }
+    stage_coarse<M, false>(ct, coarse, cx0, cy0);
+    __syncthreads();
+    if (!mine) return;
+    if constexpr (SK != SK_LEVEL) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) src0_pair_finish<M, SK>(s0, 2 * cx, 2 * cy + dy, rw[dy], gg[dy][0], gg[dy][1]);
+    }
+    Up4<M> u = pyr_up_2x2<M>(ct, lane, wv, cx, coarse.cols);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
             const Px<M> g = gg[dy][dx];
-            typename WorkT<M>::t l0, l1, l2;
-            if constexpr (M == M_I16) {  // cv::subtract saturates
-                l0 = sat_s16(g.c0 - u.v[dy][dx][0]); l1 = sat_s16(g.c1 - u.v[dy][dx][1]); l2 = sat_s16(g.c2 - u.v[dy][dx][2]);
+            Px<M> d = dd[dy][dx];
+            if constexpr (M == M_I16) {  // cv::subtract saturates; dst += static_cast<short>(lap * w), wrapping
+                d.c0 = wrap_s16(d.c0 + f2s_x86((float)sat_s16(g.c0 - u.v[dy][dx][0]) * g.w));
+                d.c1 = wrap_s16(d.c1 + f2s_x86((float)sat_s16(g.c1 - u.v[dy][dx][1]) * g.w));
+                d.c2 = wrap_s16(d.c2 + f2s_x86((float)sat_s16(g.c2 - u.v[dy][dx][2]) * g.w));
             } else {
-                l0 = g.c0 - u.v[dy][dx][0]; l1 = g.c1 - u.v[dy][dx][1]; l2 = g.c2 - u.v[dy][dx][2];
+                d.c0 = d.c0 + (g.c0 - u.v[dy][dx][0]) * g.w; d.c1 = d.c1 + (g.c1 - u.v[dy][dx][1]) * g.w; d.c2 = d.c2 + (g.c2 - u.v[dy][dx][2]) * g.w;
             }
-            accumulate<M>(dst, x_tl + fx, y_tl + fy, l0, l1, l2, g.w, have);
+            d.w = d.w + g.w;
+            store_px<M, true>(dst, x_tl + 2 * cx + dx, y_tl + 2 * cy + dy, d);
         }
 }
 
@@ -1180,6 +1201,8 @@ struct isx_blender {
     // deferred level 0: tiles recorded by feed(), consumed by blend()
     struct TileRec { Src0 s0; int sk; LevelBuf g[MAX_LEVELS]; int x_tl, y_tl, width, height; };
     bool deferred = false;          // requested by the caller
+    bool deferred_copy = false;     // ... with private copies of the fed device mats (OpenCV's contract kept)
+    std::vector<std::unique_ptr<DevBuf>> tile_copy_img, tile_copy_mask;
     bool level0_pending = false;    // recorded tiles have not been accumulated into dst[0] yet
     std::vector<TileRec> tiles;
     std::vector<std::unique_ptr<DevBuf>> tile_arenas;      // one per recorded tile (their pyramids must outlive feed)
@@ -1546,6 +1569,48 @@ int flush_feather(isx_blender* b) {
 }
 
 // FeatherBlender::feed (createWeightMap + the weighted accumulate loop)
+// deferred mode 2: a recorded tile must not reference the caller's device buffer once feed() has returned (OpenCV's
+// feed() consumes its inputs - the reference releases the fed mats before blend(), W:305-308): take a private copy, one
+// device-to-device pass on the blender's stream (4 B/px for a CV_8UC3 tile + its mask).  A copy kernel, not
+// hipMemcpy2DAsync: the runtime's pitched D2D copy moved the 59 MB of a 4K pair at 0.46 TB/s (127 us).
+template <class V>
+__global__ __launch_bounds__(256) void k_copy_rows(const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep, unsigned row_bytes, int rows) {
+    // units of sizeof(V) bytes; a row's last unit may overhang the row (never the source's pitch, checked by the host) except
+    // in the last row, whose overhanging unit is copied byte by byte
+    const unsigned u = blockIdx.x * 256 + threadIdx.x, off = u * (unsigned)sizeof(V);
+    const int y0 = blockIdx.y * 8;
+    if (off >= row_bytes) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int y = y0 + i;
+        if (y >= rows) break;
+        const unsigned char* sp = src + (size_t)y * sstep + off;
+        unsigned char* dp = dst + (size_t)y * dstep + off;
+        if (y < rows - 1 || off + (unsigned)sizeof(V) <= row_bytes) *(V*)dp = *(const V*)sp;
+        else for (unsigned b = 0; off + b < row_bytes; ++b) dp[b] = sp[b];
+    }
+}
+
+int private_copy(isx_mat& d, DevBuf& buf, hipStream_t st) {
+    const size_t row_bytes = (size_t)d.cols * mat_elem_size(d.type);
+    const size_t pitch = (row_bytes + 63) & ~(size_t)63;
+    ISX_TRY(buf.reserve(pitch * (size_t)d.rows + 64));
+    const unsigned char* src = (const unsigned char*)d.data;
+    unsigned char* dst = (unsigned char*)buf.p;
+    const double bytes = 2.0 * (double)row_bytes * d.rows;
+    const auto fits = [&](size_t unit) { return ((uintptr_t)src & (unit - 1)) == 0 && (d.step & (unit - 1)) == 0 && ((row_bytes + unit - 1) & ~(unit - 1)) <= d.step; };
+    const dim3 block(256);
+    if (fits(16)) {
+        ISX_LAUNCH("feed_copy", bytes, st, (k_copy_rows<uint4>), dim3(cdiv((int)cdiv((int)row_bytes, 16), 256), cdiv(d.rows, 8)), block, 0, src, d.step, dst, pitch, (unsigned)row_bytes, d.rows);
+    } else if (fits(4)) {
+        ISX_LAUNCH("feed_copy", bytes, st, (k_copy_rows<unsigned>), dim3(cdiv((int)cdiv((int)row_bytes, 4), 256), cdiv(d.rows, 8)), block, 0, src, d.step, dst, pitch, (unsigned)row_bytes, d.rows);
+    } else {
+        ISX_LAUNCH("feed_copy", bytes, st, (k_copy_rows<unsigned char>), dim3(cdiv((int)row_bytes, 256), cdiv(d.rows, 8)), block, 0, src, d.step, dst, pitch, (unsigned)row_bytes, d.rows);
+    }
+    d.data = buf.p; d.step = pitch;
+    return ISX_OK;
+}
+
 int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released the accumulators)");
     ISX_TRY(check_mat(img, "feed: img"));
@@ -1575,6 +1640,10 @@ int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int
     DevBuf& wbuf = can_defer ? *b->tile_arenas[slot] : b->feather_w;
     ISX_TRY(st_img.use_in(img, st, "feed: img"));
     ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
+    if (can_defer && b->deferred_copy && img->device >= 0) {   // the mask is consumed here (weight map); the image is read by blend()
+        if (b->tile_copy_img.size() <= slot) { b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf()); }
+        ISX_TRY(private_copy(st_img.d, *b->tile_copy_img[slot], st));
+    }
     const int rows = img->rows, cols = img->cols;
     const int nseg = cdiv(rows, DT_SEG);
     const int pitch = (cols + 3) & ~3;   // int4 stores of the row pass
@@ -1632,6 +1701,11 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     DevBuf& arena = can_defer ? *b->tile_arenas[slot] : b->tile_arena;
     ISX_TRY(st_img.use_in(img, b->stream, "feed: img"));
     ISX_TRY(st_mask.use_in(mask, b->stream, "feed: mask"));
+    if (can_defer && b->deferred_copy) {
+        if (b->tile_copy_img.size() <= slot) { b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf()); }
+        if (img->device >= 0) ISX_TRY(private_copy(st_img.d, *b->tile_copy_img[slot], b->stream));
+        if (mask->device >= 0) ISX_TRY(private_copy(st_mask.d, *b->tile_copy_mask[slot], b->stream));
+    }
     const isx_mat& di = st_img.d;
     const isx_mat& dm = st_mask.d;
 
@@ -1773,6 +1847,7 @@ int isx_blender_set_deferred_level0(isx_blender* b, int on) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_deferred_level0: null blender");
     ISX_CHECK_ARG(!b->prepared || b->fed.empty(), ISX_ERR_STATE, "isx_blender_set_deferred_level0: tiles have already been fed in this cycle");
     b->deferred = on != 0;
+    b->deferred_copy = on == 2;
     return ISX_OK;
 }
 

@@ -80,7 +80,7 @@ class PairStitcher:
         self.warper.set_deferred_verify(True)   # both ROI scans start after the last warp of a step (see step())
         self.blender = MultiBandBlender(False, num_bands, precision, device, stream)
         # the warped tiles and seam masks below live as long as this object: the deferred level-0 contract holds
-        self.blender.set_deferred_level0(deferred)
+        self.blender.set_deferred_level0(deferred)   # True: this object's buffers outlive blend(); "copy": feed() copies them
         # interleave: warp(t), feed(t), warp(t+1) ... with each tile's Gaussian chain on a side stream.  Measured
         # on MI355X: no gain (a kernel that fills every wave slot leaves nothing for a concurrent one), so off.
         self.interleave = interleave

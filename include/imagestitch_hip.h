@@ -191,7 +191,10 @@ int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask,
  * its inputs immediately — the reference clears the fed images before blend(), W:305-308 — so this
  * is not the default).  Host mats are staged in per-tile device buffers owned by the blender:
  * nothing changes for them.  At most 8 tiles of one type are deferred; beyond that, and when
- * isx_blender_debug_level is called, the recorded tiles are replayed through the eager path.       */
+ * isx_blender_debug_level is called, the recorded tiles are replayed through the eager path.
+ * on = 2 keeps OpenCV's contract: feed() takes a private copy of every DEVICE mat it records (one device-to-device
+ * pass on the handle's stream, 4 B/px for a CV_8UC3 tile + mask), so the caller may release or overwrite the fed
+ * mats as soon as feed() returns - the drop-in mode for callers written against cv::detail::Blender (W:286-308). */
 int isx_blender_set_deferred_level0(isx_blender* b, int on);
 /* In deferred mode: start each fed tile's Gaussian chain immediately on an internal side stream, so that
  * the (memory-bound) chain of tile t overlaps with whatever the caller enqueues next on the handle's

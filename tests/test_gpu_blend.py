@@ -359,3 +359,54 @@ def test_blend_u8_output_is_convertTo(gpu, oracle, prec):
         outs.append(mb.blend(out_u8=u8))
     assert np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(np.clip(outs[0][0], 0, 255).astype(np.uint8), outs[1][0])
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_deferred_copy_mode_keeps_opencvs_feed_contract(gpu, oracle, prec):
+    """isx_blender_set_deferred_level0(b, 2): feed() takes private copies of the device mats, so the caller may overwrite
+    them right after feed() (the reference releases the fed mats before blend(), W:305-308); results as the oracle's."""
+    import torch
+    rng = np.random.default_rng(91)
+    ntiles = 3
+    corners = [(37 * i - 5, (i % 2) * 11 - 4) for i in range(ntiles)]
+    sizes = [(66 + i * 7, 50 + i * 5) for i in range(ntiles)]
+    tiles = _tiles(rng, sizes)
+    ob = oracle.MultiBand(4, prec)
+    ob.prepare(corners, sizes)
+    for (img, mask), c in zip(tiles, corners):
+        ob.feed(img, mask, c)
+    od, om = ob.blend(False)
+    mb = gpu.MultiBandBlender(False, 4, prec)
+    mb.set_deferred_level0("copy")
+    for cycle in range(2):
+        mb.prepare(corners, sizes)
+        for (img, mask), c in zip(tiles, corners):
+            ti, tm = torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()
+            mb.feed(ti, tm, c)
+            ti.fill_(-12345 if ti.dtype == torch.int16 else 77); tm.zero_()      # the caller's buffers are reused at once
+            torch.cuda.synchronize()
+        d, m = mb.blend()
+        assert np.array_equal(m.cpu().numpy(), om), cycle
+        assert np.array_equal(d.cpu().numpy(), od), cycle
+
+
+def test_feather_deferred_copy_mode(gpu, oracle):
+    import torch
+    rng = np.random.default_rng(92)
+    corners = [(0, 0), (48, 3)]
+    sizes = [(80, 60), (75, 58)]
+    tiles = _tiles(rng, sizes)
+    res = []
+    for mode in (False, "copy"):
+        fb = gpu.FeatherBlender(False, 0.1)
+        fb.set_deferred_level0(mode)
+        fb.prepare(corners, sizes)
+        for (img, mask), c in zip(tiles, corners):
+            ti, tm = torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()
+            fb.feed(ti, tm, c)
+            if mode:
+                ti.fill_(321); tm.zero_()
+                torch.cuda.synchronize()
+        d, m = fb.blend()
+        res.append((d.cpu().numpy(), m.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

@@ -14,7 +14,8 @@ K, Rs = synth.camera_pair(W, H, F)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 imgs = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generator=g) for _ in range(2)]
-ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, _lib.PREC_F32, 0, None, "int16")
+prec = {"f32": _lib.PREC_F32, "i16": _lib.PREC_I16, "f16acc32": _lib.PREC_F16ACC32}[sys.argv[1] if len(sys.argv) > 1 else "f32"]
+ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, prec, 0, None, "int16")
 lib = _lib.load()
 if not hasattr(lib, "isx_debug_phase"):
     sys.exit("libimagestitch_hip.so was built without -DISX_PHASE_TIMING (tools/phase_probe.sh builds it)")
@@ -35,6 +36,6 @@ names = ["round 0: tile descriptors (scalar loads)", "round 0: coarse tiles issu
          "round 1: tile descriptors", "round 1: coarse tiles + out issued", "round 1: fine pixels issued", "round 1: memory + barrier wait",
          "round 0: decode + pyrUp + accumulate", "round 1: decode + pyrUp + accumulate", "epilogue: normalise, pyrUp(out), convert, stores issued"]
 tot = sum(v[:11])
-print("k_collapse_gather<F32, U8, FINE0> on a 4K pair: %.0f waves per launch, wave lifetime %.0f s_memtime ticks" % (waves / n, tot / waves))
+print("k_collapse_gather<%s, U8, FINE0> on a 4K pair:" % (sys.argv[1] if len(sys.argv) > 1 else "f32"), "%.0f waves per launch, wave lifetime %.0f s_memtime ticks" % (waves / n, tot / waves))
 for k in (0, 1, 2, 3, 8, 4, 5, 6, 7, 9, 10):
     print("  %-58s %8.1f ticks/wave  %5.1f %%" % (names[k], v[k] / waves, 100.0 * v[k] / tot))
