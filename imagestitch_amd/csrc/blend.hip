@@ -115,6 +115,19 @@ __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
     return p;
 }
 
+// the image channels only (pyrUp sources: the weight of a coarse level is never upsampled) - for I16 this skips the load
+// from the separate weight plane
+template <int M, bool DST>
+__device__ __forceinline__ Px<M> load_px_rgb(const LevelBuf& L, int x, int y) {
+    if constexpr (M == M_I16) {
+        const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
+        const short4 v = ((const short4*)L.img)[i];
+        Px<M> p;
+        p.c0 = v.x; p.c1 = v.y; p.c2 = v.z; p.w = 0.f;
+        return p;
+    } else return load_px<M, DST>(L, x, y);
+}
+
 template <int M, bool DST>
 __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const Px<M>& p) {
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
@@ -390,7 +403,7 @@ __device__ __forceinline__ void stage_coarse(Px<M> (*ct)[WAVE + 2], const LevelB
             normalise<M>(d);
             ct[ry][rx] = d;
         } else {
-            ct[ry][rx] = load_px<M, DST>(coarse, gx, gy);
+            ct[ry][rx] = load_px_rgb<M, DST>(coarse, gx, gy);
         }
     }
 }
@@ -834,12 +847,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                     for (int s = 0; s < G; ++s)
                         if (touch[s]) {
                             const LevelBuf& c = ts.coarse[t0 + s];
-                            sv[s][it] = load_px<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
+                            sv[s][it] = load_px_rgb<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
                         }
                     if (with_out) {
                         const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
                         if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
-                        else sv[G][it] = load_px<M, true>(coarse_out, gx, gy);
+                        else sv[G][it] = load_px_rgb<M, true>(coarse_out, gx, gy);
                     }
                 }
             }
