@@ -2,7 +2,7 @@
 """The reference demo's post-registration stage on one pair of images, every step on the GPU through imagestitch_amd
 (needs an MI355X):
 
-    python examples/stitch_pair.py [left.bmp right.bmp] [--focal F] [--yaw RAD] [--blend feather|multiband] [--out pano.bmp]
+    python examples/stitch_pair.py [left.bmp right.bmp] [--focal F] [--yaw RAD] [--blend feather|multiband] [--out pano.bmp | pano.jpg]
 
 Registration (features, matching, bundle adjustment — out of scope of this library) is replaced by a known rig: two cameras
 with focal length F rotated by -/+ yaw about the vertical axis.  Without input files a synthetic pair is generated.

@@ -24,8 +24,13 @@ def imread(path, device=None):
     return out
 
 
-def imwrite(path, img):
-    """cv::imwrite(path, img) for CV_8UC3 / CV_8UC1 host or device mats."""
+def imwrite(path, img, quality=95):
+    """cv::imwrite(path, img) for CV_8UC3 / CV_8UC1 host or device mats: .bmp, or .jpg / .jpeg (baseline JFIF; `quality` is
+    cv::IMWRITE_JPEG_QUALITY, OpenCV's default 95) - the format follows the extension, as in OpenCV."""
     m = as_mat(img)
-    check(_lib.load().isx_bmp_write(os.fsencode(path), C.byref(m)))
+    ext = os.path.splitext(os.fspath(path))[1].lower()
+    if ext in (".jpg", ".jpeg", ".jpe"):
+        check(_lib.load().isx_jpeg_write(os.fsencode(path), C.byref(m), int(quality)))
+    else:
+        check(_lib.load().isx_bmp_write(os.fsencode(path), C.byref(m)))
     return True

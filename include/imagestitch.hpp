@@ -202,7 +202,7 @@ private:
     int device_;
 };
 
-// cv::imread(path) / cv::imwrite(path, img) for .bmp files (W:166,315)
+// cv::imread(path) for .bmp files (W:166) / cv::imwrite(path, img) for .bmp and .jpg (W:155-156,315; "pano.jpg" S:1282)
 inline Mat imread(const char* path) {
     int rows = 0, cols = 0;
     check(isx_bmp_size(path, &rows, &cols));
@@ -211,7 +211,14 @@ inline Mat imread(const char* path) {
     check(isx_bmp_read(path, m.c()));
     return m;
 }
-inline void imwrite(const char* path, const Mat& img) { check(isx_bmp_write(path, img.c())); }
+// the format follows the extension, as in OpenCV: .jpg / .jpeg -> baseline JFIF at cv::IMWRITE_JPEG_QUALITY (default 95), else .bmp
+inline void imwrite(const char* path, const Mat& img, int jpeg_quality = 95) {
+    const char* dot = nullptr;
+    for (const char* q = path; *q; ++q) if (*q == '.') dot = q;
+    auto ieq = [](const char* a, const char* b) { for (; *a && *b; ++a, ++b) if ((*a | 32) != *b) return false; return *a == *b; };
+    if (dot && (ieq(dot, ".jpg") || ieq(dot, ".jpeg") || ieq(dot, ".jpe"))) check(isx_jpeg_write(path, img.c(), jpeg_quality));
+    else check(isx_bmp_write(path, img.c()));
+}
 
 // GainCompensator::apply: multiply(image, gain, image)  (W:241-244)
 inline void gainApply(Mat& image, double gain, int device = 0) { check(isx_gain_apply(image.c(), gain, device, nullptr)); }

@@ -254,13 +254,17 @@ int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_x
                      void* hip_stream);
 
 /* ---- on-disk format either side of the path: .bmp (W:166 imread, W:155-156,315 imwrite) ----------- */
-/* Uncompressed Windows bitmaps only (the reference's committed artefacts are BMPs; JPEG is not implemented).
+/* Reading: uncompressed Windows bitmaps only (the reference's inputs and committed artefacts are BMPs).
  * isx_bmp_read = cv::imread(path) with IMREAD_COLOR: `out` is a CV_8UC3 mat (host or device) of the size
  * isx_bmp_size reports; 8-bit paletted files are expanded through their palette.  isx_bmp_write = cv::imwrite
  * for CV_8UC3 (24-bit) and CV_8UC1 (8-bit, grey palette), host or device mats.                              */
 int isx_bmp_size(const char* path, int* rows, int* cols);
 int isx_bmp_read(const char* path, isx_mat* out);
 int isx_bmp_write(const char* path, const isx_mat* img);
+/* cv::imwrite("pano.jpg", result) (B:1132, S:1282): baseline sequential JFIF, 8-bit, the Annex K Huffman tables, 4:2:0
+ * chroma for CV_8UC3 (BGR), one component for CV_8UC1; quality 1..100 scales the Annex K quantisation tables as libjpeg does
+ * (OpenCV's default is 95).  Any JPEG decoder reads the file; it is not libjpeg's byte stream.  Host or device mats.   */
+int isx_jpeg_write(const char* path, const isx_mat* img, int quality);
 
 /* ---- the reference's in-tree single-band seam-ramp blend (B:141-717) --------------------- */
 /* images1/images2: CV_32FC3 warped tiles (B:143-145), tl1/tl2 their corners (B:148-149),

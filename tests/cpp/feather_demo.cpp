@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
                 result8.ptr<unsigned char>(y)[x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
             }
         imwrite((dir + "/pano.bmp").c_str(), result8);
+        imwrite((dir + "/pano.jpg").c_str(), result8);                                                         // S:1282 imwrite("pano.jpg", result)
         imwrite((dir + "/pano_mask.bmp").c_str(), result_mask);
         FILE* f = std::fopen((dir + "/pano_s16.raw").c_str(), "wb");
         for (int y = 0; y < result.rows(); ++y) std::fwrite(result.ptr<short>(y), 2, (size_t)3 * result.cols(), f);

@@ -94,6 +94,11 @@ def test_cpp_mirror_default_demo_stage(gpu, oracle, tmp_path):
     assert np.array_equal(got, od)
     assert np.array_equal(gpu.imread(str(tmp_path / "pano.bmp")), np.clip(od, 0, 255).astype(np.uint8))
     assert np.array_equal(gpu.imread(str(tmp_path / "pano_mask.bmp"))[:, :, 0], om)
+    Image = pytest.importorskip("PIL.Image")                                   # pano.jpg: read by a stock decoder, close to the bitmap
+    with Image.open(str(tmp_path / "pano.jpg")) as im:
+        jpg = np.asarray(im.convert("RGB"))[:, :, ::-1].astype(np.float64)
+    ref8 = np.clip(od, 0, 255).astype(np.float64)
+    assert jpg.shape == ref8.shape and 10.0 * np.log10(255.0 ** 2 / ((jpg - ref8) ** 2).mean()) > 35.0
 
 
 def test_cpp_mirror_seam_demo_reproduces_the_references_bitmaps(gpu, oracle, tmp_path):

@@ -100,3 +100,62 @@ def test_bmp_device_mats(isx, tmp_path):
     pitched[:, 3:56] = t
     isx.imwrite(p, pitched[:, 3:56])
     assert np.array_equal(isx.imread(p), a)
+
+
+def _psnr(a, b):
+    mse = ((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean()
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def _smooth(h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return np.stack([128 + 100 * np.sin(xx / 23.0) * np.cos(yy / 17.0), 128 + 90 * np.cos(xx / 31.0 + 1), 60 + xx * 0.5 + yy * 0.2], 2).clip(0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(203, 317), (16, 16), (1, 1), (7, 33), (64, 9)])
+def test_jpeg_write_is_read_by_a_stock_decoder(isx, tmp_path, size):
+    """imwrite("pano.jpg", result) (S:1282): baseline JFIF at OpenCV's defaults (quality 95, 4:2:0).  The file is decoded
+    with Pillow's libjpeg; its error against the source is that of libjpeg's own encoder at the same settings."""
+    Image = PIL
+    h, w = size
+    img = _smooth(h, w)
+    p = str(tmp_path / "t.jpg")
+    assert isx.imwrite(p, img)
+    with Image.open(p) as im:
+        assert im.format == "JPEG" and im.size == (w, h) and im.mode == "RGB"
+        dec = np.asarray(im.convert("RGB"))[:, :, ::-1]
+    ref = str(tmp_path / "ref.jpg")
+    Image.fromarray(np.ascontiguousarray(img[:, :, ::-1])).save(ref, quality=95, subsampling=2)
+    with Image.open(ref) as im:
+        dec_ref = np.asarray(im.convert("RGB"))[:, :, ::-1]
+    assert _psnr(dec, img) > min(40.0, _psnr(dec_ref, img) - 1.5), (_psnr(dec, img), _psnr(dec_ref, img))
+
+
+def test_jpeg_grey_quality_and_errors(isx, tmp_path):
+    Image = PIL
+    img = _smooth(120, 150)
+    g = np.ascontiguousarray(img[:, :, 0])
+    p = str(tmp_path / "g.jpeg")
+    isx.imwrite(p, g, quality=90)
+    with Image.open(p) as im:
+        assert im.mode == "L" and im.size == (150, 120)
+        assert _psnr(np.asarray(im), g) > 45.0
+    sizes, psnrs = [], []
+    for q in (10, 50, 95):
+        pq = str(tmp_path / ("q%d.jpg" % q))
+        isx.imwrite(pq, img, quality=q)
+        with Image.open(pq) as im:
+            psnrs.append(_psnr(np.asarray(im.convert("RGB"))[:, :, ::-1], img))
+        sizes.append(os.path.getsize(pq))
+    assert sizes[0] < sizes[1] < sizes[2] and psnrs[0] < psnrs[1] < psnrs[2]
+    # noise: every Huffman symbol class, long runs of 0xff bytes in the stream (byte stuffing)
+    noise = np.random.default_rng(5).integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    pn = str(tmp_path / "n.jpg")
+    isx.imwrite(pn, noise, quality=100)
+    with Image.open(pn) as im:
+        im.load()
+        assert im.size == (131, 97)
+    with pytest.raises(isx.IsxError):
+        isx.imwrite(str(tmp_path / "bad.jpg"), img, quality=0)
+    with pytest.raises(isx.IsxError):
+        isx.imwrite(str(tmp_path / "f.jpg"), img.astype(np.float32))
