@@ -111,7 +111,7 @@ static hipEvent_t get_event() {
     return e;
 }
 
-ProfScope::ProfScope(const char* name, hipStream_t s, double alg_bytes) : stream(s) {
+ProfScope::ProfScope(const char* name, hipStream_t, double alg_bytes) {
     if (!g_prof) return;
     std::lock_guard<std::mutex> lk(g_pm);
     if (!g_filter.empty() && g_filter != name) return;
@@ -126,14 +126,8 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double alg_bytes) : stream
     ProfEntry& e = g_entries[slot];
     e.launches++;
     e.bytes += alg_bytes;
-    hipEvent_t a = get_event(), b = get_event();
-    e.pending.emplace_back(a, b);
-    (void)hipEventRecord(a, s);
-}
-ProfScope::~ProfScope() {
-    if (slot < 0) return;
-    std::lock_guard<std::mutex> lk(g_pm);
-    (void)hipEventRecord(g_entries[slot].pending.back().second, stream);
+    start = get_event(); stop = get_event();
+    e.pending.emplace_back(start, stop);
 }
 
 }  // namespace isx

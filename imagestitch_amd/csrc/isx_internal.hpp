@@ -1,6 +1,7 @@
 // isx_internal.hpp — shared host-side plumbing of libimagestitch_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -70,20 +71,23 @@ struct MatStage {
 
 int check_mat(const isx_mat* m, const char* what);
 
-// ---- per-kernel profiler (hipEvents on the launch stream) ------------------------------------
+// ---- per-kernel profiler (HIP events on the launch stream) -------------------------------------
+// A bracketed launch goes through hipExtLaunchKernelGGL with a start and a stop event: the two events then carry the
+// kernel's own begin / end timestamps (what a kernel trace reports), not the times two separate hipEventRecord barrier
+// packets completed - those include the dispatch latency either side of the kernel and cost the stream ~13 us of gaps.
 struct ProfScope {
     ProfScope(const char* name, hipStream_t s, double alg_bytes);
-    ~ProfScope();
-    int slot = -1;
-    hipStream_t stream;
+    int slot = -1;                      // >= 0: this launch is bracketed with start / stop
+    hipEvent_t start = nullptr, stop = nullptr;
 };
 bool profiling_enabled();
 
-// Launch wrapper: records events when profiling, checks the launch error.
+// Launch wrapper: brackets the launch when profiling asks for it, checks the launch error.
 #define ISX_LAUNCH(name, alg_bytes, stream, kernel, grid, block, shmem, ...)                   \
     do {                                                                                       \
         ::isx::ProfScope ps__(name, stream, (double)(alg_bytes));                              \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                   \
+        if (ps__.slot >= 0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ps__.start, ps__.stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);              \
         hipError_t le__ = hipGetLastError();                                                   \
         if (le__ != hipSuccess)                                                                \
             return ::isx::fail(ISX_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(le__)); \
