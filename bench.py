@@ -263,8 +263,8 @@ def main():
     lib.isx_profile_reset()
     # timed region: only the dominant kernel is bracketed by HIP events (on its launch stream)
     lib.isx_profile_filter(dominant.encode() if dominant else None)
-    # ... on every SAMPLE-th launch: a hipEventRecord pair opens ~13 us of dispatch gaps around the kernel it brackets
-    # (rocprofv3 kernel trace), 4 % of this step
+    # ... on every SAMPLE-th launch (bracketing a launch is not free: its start / stop events ride on the kernel's own
+    # dispatch, hipExtLaunchKernelGGL, but still serialise it against its neighbours)
     SAMPLE = 4 if args.steps >= 8 else 1
     lib.isx_profile_sample(SAMPLE)
     if args.graph:

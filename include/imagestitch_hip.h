@@ -284,9 +284,9 @@ int isx_profile_reset(void);
 /* restrict the bracketing to one kernel name (NULL / "" = all): lets bench.py time the dominant
  * kernel inside the timed region without perturbing the other launches.                          */
 int isx_profile_filter(const char* kernel_name);
-/* bracket only every `every`-th launch that passes the filter (1 = all): a hipEventRecord pair costs the stream ~13 us
- * of dispatch gaps around the kernel it brackets, which a benchmark's timed region should pay on a sample, not on
- * every step.  launches / total_ms / alg_bytes then count the bracketed launches only.                          */
+/* bracket only every `every`-th launch that passes the filter (1 = all): a bracketed launch (start / stop events on the
+ * kernel's own dispatch) is serialised against its neighbours, which a benchmark's timed region should pay on a sample,
+ * not on every step.  launches / total_ms / alg_bytes then count the bracketed launches only.                          */
 int isx_profile_sample(int every);
 /* number of distinct kernel names seen; then name / launches / total milliseconds by index.
  * isx_profile_collect() synchronises the device and folds pending events into the totals.     */
