@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--roi-cache", action="store_true", help="with --sync-roi: isx_warper_set_roi_cache (the ROI of a fixed rig is computed once)")
     ap.add_argument("--sync-roi", action="store_true", help="return every warp's corner to the host (one stream sync per tile) instead of the planned, device-checked ROI")
     args = ap.parse_args()
     if args.cpu_worker:   # one worker of the cpu_baseline leg: no torch, no GPU
@@ -180,6 +181,9 @@ def main():
             imgs.append(torch.stack(chans, dim=2).contiguous())
         pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16"))
         del yy, xx
+    if args.roi_cache:
+        for p in pairs:
+            p.warper.set_roi_cache(True)
     bm = pairs[0].bytes_model()
 
     from imagestitch_amd import mosaic

@@ -533,6 +533,11 @@ struct isx_warper {
     std::vector<int> host_cand;
     float k[9], rinv[9];
     Proj proj;
+    // isx_warper_set_roi_cache: detectResultRoi is a pure function of (projection, source size); a fixed rig asks for the
+    // same few again and again.  Opt-in: remembered results are returned without the scan and its host round trip.
+    struct RoiEntry { Proj proj; int sw, sh; int roi[4]; float mm[4]; };
+    std::vector<RoiEntry> roi_cache;
+    bool roi_cache_on = false;
 };
 
 namespace {
@@ -650,6 +655,13 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
         return ISX_OK;
     }
+    if (!sync_free && w->roi_cache_on)
+        for (const auto& e : w->roi_cache)
+            if (e.sw == sw && e.sh == sh && memcmp(&e.proj, &w->proj, sizeof(Proj)) == 0) {
+                std::copy(e.roi, e.roi + 4, roi);
+                if (mm) std::copy(e.mm, e.mm + 4, mm);
+                return ISX_OK;
+            }
     if (sync_free) {
         isx_warper::Pending pd;
         pd.proj = w->proj; pd.sw = sw; pd.sh = sh;
@@ -691,6 +703,14 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     }
     if (mm) { mm[0] = tl_uf; mm[1] = tl_vf; mm[2] = br_uf; mm[3] = br_vf; }
     roi[0] = f2i_host(tl_uf); roi[1] = f2i_host(tl_vf); roi[2] = f2i_host(br_uf); roi[3] = f2i_host(br_vf);   // W:83-86
+    if (w->roi_cache_on) {
+        if (w->roi_cache.size() >= 16) w->roi_cache.erase(w->roi_cache.begin());
+        isx_warper::RoiEntry e;
+        e.proj = w->proj; e.sw = sw; e.sh = sh;
+        std::copy(roi, roi + 4, e.roi);
+        e.mm[0] = tl_uf; e.mm[1] = tl_vf; e.mm[2] = br_uf; e.mm[3] = br_vf;
+        w->roi_cache.push_back(e);
+    }
     return ISX_OK;
 }
 
@@ -863,6 +883,13 @@ int isx_warper_destroy(isx_warper* w) {
 int isx_warper_set_stream(isx_warper* w, void* hip_stream) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_stream: null warper");
     w->stream = (hipStream_t)hip_stream;
+    return ISX_OK;
+}
+
+int isx_warper_set_roi_cache(isx_warper* w, int on) {
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_roi_cache: null warper");
+    w->roi_cache_on = on != 0;
+    if (!on) w->roi_cache.clear();
     return ISX_OK;
 }
 

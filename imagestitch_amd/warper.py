@@ -127,6 +127,10 @@ class RotationWarper:
         check(self._lib.isx_warper_warp_with_mask_planned(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
                                                           roi, C.byref(mdi), C.byref(mdm)))
 
+    def set_roi_cache(self, on=True):
+        """Opt-in: remember detectResultRoi per (K, R, scale, source size); repeated calls skip the scan and its host sync."""
+        check(self._lib.isx_warper_set_roi_cache(self._h, int(bool(on))))
+
     def set_deferred_verify(self, on=True):
         check(self._lib.isx_warper_set_deferred_verify(self._h, int(bool(on))))
 

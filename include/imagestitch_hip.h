@@ -110,6 +110,11 @@ int isx_warper_camera(isx_warper* w, const float K[9], const float R[9],
  * minmax (optional, may be NULL) receives the four float extrema {min u, min v, max u, max v}. */
 int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9],
                    int roi[4], float minmax[4]);
+/* Opt-in: remember detectResultRoi's result per (K, R, scale, source size) - it is a pure function of them - so that a
+ * fixed rig's repeated isx_warper_warp / _roi / _build_maps calls skip the GPU scan and its host round trip (the corner
+ * must reach the host before the destination can be sized, W:148-150).  The spherical ROI (host code) is not cached.
+ * Off by default: every call then computes its ROI as the reference does.                                           */
+int isx_warper_set_roi_cache(isx_warper* w, int on);
 
 /* buildMaps (W:122-144): xmap,ymap are caller-allocated CV_32FC1 of
  * (roi[3]-roi[1]+1) rows x (roi[2]-roi[0]+1) cols (W:128-129).                               */

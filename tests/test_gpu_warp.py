@@ -202,3 +202,24 @@ def test_remap_ties_even_is_the_opencl_variant_and_matches_the_artifact(gpu):
     out = gpu.gain_apply(got, float(art["gain"]))
     d = out.astype(int) - crop
     assert (d != 0).mean() < 1e-3 and np.abs(d).max() <= 6
+
+
+def test_roi_cache_returns_the_same_roi_and_follows_the_camera(gpu, oracle):
+    """isx_warper_set_roi_cache: detectResultRoi remembered per (K, R, scale, size) - same corner / size / pixels as the
+    uncached call, and a changed rotation is a different key, not a stale hit."""
+    W, H, F = 640, 360, 500.0
+    K, Rs = synth.camera_pair(W, H, F)
+    img = synth.make_tile(H, W, 3)
+    w0 = gpu.CylindricalWarper().create(F)
+    w1 = gpu.CylindricalWarper().create(F)
+    w1.set_roi_cache(True)
+    for rep in range(3):
+        for R in (Rs[0], Rs[1], Rs[0]):
+            c0, d0 = w0.warp(img, K, R, gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
+            c1, d1 = w1.warp(img, K, R, gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
+            assert c0 == c1 and np.array_equal(d0, d1)
+            assert w1.warpRoi((W, H), K, R) == w0.warpRoi((W, H), K, R)
+    w1.set_roi_cache(False)
+    c1, d1 = w1.warp(img, K, Rs[1], gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
+    c0, d0 = w0.warp(img, K, Rs[1], gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
+    assert c0 == c1 and np.array_equal(d0, d1)
