@@ -7,7 +7,9 @@
 // Data layout in HBM (per pyramid level, row-major, pitch == cols):
 //   F32      : tile Gaussian levels and destination levels are float4 {b,g,r,weight}
 //   F16ACC32 : tile Gaussian levels are 4 x f16 {b,g,r,weight} (8 B); destination levels float4
-//   I16      : short4 {b,g,r,0} + a separate float plane for the weight (OpenCV's CV_16SC3 + CV_32F)
+//   I16      : destination levels short4 {b,g,r,0} + a separate float plane for the weight (OpenCV's CV_16SC3 + CV_32F);
+//              tile Gaussian levels {int b,g,r; float weight} (16 B, the register record: one load per pixel, and the
+//              coarse tiles can be staged by LDS-DMA like the fp32 ones; the values are still OpenCV's shorts)
 // Level 0 of a fed tile is never materialised: the level-0 kernels read the caller's image + mask
 // through the copyMakeBorder index maps (BORDER_REFLECT image, BORDER_CONSTANT weight).
 //
@@ -101,7 +103,10 @@ __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
     // levels hold < 2^31 records and fewer than 2^24 rows / columns (checked by prepare): 24-bit multiply = full-rate VALU
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
     Px<M> p;
-    if constexpr (M == M_I16) {
+    if constexpr (M == M_I16 && !DST) {   // tile Gaussian level: the register record itself, {int b, g, r; float w}
+        const int4 v = ((const int4*)L.img)[i];
+        p.c0 = v.x; p.c1 = v.y; p.c2 = v.z; p.w = __int_as_float(v.w);
+    } else if constexpr (M == M_I16) {
         short4 v = ((const short4*)L.img)[i];
         p.c0 = v.x; p.c1 = v.y; p.c2 = v.z;
         p.w = L.wgt[i];
@@ -115,11 +120,11 @@ __device__ __forceinline__ Px<M> load_px(const LevelBuf& L, int x, int y) {
     return p;
 }
 
-// the image channels only (pyrUp sources: the weight of a coarse level is never upsampled) - for I16 this skips the load
-// from the separate weight plane
+// the image channels only (pyrUp sources: the weight of a coarse level is never upsampled) - for the I16 destination
+// format this skips the load from the separate weight plane
 template <int M, bool DST>
 __device__ __forceinline__ Px<M> load_px_rgb(const LevelBuf& L, int x, int y) {
-    if constexpr (M == M_I16) {
+    if constexpr (M == M_I16 && DST) {
         const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
         const short4 v = ((const short4*)L.img)[i];
         Px<M> p;
@@ -131,7 +136,9 @@ __device__ __forceinline__ Px<M> load_px_rgb(const LevelBuf& L, int x, int y) {
 template <int M, bool DST>
 __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const Px<M>& p) {
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
-    if constexpr (M == M_I16) {
+    if constexpr (M == M_I16 && !DST) {
+        ((int4*)L.img)[i] = make_int4(p.c0, p.c1, p.c2, __float_as_int(p.w));
+    } else if constexpr (M == M_I16) {
         ((short4*)L.img)[i] = make_short4((short)p.c0, (short)p.c1, (short)p.c2, 0);
         L.wgt[i] = p.w;
     } else if constexpr (M == M_F16 && !DST) {
@@ -776,8 +783,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     // pass.  The DMA lands asynchronously, so a buffer must not be re-staged while a slower wave still reads it: the tiles'
     // buffers alternate between rounds (a wave that issues round r has passed the barrier of round r - 1, which every wave
     // reaches only after its reads of round r - 2).
-    constexpr bool DMA = (M == M_F32) && !TOP;
-    constexpr int NB = DMA ? 2 * G + 1 : G + 1;     // the last buffer is out_k's
+    // DMA_T: the tiles' Gaussian levels are 16-byte register records (fp32 and I16); DMA_O: so is out_k (fp32 only - the
+    // I16 destination format is OpenCV's short4 + weight plane, the F16 tile levels are 8-byte records: register staging).
+    constexpr bool DMA_T = (M == M_F32 || M == M_I16) && !TOP, DMA_O = (M == M_F32) && !TOP;
+    constexpr int NB = DMA_T ? 2 * G + 1 : G + 1;     // the last buffer is out_k's
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
@@ -817,43 +826,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
             }
         }
         PT(t0 == 0 ? 0 : 4);    // descriptors
-        const int b0 = DMA ? ((t0 / G) & 1) * G : 0;     // this round's tile buffers
-        Px<M> sv[DMA ? 1 : G + 1][2];                    // staging registers of the non-DMA path
-        if constexpr (DMA) {
+        const int b0 = DMA_T ? ((t0 / G) & 1) * G : 0;     // this round's tile buffers
+        Px<M> sv[G + 1][2];                                // staging registers of whatever is not staged by DMA
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int i = threadIdx.x + 256 * it;
-                if (i < NCT) {
-                    const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+        for (int it = 0; it < 2; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            if (i < NCT) {
+                const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
 #pragma unroll
-                    for (int s = 0; s < G; ++s)
-                        if (touch[s]) {
-                            const unsigned idx = __umul24((unsigned)up_row_map<M>(ly0[s] - 1 + ry, crw[s]), (unsigned)ccl[s]) + (unsigned)min(max(lx0[s] - 1 + rx, 0), ccl[s] - 1);
-                            glds16((const float4*)cimg[s] + idx, &ct[b0 + s][0][0] + (i - lane));
-                        }
-                    if (with_out) {
-                        const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
-                        glds16((const float4*)coarse_out.img + (__umul24((unsigned)gy, (unsigned)coarse_out.cols) + (unsigned)gx), &ct[NB - 1][0][0] + (i - lane));
+                for (int s = 0; s < G; ++s)
+                    if (touch[s]) {
+                        const int gx = min(max(lx0[s] - 1 + rx, 0), ccl[s] - 1), gy = up_row_map<M>(ly0[s] - 1 + ry, crw[s]);
+                        if constexpr (DMA_T) glds16((const float4*)cimg[s] + (__umul24((unsigned)gy, (unsigned)ccl[s]) + (unsigned)gx), &ct[b0 + s][0][0] + (i - lane));
+                        else sv[s][it] = load_px_rgb<M, false>(ts.coarse[t0 + s], gx, gy);
                     }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int i = threadIdx.x + 256 * it;
-                if (i < NCT) {
-                    const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
-#pragma unroll
-                    for (int s = 0; s < G; ++s)
-                        if (touch[s]) {
-                            const LevelBuf& c = ts.coarse[t0 + s];
-                            sv[s][it] = load_px_rgb<M, false>(c, min(max(lx0[s] - 1 + rx, 0), c.cols - 1), up_row_map<M>(ly0[s] - 1 + ry, c.rows));
-                        }
-                    if (with_out) {
-                        const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
-                        if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
-                        else sv[G][it] = load_px_rgb<M, true>(coarse_out, gx, gy);
-                    }
+                if (with_out) {
+                    const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
+                    if constexpr (DMA_O) glds16((const float4*)coarse_out.img + (__umul24((unsigned)gy, (unsigned)coarse_out.cols) + (unsigned)gx), &ct[NB - 1][0][0] + (i - lane));
+                    else if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
+                    else sv[G][it] = load_px_rgb<M, true>(coarse_out, gx, gy);
                 }
             }
         }
@@ -874,16 +865,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                     else { gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
                 }
             }
-        if constexpr (!DMA) {
-            if (t0 > 0) __syncthreads();     // the previous round's readers are done with ct
+        if constexpr (!DMA_T || !DMA_O) {
+            if constexpr (!DMA_T) { if (t0 > 0) __syncthreads(); }     // the previous round's readers are done with the (single) tile buffers
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int i = threadIdx.x + 256 * it;
                 if (i < NCT) {
                     const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+                    if constexpr (!DMA_T) {
 #pragma unroll
-                    for (int s = 0; s < G; ++s) if (touch[s]) ct[s][ry][rx] = sv[s][it];
-                    if (with_out) ct[G][ry][rx] = sv[G][it];
+                        for (int s = 0; s < G; ++s) if (touch[s]) ct[s][ry][rx] = sv[s][it];
+                    }
+                    if constexpr (!DMA_O) { if (with_out) ct[NB - 1][ry][rx] = sv[G][it]; }   // staged once, in the last round
                 }
             }
         }
@@ -1185,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_fill_uncovered(LevelBuf lv, Cover cov) 
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_LEVELS = 24;
 
-size_t g_px_bytes(int prec) { return prec == M_F32 ? 16 : 8; }           // tile Gaussian record
+size_t g_px_bytes(int prec) { return prec == M_F16 ? 8 : 16; }           // tile Gaussian record (I16: {int b, g, r; float w}, see the header comment)
 size_t d_px_bytes(int prec) { return prec == M_I16 ? 8 : 16; }           // destination record
 // algorithmic bytes (SURVEY §8(d) model): image part and weight part of a record
 double alg_g(int prec) { return prec == M_F32 ? 16.0 : (prec == M_I16 ? 10.0 : 8.0); }
@@ -1246,7 +1239,7 @@ int layout_levels(LevelBuf* lv, int L, int rows, int cols, int prec, bool is_dst
         lv[i].img = base ? base + off : nullptr;
         off += (ib + 255) & ~(size_t)255;
         lv[i].wgt = nullptr;
-        if (prec == M_I16) {
+        if (prec == M_I16 && is_dst) {
             lv[i].wgt = base ? (float*)(base + off) : nullptr;
             off += (n * 4 + 255) & ~(size_t)255;
         }
@@ -1761,7 +1754,6 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     {   // do not allocate level 0
         size_t n0 = (size_t)height * width;
         skip = (n0 * g_px_bytes(b->prec) + 255) & ~(size_t)255;
-        if (b->prec == M_I16) skip += (n0 * 4 + 255) & ~(size_t)255;
     }
     ISX_TRY(arena.reserve(total - skip + 256));
     layout_levels(g, L, height, width, b->prec, false, (char*)arena.p - skip, &total);
