@@ -194,7 +194,10 @@ def main():
     send, gather_buf, comm, ev_compute, ev_gather = None, None, None, None, None
     if use_dist:
         shapes = [tuple(p.out.shape) for p in pairs]
-        n_out = sum(int(np.prod(sh)) for sh in shapes)
+        # rows of the send block padded to 4 bytes (at most 3 bytes per row more on the wire): the last collapse step then
+        # stores its CV_8UC3 pixels as dwords instead of bytes
+        pitches = [(sh[1] * sh[2] + 3) // 4 * 4 for sh in shapes]
+        n_out = sum(sh[0] * pt for sh, pt in zip(shapes, pitches))
         send = [torch.empty((n_out,), dtype=torch.uint8, device=dev) for _ in range(2)]
         gather_buf = torch.empty((world * n_out,), dtype=torch.uint8, device=dev)
         comm = torch.cuda.Stream(device=dev)
@@ -203,9 +206,9 @@ def main():
         views = []
         for b in range(2):
             off, vs = 0, []
-            for sh in shapes:
-                n = int(np.prod(sh))
-                vs.append(send[b][off:off + n].view(sh)); off += n
+            for sh, pt in zip(shapes, pitches):
+                n = sh[0] * pt
+                vs.append(send[b][off:off + n].as_strided(sh, (pt, sh[2], 1))); off += n
             views.append(vs)
     if args.graph:
         if use_dist:
