@@ -410,3 +410,24 @@ def test_feather_deferred_copy_mode(gpu, oracle):
         d, m = fb.blend()
         res.append((d.cpu().numpy(), m.cpu().numpy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+def test_pair_stitcher_cycles_agree(gpu, prec):
+    """PairStitcher's three blender cycles - eager (OpenCV's contract), deferred with private copies (the same contract),
+    deferred on the caller's buffers - give identical mosaics (pitched device buffers: the 16-byte path of the copy)."""
+    import torch
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F = 1000, 600, 800.0
+    K, Rs = synth.camera_pair(W, H, F)
+    dev = torch.device("cuda:0")
+    imgs = [torch.from_numpy(synth.make_tile(H, W, 5 + i)).to(dev) for i in range(2)]
+    outs = []
+    for deferred in (False, "copy", True):
+        ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 4, prec, 0, None, "int16", deferred=deferred)
+        for _ in range(2):
+            out, om = ps.step()
+        ps.check_plan()
+        outs.append((out.cpu().numpy().copy(), om.cpu().numpy().copy()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
