@@ -783,9 +783,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     // pass.  The DMA lands asynchronously, so a buffer must not be re-staged while a slower wave still reads it: the tiles'
     // buffers alternate between rounds (a wave that issues round r has passed the barrier of round r - 1, which every wave
     // reaches only after its reads of round r - 2).
-    // DMA_T: the tiles' Gaussian levels are 16-byte register records (fp32 and I16); DMA_O: so is out_k (fp32 only - the
-    // I16 destination format is OpenCV's short4 + weight plane, the F16 tile levels are 8-byte records: register staging).
-    constexpr bool DMA_T = (M == M_F32 || M == M_I16) && !TOP, DMA_O = (M == M_F32) && !TOP;
+    // DMA_T: the tiles' Gaussian levels are 16-byte register records (fp32 and I16; the F16 tile levels are 8-byte records:
+    // register staging); DMA_O: so is out_k.
+    constexpr bool OUT_DST = M != M_I16;     // format of the out_k levels: the destination record, except I16 (see run_blend_deferred_t)
+    constexpr bool DMA_T = (M == M_F32 || M == M_I16) && !TOP, DMA_O = !TOP;   // out_k is a 16-byte record in every precision
     constexpr int NB = DMA_T ? 2 * G + 1 : G + 1;     // the last buffer is out_k's
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                     const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
                     if constexpr (DMA_O) glds16((const float4*)coarse_out.img + (__umul24((unsigned)gy, (unsigned)coarse_out.cols) + (unsigned)gx), &ct[NB - 1][0][0] + (i - lane));
                     else if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
-                    else sv[G][it] = load_px_rgb<M, true>(coarse_out, gx, gy);
+                    else sv[G][it] = load_px_rgb<M, OUT_DST>(coarse_out, gx, gy);
                 }
             }
         }
@@ -932,7 +933,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
             dd[dx] = d;
         }
         if constexpr (FINE0) write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
-        else { store_px<M, true>(fine_out, 2 * cx, fy, dd[0]); store_px<M, true>(fine_out, 2 * cx + 1, fy, dd[1]); }
+        else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
     }
     PT(10);                     // epilogue: normalise, pyrUp of out, convert, stores issued
     PT_FLUSH;
@@ -1198,6 +1199,7 @@ struct isx_blender {
     int fw = 0, fh = 0;                  // dst_roi_final_ size
     LevelBuf dst[MAX_LEVELS];
     DevBuf dst_arena, tile_arena;
+    DevBuf out_arena;                    // I16, deferred cycle: the collapsed levels out_k as 16-byte register records
     MatStage st_img, st_mask, st_out, st_outmask;
     std::vector<unsigned char> host_tmp;
     // level-0 rectangles (x, y, w, h in dst_roi_ coordinates) written by the feeds so far; `cleared`
@@ -1416,6 +1418,19 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     hipStream_t st = b->stream;
     const int L = b->num_bands, prec = M, n = (int)b->tiles.size();
     LevelBuf* d = b->dst;
+    // The collapsed levels out_k (k >= 1) only live between two steps of this chain.  The fp32 / fp16 destination levels
+    // are float4 records already; for I16 (OpenCV's short4 + weight plane) they go to a private arena in the tile-level
+    // format {int b, g, r; float w} instead, so that every precision stages out_k by LDS-DMA (OUT_DST in the kernel).
+    LevelBuf od[MAX_LEVELS];
+    if (M == M_I16) {
+        size_t total = 0;
+        layout_levels(od, L, d[0].rows, d[0].cols, prec, false, nullptr, &total);
+        const size_t skip = ((size_t)d[0].rows * d[0].cols * g_px_bytes(prec) + 255) & ~(size_t)255;   // level 0 goes to the caller's mat
+        ISX_TRY(b->out_arena.reserve(total - skip + 256));
+        layout_levels(od, L, d[0].rows, d[0].cols, prec, false, (char*)b->out_arena.p - skip, &total);
+        od[0].img = nullptr;
+        d = od;
+    }
     auto base = [&](int k_fine) {   // tile rectangles at level k_fine
         TileSet ts;
         memset(&ts, 0, sizeof(ts));
