@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cycle", default="deferred", choices=["deferred", "copy", "eager"],
+                    help="blender cycle: deferred on the stitcher's own buffers (default), deferred with private copies of the fed mats "
+                         "(OpenCV's feed contract, isx_blender_set_deferred_level0 = 2), or the eager destination-pyramid cycle")
     ap.add_argument("--roi-cache", action="store_true", help="with --sync-roi: isx_warper_set_roi_cache (the ROI of a fixed rig is computed once)")
     ap.add_argument("--sync-roi", action="store_true", help="return every warp's corner to the host (one stream sync per tile) instead of the planned, device-checked ROI")
     args = ap.parse_args()
@@ -179,7 +182,8 @@ def main():
                 noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
                 chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
             imgs.append(torch.stack(chans, dim=2).contiguous())
-        pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16"))
+        pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16",
+                                  deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle]))
         del yy, xx
     if args.roi_cache:
         for p in pairs:
@@ -334,7 +338,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d x (2 x %dx%d u8x3 tiles, cylindrical warp f=%g, %d-band %s blend) per GPU per step%s" % (
                 args.pairs, W, H, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
-                "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph),
+                "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
                                   "achieved_GBs": round(bm["total"] / (pair_ms * 1e-3) / 1e9, 1), "frac": round(bm["total"] / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
