@@ -70,10 +70,22 @@ struct Finder {
             const unsigned char* b = &mask2_[(size_t)y * uw];
             int x = 0;
             while (x < uw) {
-                const int cls = (a[x] && b[x]) ? INTERS : (a[x] ? FIRST : (b[x] ? SECOND : 0));
+                const bool ca = a[x] != 0, cb = b[x] != 0;
+                const int cls = (ca && cb) ? INTERS : (ca ? FIRST : (cb ? SECOND : 0));
                 int e = x + 1;
-                if (cls == 0) { while (e < uw && !a[e] && !b[e]) ++e; }
-                else { while (e < uw && ((a[e] && b[e]) ? INTERS : (a[e] ? FIRST : (b[e] ? SECOND : 0))) == cls) ++e; }
+                // the run goes on while (a != 0, b != 0) stays (ca, cb): eight pixels per step on the per-byte "non-zero" flags
+                const unsigned long long pa = ca ? 0x8080808080808080ull : 0ull, pb = cb ? 0x8080808080808080ull : 0ull;
+                while (e + 8 <= uw) {
+                    unsigned long long va, vb;
+                    memcpy(&va, a + e, 8); memcpy(&vb, b + e, 8);
+                    const unsigned long long na = (((va & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | va) & 0x8080808080808080ull;
+                    const unsigned long long nb = (((vb & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | vb) & 0x8080808080808080ull;
+                    const unsigned long long diff = (na ^ pa) | (nb ^ pb);
+                    if (diff) { e += __builtin_ctzll(diff) >> 3; goto run_done; }   // little-endian: the lowest set flag is the first differing pixel
+                    e += 8;
+                }
+                while (e < uw && (a[e] != 0) == ca && (b[e] != 0) == cb) ++e;
+            run_done:
                 if (cls) runs.push_back({x, e, cls, 0});
                 x = e;
             }
