@@ -446,17 +446,21 @@ struct Finder {
             edges.erase({c2, c1});
         }
         const int dx1 = utlx - tl1.x, dy1 = utly - tl1.y, dx2 = utlx - tl2.x, dy2 = utly - tl2.y;   // S:495-523
-        for (int y = 0; y < rows2; ++y)
-            for (int x = 0; x < cols2; ++x) {
-                const int l = L(y - dy2, x - dx2);
-                if (l > 0 && (states[l - 1] & FIRST) && mask1[(size_t)(y - dy2 + dy1) * step1 + (x - dx2 + dx1)]) mask2[(size_t)y * step2 + x] = 0;
+        // Both loops only touch pixels that lie inside BOTH tiles (the other tile's mask is read at the same union position),
+        // i.e. the intersection rectangle; per label one flag byte instead of a states[] lookup per pixel.  The second loop
+        // reads mask2 as the first one left it, as S:509-523 does.
+        std::vector<unsigned char> is_first(states.size() + 1, 0), is_second(states.size() + 1, 0);
+        for (size_t i = 0; i < states.size(); ++i) { is_first[i + 1] = (states[i] & FIRST) ? 1 : 0; is_second[i + 1] = (states[i] & SECOND) ? 1 : 0; }
+        const int ux0 = std::max(tl1.x, tl2.x) - utlx, ux1 = std::min(tl1.x + cols1, tl2.x + cols2) - utlx;   // intersection in union coordinates
+        const int uy0 = std::max(tl1.y, tl2.y) - utly, uy1 = std::min(tl1.y + rows1, tl2.y + rows2) - utly;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int uy = uy0; uy < uy1; ++uy) {
+                const int* lrow = &labels[(size_t)uy * uw];
+                unsigned char* m1 = mask1 + (size_t)(uy + dy1) * step1 + dx1;   // indexed by the union x
+                unsigned char* m2 = mask2 + (size_t)(uy + dy2) * step2 + dx2;
+                if (pass == 0) { for (int ux = ux0; ux < ux1; ++ux) if (is_first[lrow[ux]] & (m1[ux] != 0)) m2[ux] = 0; }
+                else { for (int ux = ux0; ux < ux1; ++ux) if (is_second[lrow[ux]] & (m2[ux] != 0)) m1[ux] = 0; }
             }
-        for (int y = 0; y < rows1; ++y)
-            for (int x = 0; x < cols1; ++x) {
-                const int l = L(y - dy1, x - dx1);
-                if (l > 0 && (states[l - 1] & SECOND) && mask2[(size_t)(y - dy1 + dy2) * step2 + (x - dx1 + dx2)]) mask1[(size_t)y * step1 + x] = 0;
-            }
-        (void)rows1; (void)cols1;
         return ISX_OK;
     }
 
