@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--focal", type=float, default=3000.0)
+    ap.add_argument("--yaw", type=float, default=0.36, help="the pair's cameras are rotated by -/+ yaw about the vertical axis")
+    ap.add_argument("--kind", default="cylindrical", choices=["cylindrical", "spherical"],
+                    help="spherical (BASELINE config 5) implies --sync-roi: its ROI is a host-side border scan, there is no planned variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
@@ -167,7 +170,9 @@ def main():
     prec = {"i16": _lib.PREC_I16, "f32": _lib.PREC_F32, "f16acc32": _lib.PREC_F16ACC32}[args.precision]
 
     W, H, F = args.width, args.height, args.focal
-    K, Rs = synth.camera_pair(W, H, F)
+    K, Rs = synth.camera_pair(W, H, F, yaw=args.yaw)
+    if args.kind == "spherical":
+        args.sync_roi = True
     gen = torch.Generator(device=dev)
     pairs = []
     for p in range(args.pairs):
@@ -182,7 +187,7 @@ def main():
                 noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
                 chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
             imgs.append(torch.stack(chans, dim=2).contiguous())
-        pairs.append(PairStitcher(imgs, K, Rs, F, "cylindrical", args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16",
+        pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16",
                                   deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle]))
         del yy, xx
     if args.roi_cache:
@@ -336,8 +341,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%d x (2 x %dx%d u8x3 tiles, cylindrical warp f=%g, %d-band %s blend) per GPU per step%s" % (
-                args.pairs, W, H, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
+            "config": {"workload": "%d x (2 x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
+                args.pairs, W, H, args.kind, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
                 "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
