@@ -518,7 +518,9 @@ int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_x
             mp[i] = hostm[i].data(); ms[i] = (size_t)masks[i].cols;
         } else { mp[i] = (unsigned char*)masks[i].data; ms[i] = masks[i].step; }
     }
-    Finder f;
+    // the union-sized work images (labels, the two masks: ~6 B per union pixel) keep their storage between calls of a thread:
+    // a fresh 70 MB of vectors per 4K pair spent a third of the call in page faults
+    static thread_local Finder f;
     f.device = device;
     f.stream = (hipStream_t)hip_stream;
     std::vector<std::pair<int, int>> pairs;   // S:98-113
