@@ -368,16 +368,19 @@ struct Finder {
         brs[c] = {INT_MIN, INT_MIN};
         contours[c].clear();
         if (x0 >= x1 || y0 >= y1) return;
+        // runs of label l in row y, clipped to the old rectangle widened by one pixel: everything below only asks whether a
+        // pixel of [x0, x1) has a same-label neighbour left / right / above / below, which that window decides
+        const int wx0 = std::max(x0 - 1, 0), wx1 = std::min(x1 + 1, uw);
         auto runs_of = [&](int y, std::vector<std::pair<int, int>>& out) {
             out.clear();
             if (y < 0 || y >= uh) return;
             const int* row = &labels[(size_t)y * uw];
-            int x = 0;
-            while (x < uw) {
-                while (x < uw && row[x] != l) ++x;
-                if (x >= uw) break;
+            int x = wx0;
+            while (x < wx1) {
+                while (x < wx1 && row[x] != l) ++x;
+                if (x >= wx1) break;
                 int e = x + 1;
-                while (e < uw && row[e] == l) ++e;
+                while (e < wx1 && row[e] == l) ++e;
                 out.push_back({x, e});
                 x = e;
             }
