@@ -41,6 +41,7 @@ struct Finder {
     std::vector<std::vector<Pt>> contours;
     std::set<std::pair<int, int>> edges;
 
+    std::vector<int> seam_mask_;
     int L(int y, int x) const { return labels[(size_t)y * uw + x]; }
     bool on_contour(int y, int x, int l) const {   // S:249-253
         return (x == 0 || L(y, x - 1) != l) || (x == uw - 1 || L(y, x + 1) != l) || (y == 0 || L(y - 1, x) != l) || (y == uh - 1 || L(y + 1, x) != l);
@@ -262,7 +263,8 @@ struct Finder {
     void update_labels_using_seam(int comp1, int comp2, const std::vector<Pt>& seam, bool horiz) {   // S:960-1093
         const Pt tl = tls[comp1], br = brs[comp1];
         const int h = br.y - tl.y, w = br.x - tl.x;
-        std::vector<int> mask((size_t)h * w, 0);
+        std::vector<int>& mask = seam_mask_;     // member: keeps its storage between calls
+        mask.assign((size_t)h * w, 0);
         auto M = [&](int y, int x) -> int& { return mask[(size_t)y * w + x]; };
         for (const Pt& p : contours[comp1]) M(p.y - tl.y, p.x - tl.x) = 255;
         for (const Pt& p : seam) M(p.y - tl.y, p.x - tl.x) = 255;
