@@ -5,11 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = every rank pushes `--pairs` (default 1) 4K pairs (BASELINE config 2: 2 x 3840x2160 u8x3
-tiles, cylindrical warp, 5-band fp32 blend) through warp -> prepare -> feed x2 -> blend with inputs
-resident in HBM; with N > 1 the blended mosaics are assembled on every rank with ONE all-gather
-(RCCL over xGMI).  Weak scaling: per-GPU work is fixed.  Mpix = source-tile pixels processed.
-Rank 0 prints one JSON line.
+A step = every rank pushes `--pairs` 4K pairs (BASELINE config 2: 2 x 3840x2160 u8x3 tiles, cylindrical warp,
+5-band fp32 blend) through warp -> prepare -> feed x2 -> blend with inputs resident in HBM.  --pairs defaults to 1
+with one GPU (config 2) and to 4 with N > 1 (config 4: 64 x 4K tiles on 8 GPUs = 8 tiles = 4 pairs per GPU); with
+N > 1 the blended mosaics are assembled on every rank with ONE all-gather (RCCL over xGMI).  Weak scaling: per-GPU
+work is fixed.  Mpix = source-tile pixels processed.  Rank 0 prints one JSON line.
+
+At N = 1 the line also carries `dropin`: the same workload as a caller written against cv::detail::RotationWarper /
+cv::detail::Blender gets it - every warp returns its corner to the host (W:160), feed() consumes its inputs (W:305-308) -
+with device mats and with host (cv::Mat-like, PCIe-inclusive) mats; timed after the headline region, never part of `value`.
 """
 import argparse
 import json
@@ -37,53 +41,65 @@ def measured_traffic(kernel, args):
         return None
 
 
-def cpu_pair_seconds(width, height, focal, bands, precision):
+def cpu_pair_seconds(width, height, focal, bands, precision, kind="cylindrical", tiles=2, yaw=0.36):
     """The CPU oracle (plain C, 1 thread, -O2, no FMA) on ONE pair of the workload: the reference's call
     sequence W:229,232 (two warps per tile), W:294, W:281,302,313.  Returns (warp seconds, blend seconds)."""
     import numpy as np
     from oracle import capi as O
     from imagestitch_amd import synth
-    K, Rs = synth.camera_pair(width, height, focal)
-    imgs = [synth.make_tile(height, width, i) for i in range(2)]
+    K, Rs = synth.camera_ring(width, height, focal, tiles, 2.0 * yaw)
+    imgs = [synth.make_tile(height, width, i) for i in range(tiles)]
+    pk = O.CYL if kind == "cylindrical" else O.SPH
     t0 = time.perf_counter()
     corners, warped, wmasks = [], [], []
-    for i in range(2):
-        c, wi, _ = O.warp_u8(O.CYL, focal, K, Rs[i], imgs[i], O.LINEAR, O.BORDER_REFLECT)
-        _, wm, _ = O.warp_u8(O.CYL, focal, K, Rs[i], np.full((height, width), 255, np.uint8), O.NEAREST, O.BORDER_CONSTANT)
+    for i in range(tiles):
+        c, wi, _ = O.warp_u8(pk, focal, K, Rs[i], imgs[i], O.LINEAR, O.BORDER_REFLECT)
+        _, wm, _ = O.warp_u8(pk, focal, K, Rs[i], np.full((height, width), 255, np.uint8), O.NEAREST, O.BORDER_CONSTANT)
         corners.append(c); warped.append(wi); wmasks.append(wm)
     t1 = time.perf_counter()
     seam = synth.seam_masks(corners, wmasks)   # seam finder stand-in: not timed
     t2 = time.perf_counter()
     mb = O.MultiBand(bands, precision)
     mb.prepare(corners, [(w.shape[1], w.shape[0]) for w in warped])
-    for i in range(2):
+    for i in range(tiles):
         mb.feed(warped[i].astype(np.int16), seam[i], corners[i])
     mb.blend(False)
     t3 = time.perf_counter()
     return t1 - t0, t3 - t2
 
 
-def cpu_baseline(width, height, focal, bands, precision):
+def cpu_baseline(width, height, focal, bands, precision, kind="cylindrical", tiles=2, yaw=0.36):
     """The oracle on the host cores of this box: one independent pair per worker process (the same partitioning as
     the GPU path, no shared state), as many workers as there are cores, bounded by memory (about 1 GB per 4K pair).
     value = sum of the workers' rates while they run concurrently; value_1core = one worker alone."""
     import subprocess
-    one = cpu_pair_seconds(width, height, focal, bands, precision)
-    px = 2.0 * width * height
+    # SURVEY §8(d): the CPU stand-in is the oracle built for THIS host (-O3 -march=native; still no FMA contraction, so the
+    # results stay those of the parity oracle).  Falls back to the portable -O2 build when gcc is missing.
+    flags = "-O2"
+    native = os.path.join(ROOT, "oracle", "liboracle_native.so")
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-o", native,
+                               os.path.join(ROOT, "oracle", "oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["ISX_ORACLE_LIB"] = native
+        flags = "-O3 -march=native"
+    except Exception:
+        pass
+    one = cpu_pair_seconds(width, height, focal, bands, precision, kind, tiles, yaw)
+    px = float(tiles) * width * height
     rate1 = px / (one[0] + one[1]) / 1e6
     cores = os.cpu_count() or 1
     try:
         import psutil
-        per_worker = 1.0e9 * (width * height) / (3840.0 * 2160.0) + 0.2e9
+        per_worker = 0.5e9 * tiles * (width * height) / (3840.0 * 2160.0) + 0.2e9
         cores = int(max(1, min(cores, psutil.virtual_memory().available * 0.25 // per_worker)))
     except Exception:
         cores = min(cores, 8)
     cores = min(cores, 64)
     out = {"value": round(rate1, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-           "sample": "1 pair of %dx%d tiles (oracle/oracle.c, warp %.2fs + blend %.2fs)" % (width, height, one[0], one[1])}
+           "sample": "1 mosaic of %d %dx%d tiles (oracle/oracle.c, %s, warp %.2fs + blend %.2fs)" % (tiles, width, height, flags, one[0], one[1])}
     if cores > 1:
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--width", str(width), "--height", str(height), "--focal", str(focal),
-               "--bands", str(bands), "--precision", {0: "i16", 1: "f32", 2: "f16acc32"}[precision]]
+               "--bands", str(bands), "--precision", {0: "i16", 1: "f32", 2: "f16acc32"}[precision], "--kind", kind, "--tiles", str(tiles), "--yaw", str(yaw)]
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for _ in range(cores)]
         rates = []
@@ -96,8 +112,8 @@ def cpu_baseline(width, height, focal, bands, precision):
                 pr.kill()
         if len(rates) == cores:
             out = {"value": round(sum(rates), 3), "unit": "Mpix/s", "cores": cores, "kind": "port", "value_1core": round(rate1, 3),
-                   "sample": "%d concurrent worker processes, one %dx%d pair each (oracle/oracle.c: single-threaded C, -O2, no FMA); "
-                             "one worker alone: warp %.2fs + blend %.2fs" % (cores, width, height, one[0], one[1])}
+                   "sample": "%d concurrent worker processes, one mosaic of %d %dx%d tiles each (oracle/oracle.c: single-threaded C, %s, "
+                             "no FMA contraction); one worker alone: warp %.2fs + blend %.2fs" % (cores, tiles, width, height, flags, one[0], one[1])}
     out["host"] = host_cpu()
     return out
 
@@ -115,13 +131,89 @@ def host_cpu():
         pass
     return {"cpu_model": model, "logical_cpus": os.cpu_count() or 1}
 
+def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
+    """The workload as a drop-in caller of the reference's interface gets it, timed AFTER the headline region:
+    every warp returns its corner to the host (W:160: one host round trip per tile, no ROI memo), feed() consumes its
+    inputs (W:305-308: isx_blender_set_deferred_level0 = 2 takes private copies of device mats; host mats are staged by
+    the library), blend() to CV_16SC3 + mask (W:313).  `device`: mats resident in HBM (zero copy).  `host`: every mat
+    is a host array as a cv::Mat is (pageable numpy memory; `host_pinned`: page-locked), i.e. PCIe-inclusive —
+    sources in, warped tiles + masks out, warped tiles + seam masks in again, mosaic + mask out."""
+    import numpy as np
+    import torch
+    import imagestitch_amd as I
+    from imagestitch_amd import synth
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F = args.width, args.height, args.focal
+    mpix = len(host_imgs) * W * H / 1e6
+    steps = max(args.steps, 5)
+    out = {"sequence": "per tile warp(image)+warp(mask) with the corner returned to the host (no ROI memo); prepare; feed x n "
+                       "(inputs consumed: private copies); blend -> CV_16SC3 + mask", "steps": steps}
+    for pname in ("f32", "i16"):
+        prec = prec_map[pname]
+        ps = PairStitcher([torch.from_numpy(h).to(dev) for h in host_imgs], K, Rs, F, args.kind, args.bands, prec, dev.index, None, "int16", deferred="copy")
+        for _ in range(2):
+            ps.step_sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ps.step_sync()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1)}
+        seam_host = [m.cpu().numpy() for m in ps.seam]
+        corners, sizes, shape_out = ps.corners, ps.sizes, tuple(ps.out.shape)
+        del ps
+        for mem in ("host", "host_pinned"):
+            def alloc(shape, dtype):
+                if mem == "host":
+                    return np.empty(shape, dtype)
+                return torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name)).pin_memory().numpy()
+            src = []
+            for h in host_imgs:
+                a = alloc(h.shape, np.uint8); a[...] = h; src.append(a)
+            seam = []
+            for m in seam_host:
+                a = alloc(m.shape, np.uint8); a[...] = m; seam.append(a)
+            wimg = [alloc((h, w, 3), np.uint8) for (w, h) in sizes]
+            wmsk = [alloc((h, w), np.uint8) for (w, h) in sizes]
+            res, res_mask = alloc(shape_out, np.int16), alloc(shape_out[:2], np.uint8)
+            warper = (I.CylindricalWarper if args.kind == "cylindrical" else I.SphericalWarper)(dev.index).create(F)
+            blender = I.MultiBandBlender(False, args.bands, prec, dev.index)
+            blender.set_deferred_level0(True)   # host mats: the library stages them in its own buffers, feed() consumes them
+
+            def host_step():
+                cs = []
+                for i in range(len(src)):
+                    c, _, _ = warper.warp_with_mask(src[i], K, Rs[i], dst_img=wimg[i], dst_mask=wmsk[i])
+                    cs.append(c)
+                blender.prepare(cs, sizes)
+                for i in range(len(src)):
+                    blender.feed_u8(wimg[i], seam[i], cs[i])
+                blender.blend(res, res_mask)
+            n_host = max(3, steps // 4)
+            host_step()
+            t0 = time.perf_counter()
+            for _ in range(n_host):
+                host_step()
+            dt = (time.perf_counter() - t0) / n_host
+            h2d = sum(a.nbytes for a in src) + sum(a.nbytes for a in wimg) + sum(a.nbytes for a in seam)
+            d2h = sum(a.nbytes for a in wimg) + sum(a.nbytes for a in wmsk) + res.nbytes + res_mask.nbytes
+            out["%s_%s" % (mem, pname)] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),
+                                           "d2h_MB": round(d2h / 1e6, 1), "pcie_GBs": round((h2d + d2h) / dt / 1e9, 1), "steps": n_host}
+            del warper, blender
+    torch.cuda.empty_cache()
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1, help="4K pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=None, help="4K pairs per GPU per step (default: 1 with one GPU = BASELINE config 2, "
+                                                           "4 with N > 1 = config 4's 8 tiles per GPU)")
+    ap.add_argument("--tiles", type=int, default=2, help="tiles per mosaic (2 = a pair; 8 = BASELINE config 5's row of 8, yaw step 2 * --yaw)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in (reference call sequence) legs after the timed region")
     ap.add_argument("--bands", type=int, default=5)
     ap.add_argument("--precision", default="f32", choices=["i16", "f32", "f16acc32"])
     ap.add_argument("--width", type=int, default=3840)
@@ -142,7 +234,7 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:   # one worker of the cpu_baseline leg: no torch, no GPU
         prec_w = {"i16": 0, "f32": 1, "f16acc32": 2}[args.precision]
-        tw, tb = cpu_pair_seconds(args.width, args.height, args.focal, args.bands, prec_w)
+        tw, tb = cpu_pair_seconds(args.width, args.height, args.focal, args.bands, prec_w, args.kind, args.tiles, args.yaw)
         print(json.dumps({"warp": tw, "blend": tb}))
         return
 
@@ -154,6 +246,8 @@ def main():
     from imagestitch_amd.pipeline import PairStitcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.pairs is None:
+        args.pairs = 1 if world == 1 else 4
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
@@ -170,7 +264,8 @@ def main():
     prec = {"i16": _lib.PREC_I16, "f32": _lib.PREC_F32, "f16acc32": _lib.PREC_F16ACC32}[args.precision]
 
     W, H, F = args.width, args.height, args.focal
-    K, Rs = synth.camera_pair(W, H, F, yaw=args.yaw)
+    NT = args.tiles
+    K, Rs = synth.camera_ring(W, H, F, NT, 2.0 * args.yaw)   # NT = 2: synth.camera_pair(W, H, F, yaw)
     if args.kind == "spherical":
         args.sync_roi = True
     gen = torch.Generator(device=dev)
@@ -180,13 +275,15 @@ def main():
         # same statistics as synth.make_tile (sinusoid + U{-32..31} noise), generated on the device
         yy, xx = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
         imgs = []
-        for t in range(2):
+        for t in range(NT):
             chans = []
             for c in range(3):
                 base = 128.0 + 64.0 * torch.sin(2 * np.pi * xx / 257.0 + c * 0.7 + t) * torch.cos(2 * np.pi * yy / 193.0 + c * 0.4)
                 noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
                 chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
             imgs.append(torch.stack(chans, dim=2).contiguous())
+        if p == 0 and rank == 0:
+            host_imgs0 = [im.cpu().numpy() for im in imgs]
         pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16",
                                   deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle]))
         del yy, xx
@@ -325,7 +422,7 @@ def main():
         split = (dt_c, dt_g, int(send[0].numel()))
 
     if rank == 0:
-        mpix_step = world * args.pairs * 2 * W * H / 1e6
+        mpix_step = world * args.pairs * NT * W * H / 1e6
         roof = None
         if dominant and ent.get(dominant, {}).get("launches", 0) > 0:
             e = ent[dominant]
@@ -341,8 +438,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%d x (2 x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
-                args.pairs, W, H, args.kind, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
+            "config": {"workload": "%s%d x (%d x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
+                ("%d x %dx%d tiles, %d tiles/GPU: " % (world * args.pairs * NT, W, H, args.pairs * NT)) if world > 1 else "",
+                args.pairs, NT, W, H, args.kind, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
+                "tiles_per_mosaic": NT,
                 "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
@@ -357,8 +456,12 @@ def main():
                                 "gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1),
                                 "note": "value = steps with the gather of step i overlapped with step i+1; the two legs here are timed after it, "
                                         "each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}
+        if world == 1 and not args.no_dropin:
+            for p in pairs:
+                del p
+            out["dropin"] = dropin_legs(args, K, Rs, host_imgs0, dev, {"f32": _lib.PREC_F32, "i16": _lib.PREC_I16})
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, F, args.bands, prec)
+            out["cpu_baseline"] = cpu_baseline(W, H, F, args.bands, prec, args.kind, NT, args.yaw)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -52,6 +52,8 @@ _SIGS = {
     "isx_warper_roi": [C.c_void_p, C.c_int, C.c_int, _F9, _F9, _IP, _F9],
     "isx_warper_build_maps": [C.c_void_p, C.c_int, C.c_int, _F9, _F9, _MP, _MP, _IP],
     "isx_warper_warp": [C.c_void_p, _MP, _F9, _F9, C.c_int, C.c_int, _MP, _IP],
+    "isx_warper_warp_roi": [C.c_void_p, _MP, _F9, _F9, C.c_int, C.c_int, _IP, _MP],
+    "isx_warper_warp_with_mask_roi": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],
     "isx_warper_warp_with_mask": [C.c_void_p, _MP, _MP, _F9, _F9, _MP, _MP, _IP],
     "isx_warper_warp_with_mask_planned": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],
     "isx_warper_plan_status": [C.c_void_p, _IP],
@@ -74,6 +76,7 @@ _SIGS = {
     "isx_seam_estimate": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _MP, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                           C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p],
     "isx_dp_seam_find": [C.c_int, _MP, C.POINTER(C.c_int), _MP, C.c_int, C.c_void_p],
+    "isx_dp_seam_release": [],
     "isx_bmp_size": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "isx_bmp_read": [C.c_char_p, _MP],
     "isx_bmp_write": [C.c_char_p, _MP],

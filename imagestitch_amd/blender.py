@@ -24,6 +24,9 @@ class MultiBandBlender:
         check(self._lib.isx_blender_create(BLEND_MULTI_BAND, int(num_bands), int(precision), int(device), C.byref(self._h)))
         self.precision = precision
         self._like = None
+        self._stream_obj = None
+        self._deferred_refs = False   # deferred mode 1: the C side reads the fed device mats in blend()
+        self._fed = []                # ... so they are kept alive here from feed() to blend() / the next prepare()
         if stream is not None:
             self.set_stream(stream)
 
@@ -33,8 +36,17 @@ class MultiBandBlender:
             self._lib.isx_blender_destroy(h)
             self._h = None
 
+    def _keep(self, img, mask):
+        """Deferred mode 1 records raw device pointers of the fed mats and reads them in blend(): a temporary such as
+        `torch.from_numpy(m).to(dev)` passed to feed() would otherwise be freed and its memory recycled by torch's caching
+        allocator before blend() runs.  (Mode 2 copies, the eager cycle consumes at once: nothing to keep.)"""
+        self._like = img
+        if self._deferred_refs:
+            self._fed.append((img, mask))
+
     def set_stream(self, stream):
         ptr = getattr(stream, "cuda_stream", stream)
+        self._stream_obj = stream if hasattr(stream, "cuda_stream") else None
         check(self._lib.isx_blender_set_stream(self._h, C.c_void_p(ptr or 0)))
 
     def set_deferred_level0(self, on=True):
@@ -42,6 +54,7 @@ class MultiBandBlender:
         "copy" / 2 = feed() takes private copies of them (OpenCV's contract: feed consumes its inputs)."""
         mode = 2 if on in ("copy", 2) else int(bool(on))
         check(self._lib.isx_blender_set_deferred_level0(self._h, mode))
+        self._deferred_refs = mode == 1
 
     def set_mark_event(self, event, after_level=0):
         """A deferred blend() records `event` (torch.cuda.Event / hipEvent_t / None) right after its pyrDown launch of
@@ -63,6 +76,7 @@ class MultiBandBlender:
 
     def prepare(self, corners, sizes=None):
         """prepare(corners, sizes) (W:281) or prepare((x, y, w, h)) = MultiBandBlender::prepare(Rect)."""
+        self._fed = []
         if sizes is None:
             x, y, w, h = [int(v) for v in corners]
             check(self._lib.isx_blender_prepare_roi(self._h, x, y, w, h))
@@ -76,13 +90,13 @@ class MultiBandBlender:
     def feed(self, img, mask, tl):
         """feed(img CV_16SC3 [or CV_32FC3 in the float precisions], mask CV_8U, tl) (W:302)."""
         mi, mm = as_mat(img), as_mat(mask)
-        self._like = img
+        self._keep(img, mask)
         check(self._lib.isx_blender_feed(self._h, C.byref(mi), C.byref(mm), int(tl[0]), int(tl[1])))
 
     def feed_u8(self, img, mask, tl):
         """convertTo(CV_16S) (W:294) fused into feed: img is CV_8UC3."""
         mi, mm = as_mat(img), as_mat(mask)
-        self._like = img
+        self._keep(img, mask)
         check(self._lib.isx_blender_feed_u8(self._h, C.byref(mi), C.byref(mm), int(tl[0]), int(tl[1])))
 
     def result_size(self):
@@ -108,7 +122,16 @@ class MultiBandBlender:
         if dst_mask is None:
             dst_mask = _empty_like_kind(like, (h, w), np.uint8)
         md, mm = as_mat(dst), as_mat(dst_mask)
-        check(self._lib.isx_blender_blend(self._h, C.byref(md), C.byref(mm)))
+        try:
+            check(self._lib.isx_blender_blend(self._h, C.byref(md), C.byref(mm)))
+        finally:
+            # blend() only ENQUEUES the kernels that read the fed mats; torch frees a tensor's block for reuse on the stream it
+            # was allocated on, which is safe as long as that is the blender's stream - record the use for other streams
+            for img, mask in self._fed:
+                for t in (img, mask):
+                    if _is_tensor(t) and t.is_cuda and self._stream_obj is not None and hasattr(t, "record_stream"):
+                        t.record_stream(self._stream_obj)
+            self._fed = []
         return dst, dst_mask
 
 
@@ -123,6 +146,9 @@ class FeatherBlender(MultiBandBlender):
         check(self._lib.isx_blender_create(_lib.BLEND_FEATHER, 0, PREC_I16, int(device), C.byref(self._h)))
         self.precision = PREC_I16
         self._like = None
+        self._stream_obj = None
+        self._deferred_refs = False
+        self._fed = []
         if stream is not None:
             self.set_stream(stream)
         self.setSharpness(sharpness)

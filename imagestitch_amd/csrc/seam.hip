@@ -200,7 +200,22 @@ __global__ __launch_bounds__(SEAM_NT) void k_seam_dp(const float4* ra, const flo
     if (threadIdx.x == 0) *found = reach[cur * n + (horiz ? dy : dx)] ? 1 : 0;   // S:918
 }
 
+struct SeamScratch { MatStage stages[3]; DevBuf scratch; int device = -1; };
+SeamScratch& seam_scratch() {
+    static thread_local SeamScratch* s = new SeamScratch();   // never destroyed at thread exit (the HIP runtime may be gone by then)
+    return *s;
+}
+
 }  // namespace
+
+namespace isx {
+void seam_scratch_release() {
+    SeamScratch& ss = seam_scratch();
+    for (int i = 0; i < 3; ++i) ss.stages[i].buf.release();
+    ss.scratch.release();
+    ss.device = -1;
+}
+}  // namespace isx
 
 extern "C" {
 
@@ -235,16 +250,14 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
 
     ISX_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
-    // staging and scratch persist per host thread (grow-only, never freed: a finder calls this once per conflict)
-    static thread_local MatStage* stages = new MatStage[3];
-    static thread_local DevBuf* scratch_p = new DevBuf();
-    static thread_local int scratch_device = -1;
-    if (scratch_device != device) {   // the buffers live on one device: a call for another one starts afresh
-        for (int i = 0; i < 3; ++i) stages[i].buf.release();
-        scratch_p->release();
-        scratch_device = device;
+    // staging and scratch persist per host thread (grow-only; isx_dp_seam_release frees them: a finder calls this once per conflict)
+    SeamScratch& ss = seam_scratch();
+    if (ss.device != device) {   // the buffers live on one device: a call for another one starts afresh
+        for (int i = 0; i < 3; ++i) ss.stages[i].buf.release();
+        ss.scratch.release();
+        ss.device = device;
     }
-    MatStage &s1 = stages[0], &s2 = stages[1], &sl = stages[2];
+    MatStage &s1 = ss.stages[0], &s2 = ss.stages[1], &sl = ss.stages[2];
     ISX_TRY(s1.use_in(image1, st, "seam_estimate: image1"));
     ISX_TRY(s2.use_in(image2, st, "seam_estimate: image2"));
     ISX_TRY(sl.use_in(labels, st, "seam_estimate: labels"));
@@ -254,7 +267,7 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
     g.labels = (const unsigned char*)sl.d.data; g.lstep = sl.d.step;
     g.uh = labels->rows; g.uw = labels->cols; g.label = label;
     g.rx = rx; g.ry = ry; g.rw = rw; g.rh = rh; g.dx1 = dx1; g.dy1 = dy1; g.dx2 = dx2; g.dy2 = dy2;
-    DevBuf& scratch = *scratch_p;
+    DevBuf& scratch = ss.scratch;
     const size_t cv_b = ((size_t)rh * (rw + 1) * 4 + 255) & ~(size_t)255, ch_b = ((size_t)(rh + 1) * rw * 4 + 255) & ~(size_t)255,
                  ct_b = ((size_t)rh * rw + 255) & ~(size_t)255;
     const int first = (horiz ? sx : sy) + 1, nsteps = std::max((horiz ? dx : dy) - first + 1, 0);

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <utility>
 #include <vector>
@@ -495,9 +496,31 @@ struct Finder {
     }
 };
 
+Finder& finder() {
+    static thread_local Finder* f = new Finder();
+    return *f;
+}
+struct FinderStages { std::vector<std::unique_ptr<MatStage>> img; int device = -1; };
+FinderStages& finder_stages() {
+    static thread_local FinderStages* s = new FinderStages();
+    return *s;
+}
+
 }  // namespace
 
+namespace isx { void seam_scratch_release(); }
+
 extern "C" {
+
+int isx_dp_seam_release(void) {
+    clear_error();
+    Finder& f = finder();
+    f = Finder();                       // labels, union masks, contours, the seam mask: back to empty vectors
+    finder_stages().img.clear();        // the staged images
+    finder_stages().device = -1;
+    isx::seam_scratch_release();        // cost maps, DP records and the staging of isx_seam_estimate
+    return ISX_OK;
+}
 
 int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_xy, isx_mat* masks, int device, void* hip_stream) {
     clear_error();
@@ -516,16 +539,34 @@ int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_x
     std::vector<std::vector<unsigned char>> hostm(num_images);
     std::vector<unsigned char*> mp(num_images);
     std::vector<size_t> ms(num_images);
+    bool any_dev = false;
     for (int i = 0; i < num_images; ++i) {
         if (masks[i].device >= 0) {
             hostm[i].resize((size_t)masks[i].rows * masks[i].cols);
-            ISX_HIP(hipMemcpy2D(hostm[i].data(), masks[i].cols, masks[i].data, masks[i].step, masks[i].cols, masks[i].rows, hipMemcpyDeviceToHost));
+            // on the caller's stream: the masks may still be in production there (a non-blocking stream is not ordered
+            // against the legacy null stream a plain hipMemcpy2D would use)
+            ISX_HIP(hipMemcpy2DAsync(hostm[i].data(), masks[i].cols, masks[i].data, masks[i].step, masks[i].cols, masks[i].rows, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
             mp[i] = hostm[i].data(); ms[i] = (size_t)masks[i].cols;
+            any_dev = true;
         } else { mp[i] = (unsigned char*)masks[i].data; ms[i] = masks[i].step; }
     }
+    if (any_dev) ISX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    // host images are staged in HBM once per call, not once per conflict (estimateSeam runs for every conflicting pair of
+    // components and reads both images each time: ~100 MB per CV_32FC3 4K image and upload otherwise)
+    std::vector<isx_mat> dimg(images, images + num_images);
+    FinderStages& fs = finder_stages();
+    if (fs.device != device) { fs.img.clear(); fs.device = device; }
+    if ((int)fs.img.size() < num_images) fs.img.resize(num_images);
+    for (int i = 0; i < num_images; ++i)
+        if (images[i].device < 0) {
+            if (!fs.img[i]) fs.img[i].reset(new MatStage());
+            ISX_TRY(fs.img[i]->use_in(&images[i], (hipStream_t)hip_stream, "dp_seam_find: image"));
+            dimg[i] = fs.img[i]->d; dimg[i].device = device;
+        }
+    images = dimg.data();
     // the union-sized work images (labels, the two masks: ~6 B per union pixel) keep their storage between calls of a thread:
-    // a fresh 70 MB of vectors per 4K pair spent a third of the call in page faults
-    static thread_local Finder f;
+    // a fresh 70 MB of vectors per 4K pair spent a third of the call in page faults (isx_dp_seam_release returns it)
+    Finder& f = finder();
     f.device = device;
     f.stream = (hipStream_t)hip_stream;
     std::vector<std::pair<int, int>> pairs;   // S:98-113
@@ -538,7 +579,8 @@ int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_x
     }
     for (int i = 0; i < num_images; ++i)
         if (masks[i].device >= 0)
-            ISX_HIP(hipMemcpy2D(masks[i].data, masks[i].step, hostm[i].data(), masks[i].cols, masks[i].cols, masks[i].rows, hipMemcpyHostToDevice));
+            ISX_HIP(hipMemcpy2DAsync(masks[i].data, masks[i].step, hostm[i].data(), masks[i].cols, masks[i].cols, masks[i].rows, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    if (any_dev) ISX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));   // hostm dies with this frame
     return ISX_OK;
 }
 

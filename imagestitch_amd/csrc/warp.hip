@@ -764,14 +764,14 @@ int check_roi_sane(const int roi[4]) {
 }
 
 int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, const float K[9], const float R[9], int interp, int border,
-                isx_mat* dst, isx_mat* dst_mask, int corner[2], const int* planned, bool fused) {
+                isx_mat* dst, isx_mat* dst_mask, int corner[2], const int* planned, bool fused, bool verify_plan = true) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "warp: null warper");
     ISX_TRY(check_mat(src, "warp: src"));
     ISX_TRY(check_mat(dst, "warp: dst"));
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(set_camera(w, K, R));
     int roi[4];
-    ISX_CHECK_ARG(!(planned && w->kind == ISX_WARP_SPHERICAL), ISX_ERR_UNSUPPORTED,
+    ISX_CHECK_ARG(!(planned && verify_plan && w->kind == ISX_WARP_SPHERICAL), ISX_ERR_UNSUPPORTED,
                   "planned warp: the spherical ROI is computed on the host; use isx_warper_warp_with_mask");
     if (planned) std::copy(planned, planned + 4, roi);   // the verifying scan is enqueued behind the warp kernel (below)
     else ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, false, nullptr));
@@ -826,7 +826,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         else { if (vec) ISX_WARP_FUSED(false, true); else ISX_WARP_FUSED(false, false); }
 #undef ISX_WARP_FUSED
         ISX_TRY(w->st_dmask.finish_out(st));
-        if (planned) {
+        if (planned && verify_plan) {
             int scratch[4];
             ISX_TRY(detect_roi(w, src->cols, src->rows, scratch, nullptr, true, planned));
         }
@@ -994,6 +994,19 @@ int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img, con
     clear_error();
     ISX_CHECK_ARG(planned_roi != nullptr, ISX_ERR_INVALID, "planned warp: null planned_roi");
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, planned_roi, true);
+}
+
+int isx_warper_warp_roi(isx_warper* w, const isx_mat* src, const float K[9], const float R[9], int interp, int border, const int roi[4], isx_mat* dst) {
+    clear_error();
+    ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "warp_roi: null roi");
+    return warp_common(w, src, nullptr, K, R, interp, border, dst, nullptr, nullptr, roi, false, false);
+}
+
+int isx_warper_warp_with_mask_roi(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9], const float R[9],
+                                  const int roi[4], isx_mat* dst_img, isx_mat* dst_mask) {
+    clear_error();
+    ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "warp_with_mask_roi: null roi");
+    return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, roi, true, false);
 }
 
 int isx_warper_set_deferred_verify(isx_warper* w, int on) {

@@ -1,5 +1,6 @@
 """cv::imread / cv::imwrite for the .bmp files either side of the hot path (W:166, W:155-156, W:315) — SURVEY §8(f) N4.
-Uncompressed Windows bitmaps only (the reference's committed artefacts); JPEG is not implemented."""
+Reading: uncompressed Windows bitmaps (the reference's inputs and committed artefacts).  Writing: .bmp and baseline
+JFIF .jpg (imwrite("pano.jpg", result), S:1282).  JPEG decoding is not implemented (the reference reads bitmaps only)."""
 import ctypes as C
 import os
 

@@ -1,5 +1,6 @@
-"""The hot path as the reference's main() drives it (W:223-233, 281, 294-302, 313), for one pair of
-tiles on one GPU: warp(image) + warp(mask) per tile -> prepare -> feed x2 -> blend.
+"""The hot path as the reference's main() drives it (W:223-233, 281, 294-302, 313), for the tiles of one
+mosaic on one GPU (a pair in BASELINE configs 1-4, a row of 8 in config 5): warp(image) + warp(mask) per
+tile -> prepare -> feed x n -> blend.
 
 PairStitcher owns the device buffers so that the steady state allocates nothing.  Seam masks (the
 output of the seam finder, which is out of scope: SURVEY §8(f) N1) are inputs: they are built
@@ -67,7 +68,8 @@ def model_bytes(src_px, warped_px, tile_base_px, mosaic_px, precision, num_bands
 
 
 class PairStitcher:
-    """One pair of tiles -> one blended mosaic, buffers resident in HBM (torch CUDA tensors)."""
+    """The n >= 2 tiles of one mosaic (normally a pair) -> one blended mosaic, buffers resident in HBM (torch CUDA
+    tensors).  At most 8 tiles stay on the deferred blender cycle (isx_blender_set_deferred_level0)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
                  device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1):
@@ -190,3 +192,6 @@ class PairStitcher:
         out = model_bytes(src_px, warped_px, [float(b) for b in base], float(mosaic), self.precision, self.L)
         out.update({"src_px": src_px, "warped_px": warped_px, "tile_base_px": [int(b) for b in base], "mosaic_px": int(mosaic)})
         return out
+
+
+MosaicStitcher = PairStitcher   # the same object under the name that fits n > 2 tiles (BASELINE config 5: a row of 8)

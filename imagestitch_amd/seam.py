@@ -39,3 +39,8 @@ class DpSeamFinder:
         ptr = getattr(self.stream, "cuda_stream", self.stream)
         check(_lib.load().isx_dp_seam_find(n, mats_i, c, mats_m, int(self.device), C.c_void_p(ptr or 0)))
         return masks
+
+    @staticmethod
+    def release():
+        """Return the work images the finder keeps per calling thread between find() calls (isx_dp_seam_release)."""
+        check(_lib.load().isx_dp_seam_release())

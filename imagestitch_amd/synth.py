@@ -40,18 +40,36 @@ def make_tile(height, width, tile_index=0, noise_only=False):
     return out
 
 
+def camera_ring(width, height, focal, n, yaw_step, pitch=0.010, roll=0.005):
+    """n cameras on one rig, yaw_i = (i - (n - 1) / 2) * yaw_step (BASELINE config 5: n = 8, yaw step 0.55 rad);
+    n = 2 with yaw_step = 2 * yaw is camera_pair."""
+    K = np.array([[focal, 0, width / 2.0], [0, focal, height / 2.0], [0, 0, 1]], np.float32)
+    Rs = [(_rot("y", (i - (n - 1) / 2.0) * yaw_step) @ _rot("x", pitch) @ _rot("z", roll)).astype(np.float32) for i in range(n)]
+    return K, Rs
+
+
 def seam_masks(corners, warped_masks):
-    """Global seam x_s(y) = x_mid + round(40 sin(2 pi y / 512)) through the centre of the overlap of two
-    tiles; mask0 = warped0 & (X < x_s), mask1 = warped1 & (X >= x_s) (X, y in panorama coordinates)."""
-    (x0, y0), (x1, y1) = corners
-    m0, m1 = warped_masks
-    ov_l, ov_r = max(x0, x1), min(x0 + m0.shape[1], x1 + m1.shape[1])
-    x_mid = (ov_l + ov_r) // 2
-    out = []
-    for (cx, cy), m, left in (((x0, y0), m0, x0 <= x1), ((x1, y1), m1, x0 > x1)):
+    """Seam-finder stand-in for a row of n >= 2 tiles: between neighbours (in order of their corner x) the
+    seam x_s(y) = x_mid + round(40 sin(2 pi y / 512)) runs through the centre of their overlap; tile i keeps
+    warped_i & (x_s[i-1] <= X < x_s[i]) (X, y in panorama coordinates).  For a pair: mask0 = warped0 & (X < x_s),
+    mask1 = warped1 & (X >= x_s)."""
+    n = len(corners)
+    order = sorted(range(n), key=lambda i: corners[i][0])
+    mids = []
+    for a, b in zip(order[:-1], order[1:]):
+        ov_l = max(corners[a][0], corners[b][0])
+        ov_r = min(corners[a][0] + warped_masks[a].shape[1], corners[b][0] + warped_masks[b].shape[1])
+        mids.append((ov_l + ov_r) // 2)
+    out = [None] * n
+    for pos, i in enumerate(order):
+        (cx, cy), m = corners[i], warped_masks[i]
         Y = cy + np.arange(m.shape[0])[:, None]
         X = cx + np.arange(m.shape[1])[None, :]
-        xs = x_mid + np.rint(40.0 * np.sin(2 * np.pi * Y / 512.0)).astype(np.int64)
-        keep = (X < xs) if left else (X >= xs)
-        out.append(np.where(keep, m, 0).astype(np.uint8))
+        wob = np.rint(40.0 * np.sin(2 * np.pi * Y / 512.0)).astype(np.int64)
+        keep = np.ones(m.shape, bool)
+        if pos > 0:
+            keep &= X >= mids[pos - 1] + wob
+        if pos < n - 1:
+            keep &= X < mids[pos] + wob
+        out[i] = np.where(keep, m, 0).astype(np.uint8)
     return out

@@ -89,13 +89,16 @@ class RotationWarper:
     def warp(self, src, K, R, interp_mode, border_mode, dst=None):
         """Point warp(src, K, R, interp, border, dst) (W:145-161) -> (corner, dst)."""
         ms = as_mat(src)
-        if dst is None:
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        if dst is None:   # one detectResultRoi per warp() (W:126): isx_warper_roi sizes dst, isx_warper_warp_roi runs the remap
             roi = self.warpRoi((ms.cols, ms.rows), K, R)
             shape = (roi[3] - roi[1] + 1, roi[2] - roi[0] + 1) + tuple(src.shape[2:])
             dst = _empty_like_kind(src, shape, np.dtype(str(src.dtype).replace("torch.", "")))
+            md = as_mat(dst)
+            check(self._lib.isx_warper_warp_roi(self._h, C.byref(ms), kp, rp, int(interp_mode), int(border_mode), (C.c_int * 4)(*roi), C.byref(md)))
+            return (roi[0], roi[1]), dst
         md = as_mat(dst)
-        _k, kp = f9(K)
-        _r, rp = f9(R)
         corner = (C.c_int * 2)()
         check(self._lib.isx_warper_warp(self._h, C.byref(ms), kp, rp, int(interp_mode), int(border_mode), C.byref(md), corner))
         return (corner[0], corner[1]), dst
@@ -103,15 +106,19 @@ class RotationWarper:
     def warp_with_mask(self, img, K, R, mask=None, out16=False, dst_img=None, dst_mask=None):
         """W:229 + W:232 (+ W:294 when out16) in one pass -> (corner, warped_img, warped_mask)."""
         mi = as_mat(img)
-        if dst_img is None or dst_mask is None:
+        mm = as_mat(mask) if mask is not None else None
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        if dst_img is None or dst_mask is None:   # one detectResultRoi for the call, as in warp()
             roi = self.warpRoi((mi.cols, mi.rows), K, R)
             h, w = roi[3] - roi[1] + 1, roi[2] - roi[0] + 1
             dst_img = _empty_like_kind(img, (h, w, 3), np.int16 if out16 else np.uint8)
             dst_mask = _empty_like_kind(img, (h, w), np.uint8)
+            mdi, mdm = as_mat(dst_img), as_mat(dst_mask)
+            check(self._lib.isx_warper_warp_with_mask_roi(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
+                                                          (C.c_int * 4)(*roi), C.byref(mdi), C.byref(mdm)))
+            return (roi[0], roi[1]), dst_img, dst_mask
         mdi, mdm = as_mat(dst_img), as_mat(dst_mask)
-        mm = as_mat(mask) if mask is not None else None
-        _k, kp = f9(K)
-        _r, rp = f9(R)
         corner = (C.c_int * 2)()
         check(self._lib.isx_warper_warp_with_mask(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
                                                   C.byref(mdi), C.byref(mdm), corner))

@@ -57,7 +57,9 @@ public:
     cv::Mat toCv() const { return cv::Mat(m_.rows, m_.cols, m_.type, m_.data, m_.step); }
 #endif
     void create(int rows, int cols, int type) {   // OutputArray::create (W:128-129,150)
-        if (own_ && m_.rows == rows && m_.cols == cols && m_.type == type) return;
+        // cv::Mat::create: a mat that already has this geometry keeps its buffer - whether it owns it or aliases the caller's
+        // (host or device) memory
+        if (m_.data != nullptr && m_.rows == rows && m_.cols == cols && m_.type == type) return;
         size_t es = elemSize(type);
         own_ = std::shared_ptr<unsigned char>(new unsigned char[(size_t)rows * cols * es], std::default_delete<unsigned char[]>());
         m_.data = own_.get(); m_.rows = rows; m_.cols = cols; m_.type = type; m_.step = (size_t)cols * es; m_.device = -1;
@@ -102,11 +104,10 @@ public:
     // Point warp(src, K, R, interp_mode, border_mode, dst)  W:145
     Point warp(const Mat& src, const float K[9], const float R[9], int interp_mode, int border_mode, Mat& dst) {
         int roi[4];
-        check(isx_warper_roi(h_, src.cols(), src.rows(), K, R, roi, nullptr));
+        check(isx_warper_roi(h_, src.cols(), src.rows(), K, R, roi, nullptr));   // buildMaps -> detectResultRoi, ONCE per call  W:126,149
         dst.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, src.type());   // dst.create(roi.height + 1, roi.width + 1)  W:150
-        int corner[2];
-        check(isx_warper_warp(h_, src.c(), K, R, interp_mode, border_mode, dst.c(), corner));
-        return Point(corner[0], corner[1]);   // dst_roi.tl()  W:160
+        check(isx_warper_warp_roi(h_, src.c(), K, R, interp_mode, border_mode, roi, dst.c()));   // the remap with that ROI  W:157
+        return Point(roi[0], roi[1]);   // dst_roi.tl()  W:160
     }
     Rect warpRoi(Size src_size, const float K[9], const float R[9]) {
         int roi[4];
@@ -132,6 +133,8 @@ class Blender {
 public:
     enum { NO = ISX_BLEND_NO, FEATHER = ISX_BLEND_FEATHER, MULTI_BAND = ISX_BLEND_MULTI_BAND };
     virtual ~Blender() { isx_blender_destroy(h_); }
+    Blender(const Blender&) = delete;              // owns the handle: a copy would destroy it twice
+    Blender& operator=(const Blender&) = delete;
     static std::shared_ptr<Blender> createDefault(int type, bool try_gpu = false, int precision = ISX_PREC_I16);
     void prepare(const std::vector<Point>& corners, const std::vector<Size>& sizes) {   // W:281
         if (corners.size() != sizes.size()) throw Exception(ISX_ERR_INVALID, "prepare: corners.size() != sizes.size()");

@@ -128,6 +128,16 @@ int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9],
 int isx_warper_warp(isx_warper* w, const isx_mat* src, const float K[9], const float R[9],
                     int interp, int border, isx_mat* dst, int corner[2]);
 
+/* The second half of the same call for adapters that must size `dst` themselves (OutputArray::create, W:150): `roi` is what
+ * isx_warper_roi just returned for the same (source size, K, R) on this handle, so that ONE reference warp() = one
+ * detectResultRoi (W:126) = isx_warper_roi + isx_warper_warp_roi, not two scans.  No scan, no host synchronisation (device
+ * mats).  A `roi` that is not detectResultRoi's is not checked: the result is then the remap over that rectangle.          */
+int isx_warper_warp_roi(isx_warper* w, const isx_mat* src, const float K[9], const float R[9],
+                        int interp, int border, const int roi[4], isx_mat* dst);
+/* ... and of the fused image + mask call below.                                                                        */
+int isx_warper_warp_with_mask_roi(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9],
+                                  const float R[9], const int roi[4], isx_mat* dst_img, isx_mat* dst_mask);
+
 /* The two calls of W:229 + W:232 on one tile fused: image LINEAR/REFLECT and mask
  * NEAREST/CONSTANT in one pass over the destination.  src_mask may be NULL = all 255
  * (W:213-214).  dst_img may be CV_8UC3 or CV_16SC3 (= warp + convertTo(CV_16S), W:294).      */
@@ -257,6 +267,10 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
  * of the images' sizes, edited in place.                                                                            */
 int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_xy, isx_mat* masks, int device,
                      void* hip_stream);
+/* isx_dp_seam_find / isx_seam_estimate keep their work images (about 6-10 B per union pixel on the host, the staged images,
+ * cost maps and DP records on the device) per calling thread between calls; this returns all of it (the analogue of the
+ * DpSeamFinder going out of scope, S:1188-1192).                                                                   */
+int isx_dp_seam_release(void);
 
 /* ---- on-disk format either side of the path: .bmp (W:166 imread, W:155-156,315 imwrite) ----------- */
 /* Reading: uncompressed Windows bitmaps only (the reference's inputs and committed artefacts are BMPs).

@@ -30,7 +30,9 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        # ISX_ORACLE_LIB: bench.py's cpu_baseline leg times a build of the same oracle.c made on the box it runs on
+        # (-O3 -march=native); the parity tests always use the portable -O2 build
+        path = os.environ.get("ISX_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
