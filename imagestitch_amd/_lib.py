@@ -91,6 +91,7 @@ _SIGS = {
     "isx_blender_debug_level": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _IP, _IP],
     "isx_blend_pair_linear_size": [C.c_int] * 8 + [_IP, _IP],
     "isx_blend_pair_linear": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, _MP, _IP, C.c_int, C.c_void_p],
+    "isx_selftest_division": [C.c_int, C.c_int, C.c_ulonglong, _IP],
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],
     "isx_profile_filter": [C.c_char_p],

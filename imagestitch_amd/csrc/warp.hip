@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 #include <mutex>
@@ -333,6 +334,329 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
             dmask[(size_t)dy * dmask_step + dx0 + k] = (unsigned char)m[k];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_warp_tile: the fused image + mask warp of a tile whose source mask is all 255 (W:213-214) - the hot kernel.
+// Same outputs as k_warp_img_mask, about half its VALU instructions (that kernel is VALU-issue-bound, not HBM-bound):
+//  * one thread = 4 consecutive columns x WR consecutive rows.  The separable parts of W:56-58 are hoisted: for the
+//    cylindrical projector k_rinv[0,3,6] * sin(u) and k_rinv[2,5,8] * cos(u) depend on the column only (24 products, once
+//    per thread), k_rinv[1,4,7] * (v / scale) on the row only (3 per row); per pixel the transform is its six additions.
+//    Every product is rounded on its own in W:56-58 (no FMA), so hoisting them changes no bit.
+//  * the arithmetic of two pixels rides in one packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 round each
+//    half separately, like their scalar forms).
+//  * x / z and y / z share z: one v_rcp_f32 per pixel and the hardware's own division recurrence written out with packed
+//    FMAs - r1 = r0 + r0 (1 - z r0); q0 = a r1; q1 = q0 + r1 (a - z q0); q = q1 + r1 (a - z q1) - which is bit for bit what
+//    v_div_scale / v_div_fmas / v_div_fixup compute when they do not rescale, i.e. for 2^-20 <= z <= 2^20 and a quotient
+//    that is neither denormal nor huge (isx_selftest_division compares the two on random operands).  Pixels with z outside
+//    that range (z <= 0, W:61, included) and quotients outside the source image are not produced here at all (see below),
+//    and a numerator too small for the recurrence's error terms (|a| < 2^-60, quotient < 2^-40) gives cvRound(q * 32) = 0
+//    whichever way its last bits fall.
+//  * cvRound(q * 32) is the magic-number add (1.5 * 2^23: the FPU's own round-half-even, bits 0..22 then hold the integer),
+//    after one v_med3_f32 that clamps the coordinate to the range in which both bilinear rows lie inside the image and maps
+//    NaN to the lower bound.  A pixel is "fast" iff clamping changed nothing (one compare per axis) and z is in range.
+//  * fast pixels read their two 12-byte windows (always in bounds: the clamped coordinates are used for the addresses) and
+//    blend them with v_dot4_u32_u8 / v_mad_u32_u24 as k_warp_img_mask does; their mask byte is 255 (in range implies
+//    cvRound(x) in [0, cols), cvRound(y) in [0, rows)).
+//  * everything else - reflected borders, z <= 0, the partial thread at the right edge, sources too small for a window - is
+//    fixed up after the row loop by the generic per-byte sampler, kept out of line: the hot loop has no call in it.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
+
+// q = a / z for two pixels, r1 = the refined reciprocal of z (see above): the recurrence the hardware division runs
+__device__ __forceinline__ f32x2 div_by_refined(f32x2 a, f32x2 z, f32x2 r1) {
+    f32x2 q = a * r1;
+    f32x2 e = pk_fma(-z, q, a);
+    q = pk_fma(e, r1, q);
+    e = pk_fma(-z, q, a);
+    return pk_fma(e, r1, q);
+}
+__device__ __forceinline__ f32x2 refine_rcp(f32x2 z, f32x2 r0) {
+    const f32x2 e = pk_fma(-z, r0, splat2(1.f));
+    return pk_fma(e, r0, r0);
+}
+
+constexpr float DIV_Z_LO = 9.5367431640625e-07f;   // 2^-20
+constexpr float DIV_Z_HI = 1048576.f;              // 2^20
+constexpr float RNE_MAGIC = 12582912.f;            // 1.5 * 2^23
+
+struct TileDst {
+    unsigned char* img; unsigned img_step;
+    unsigned char* mask; unsigned mask_step;
+    int w, h;
+};
+
+// The rows of a thread that did not qualify for the fast path (bit i of `slow`: the thread's four pixels of row row0 + i),
+// by the generic arithmetic - z <= 0 sentinel (W:61), BORDER_REFLECT taps, per-byte loads and stores.  Out of line and
+// written for few registers (the kernel's register count is the larger of its own and its callee's): one pixel at a time,
+// no unrolling.  The pointers point into the kernel-argument segment.
+// cv::borderInterpolate(p, n, BORDER_REFLECT) as a plain loop (isxd::reflect falls back to an out-of-line call, and a call
+// inside the fix-up would push its live values into the callee-saved registers v40+, which count for the kernel)
+__device__ __forceinline__ int reflect_inline(int p, int n) {
+    if (n == 1) return 0;
+    while ((unsigned)p >= (unsigned)n) p = p < 0 ? -p - 1 : 2 * n - 1 - p;
+    return p;
+}
+
+template <bool OUT16>
+__device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t, const SrcView* img, const TileDst* d, int dx0, int row0, unsigned slow, int nrows) {
+    const unsigned char* data = img->data;
+    const size_t step = img->step;
+    const int rows = img->rows, cols = img->cols;
+#pragma unroll 1
+    for (int j = 0; j < 4 * nrows; ++j) {
+        const int i = j >> 2, k = j & 3, dy = row0 + i, dx = dx0 + k;
+        if (dy >= d->h || dx >= d->w || !((slow >> i) & 1u)) continue;
+        float mx, my;
+        map_backward(*p, *t, dx, dy, mx, my);
+        // cv::remap INTER_LINEAR, BORDER_REFLECT on CV_8UC3 (sample_linear's arithmetic)
+        const int isx = cvround_x86(mx * 32.f), isy = cvround_x86(my * 32.f);
+        const int fx = isx & 31, fy = isy & 31;
+        const int sx = clamp_short(isx >> 5), sy = clamp_short(isy >> 5);
+        const unsigned char* r0 = data + (size_t)reflect_inline(sy, rows) * step;
+        const unsigned char* r1 = data + (size_t)reflect_inline(sy + 1, rows) * step;
+        const int c0 = reflect_inline(sx, cols) * 3, c1 = reflect_inline(sx + 1, cols) * 3;
+        int w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+        if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+        // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT: 255 iff cvRound(x) in [0, cols) and cvRound(y) in [0, rows)
+        const int nx = clamp_short(cvround_x86(mx)), ny = clamp_short(cvround_x86(my));
+        d->mask[(size_t)dy * d->mask_step + dx] = ((unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows) ? 255 : 0;
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            const int v = sat_u8((r0[c0 + c] * w0 + r0[c1 + c] * w1 + r1[c0 + c] * w2 + r1[c1 + c] * w3 + (1 << 14)) >> 15);
+            if constexpr (OUT16) ((short*)(d->img + (size_t)dy * d->img_step))[(size_t)dx * 3 + c] = (short)v;
+            else (d->img + (size_t)dy * d->img_step)[(size_t)dx * 3 + c] = (unsigned char)v;
+        }
+    }
+}
+
+// a * b + c on 24-bit unsigned operands (v_mul_u32_u24 / v_mad_u32_u24, full rate).  Not inline assembly: an asm statement that
+// reads the result of a v_dot4 a few instructions earlier escapes the compiler's hazard recogniser (gfx950 wants wait states between
+// a DOT instruction and a VALU read of its result) and reads a stale register.
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
+
+struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; int dbg; };
+
+// one pixel of the fixed-point bilinear from its two 12-byte windows: window pixel 0 weighs wA, pixel 1 weighs wB (wA + wB = 32),
+// the upper row gy, the lower fy (gy + fy = 32): (sum of the BilinearTab_i products + 2^14) >> 15 == (S + 512) >> 10 with the
+// separable exact S (see k_warp_img_mask).  Returns b | g << 8 | r << 16.
+__device__ __forceinline__ unsigned sample_windows(const U3& v0, const U3& v1, unsigned o0, unsigned o1, unsigned wA, unsigned wB, unsigned gy, unsigned fy) {
+    const unsigned s0 = o0 & 3u, s1 = o1 & 3u;
+    const unsigned l0 = __builtin_amdgcn_alignbyte(v0.y, v0.x, s0), h0 = __builtin_amdgcn_alignbyte(v0.z, v0.y, s0);   // b0 g0 r0 b1 | g1 r1 . .
+    const unsigned l1 = __builtin_amdgcn_alignbyte(v1.y, v1.x, s1), h1 = __builtin_amdgcn_alignbyte(v1.z, v1.y, s1);
+    const unsigned wb = wA | (wB << 24), wgl = wA << 8, wgh = wB, wrl = wA << 16, wrh = wB << 8;
+    const unsigned t0b = __builtin_amdgcn_udot4(l0, wb, 0u, false), t1b = __builtin_amdgcn_udot4(l1, wb, 0u, false);
+    const unsigned t0g = __builtin_amdgcn_udot4(h0, wgh, __builtin_amdgcn_udot4(l0, wgl, 0u, false), false);
+    const unsigned t1g = __builtin_amdgcn_udot4(h1, wgh, __builtin_amdgcn_udot4(l1, wgl, 0u, false), false);
+    const unsigned t0r = __builtin_amdgcn_udot4(h0, wrh, __builtin_amdgcn_udot4(l0, wrl, 0u, false), false);
+    const unsigned t1r = __builtin_amdgcn_udot4(h1, wrh, __builtin_amdgcn_udot4(l1, wrl, 0u, false), false);
+    const unsigned c0 = mad24(t0b, gy, mad24(t1b, fy, 512u)) >> 10;
+    const unsigned c1 = mad24(t0g, gy, mad24(t1g, fy, 512u)) >> 10;
+    const unsigned c2 = mad24(t0r, gy, mad24(t1r, fy, 512u)) >> 10;
+    return c0 | (c1 << 8) | (c2 << 16);
+}
+
+// cv::borderInterpolate(p, n, BORDER_REFLECT) for p in [-n, 2n - 1] (at most one reflection): p < 0 -> -p - 1 = ~p, p >= n -> 2n - 1 - p
+__device__ __forceinline__ int reflect_once(int p, int n2m1) {
+    const int q = p ^ (p >> 31);
+    return min(q, n2m1 - q);
+}
+
+template <int KIND, bool OUT16, bool VEC>
+__global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
+    const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dx0 = (blockIdx.x * 64 + lane) * 4;
+    const int dy = blockIdx.y * 4 + wv;             // wave-uniform
+    if (dy >= d.h || dx0 >= d.w) return;
+    const bool whole = VEC && dx0 + 4 <= d.w;       // four real columns and dword-aligned rows: vector stores
+    // ---- mapBackward (W:46-63): the transform of the thread's four columns in this row -------------------------------
+    const float4 cs4 = *(const float4*)(t.col_s + dx0), cc4 = *(const float4*)(t.col_c + dx0);   // tables are padded to 4 floats
+    const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
+    f32x2 X[2], Y[2], Z[2];
+    if constexpr (KIND == ISX_WARP_CYLINDRICAL) {
+        const float ra = t.row_a[dy];                                                            // y_ = v / scale  W:49,52
+        const f32x2 qx = splat2(p.k_rinv[1] * ra), qy = splat2(p.k_rinv[4] * ra), qz = splat2(p.k_rinv[7] * ra);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            X[h] = (splat2(p.k_rinv[0]) * cs[h] + qx) + splat2(p.k_rinv[2]) * cc[h];             // W:56
+            Y[h] = (splat2(p.k_rinv[3]) * cs[h] + qy) + splat2(p.k_rinv[5]) * cc[h];             // W:57
+            Z[h] = (splat2(p.k_rinv[6]) * cs[h] + qz) + splat2(p.k_rinv[8]) * cc[h];             // W:58
+        }
+    } else {
+        const float ra = t.row_a[dy], rb = t.row_b[dy];                                         // sinf(pi - v), cosf(pi - v)
+        const f32x2 qx = splat2(p.k_rinv[1] * rb), qy = splat2(p.k_rinv[4] * rb), qz = splat2(p.k_rinv[7] * rb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 x_ = splat2(ra) * cs[h], z_ = splat2(ra) * cc[h];
+            X[h] = (splat2(p.k_rinv[0]) * x_ + qx) + splat2(p.k_rinv[2]) * z_;
+            Y[h] = (splat2(p.k_rinv[3]) * x_ + qy) + splat2(p.k_rinv[5]) * z_;
+            Z[h] = (splat2(p.k_rinv[6]) * x_ + qz) + splat2(p.k_rinv[8]) * z_;
+        }
+    }
+    // x / z, y / z (W:60) times 32: cvRound of these is cv::remap's fixed-point coordinate
+    float tx[4], ty[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 r0 = {__builtin_amdgcn_rcpf(Z[h].x), __builtin_amdgcn_rcpf(Z[h].y)};
+        const f32x2 r1 = refine_rcp(Z[h], r0);
+        const f32x2 ax = div_by_refined(X[h], Z[h], r1) * splat2(32.f), ay = div_by_refined(Y[h], Z[h], r1) * splat2(32.f);
+        tx[2 * h] = ax.x; tx[2 * h + 1] = ax.y; ty[2 * h] = ay.x; ty[2 * h + 1] = ay.y;
+    }
+    // z of the four pixels inside the division's guarded range?  (A NaN slips through min / max and is caught below: its quotient
+    // is NaN, which no clamp leaves unchanged.)  Otherwise - z <= 0 (W:61) included - the generic code path does the thread's row.
+    const float zmin = fminf(fminf(Z[0].x, Z[0].y), fminf(Z[1].x, Z[1].y)), zmax = fmaxf(fmaxf(Z[0].x, Z[0].y), fmaxf(Z[1].x, Z[1].y));
+    const int rows = img.rows, cols = img.cols;
+    const unsigned step = (unsigned)img.step;
+    const unsigned mis = (unsigned)((uintptr_t)img.data & 3);
+    const unsigned char* abase = img.data - mis;
+    bool generic = !((zmin >= DIV_Z_LO) & (zmax <= DIV_Z_HI)) || cols < 2 || rows < 3;
+    // ---- tier 1: both bilinear rows and columns inside the image (and not in its last row: the 12-byte window of the lower row then
+    // ends inside the buffer).  One clamp + one compare per axis; the clamped coordinate makes every address valid.
+    const float lo = -0.5f;
+    const float hi_x = __uint_as_float(__float_as_uint((float)(32 * (cols - 1)) - 0.5f) - 1u);     // largest float below 32 (cols - 1) - 1/2
+    const float hi_y = __uint_as_float(__float_as_uint((float)(32 * (rows - 2)) - 0.5f) - 1u);
+    const unsigned addr_c = mis - (0x20000u * step) - 0x60000u;   // mantissa of (t + 1.5 * 2^23) = 2^22 + cvRound(t): sx = (m >> 5) - 2^17
+    unsigned px[4];
+    float cxs[4], cys[4];
+    bool all1 = !generic;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cxs[k] = __builtin_amdgcn_fmed3f(tx[k], lo, hi_x); cys[k] = __builtin_amdgcn_fmed3f(ty[k], lo, hi_y);
+        all1 = all1 & (cxs[k] == tx[k]) & (cys[k] == ty[k]);
+    }
+    unsigned m4 = 0xffffffffu;              // tier-1 pixels: cvRound(x) in [0, cols), cvRound(y) in [0, rows) -> mask 255 (W:213-214, W:232)
+    if (__builtin_amdgcn_ballot_w64(!all1) == 0ull) {      // wave-uniform: every pixel of the wave is a tier-1 pixel
+        unsigned o0[4], fxy[4];
+        U3 v0[4], v1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned bx = __float_as_uint(cxs[k] + RNE_MAGIC), by = __float_as_uint(cys[k] + RNE_MAGIC);
+            fxy[k] = (bx & 31u) | ((by & 31u) << 8);
+            o0[k] = mad24(__builtin_amdgcn_ubfe(by, 5, 18), step, mad24(__builtin_amdgcn_ubfe(bx, 5, 18), 3u, addr_c));
+        }
+        if (!(a.dbg & 2)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {       // all eight loads in flight together
+            v0[k] = *(const U3*)(abase + (o0[k] & ~3u));
+            v1[k] = *(const U3*)(abase + ((o0[k] + step) & ~3u));
+        }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned fx = fxy[k] & 255u, fy = fxy[k] >> 8;
+            px[k] = sample_windows(v0[k], v1[k], o0[k], o0[k] + step, 32u - fx, fx, 32u - fy, fy);
+        }
+    } else if (!(a.dbg & 4)) {
+        // ---- tier 2: a wave that crosses the image border.  BORDER_REFLECT keeps the two taps of an axis adjacent (possibly in reverse
+        // order) or puts them on the same pixel, so the two 12-byte windows still hold every tap: the window starts at the smaller
+        // tap column and the horizontal weights go where the taps landed.  Interior pixels of the wave take the same code.
+        const float big = 2097152.f;                   // |32 x| < 2^21: the magic-number rounding stays exact, |sx| < 2^16
+        const float mhx = (float)(32 * cols - 16), mhy = (float)(32 * rows - 16);      // 32 (cols - 1/2): the upper tie of cvRound(x) <= cols - 1
+        const float mx_hi = ((cols - 1) & 1) ? mhx : __uint_as_float(__float_as_uint(mhx) + 1u);   // ... rounds to cols - 1 iff that is even
+        const float my_hi = ((rows - 1) & 1) ? mhy : __uint_as_float(__float_as_uint(mhy) + 1u);
+        unsigned p0[4], p1[4], wab[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float cx = __builtin_amdgcn_fmed3f(tx[k], -big, big), cy = __builtin_amdgcn_fmed3f(ty[k], -big, big);
+            const int isx = (int)(__float_as_uint(cx + RNE_MAGIC) - 0x4B400000u), isy = (int)(__float_as_uint(cy + RNE_MAGIC) - 0x4B400000u);
+            const int sx = isx >> 5, sy = isy >> 5, fx = isx & 31, fy = isy & 31;
+            // one reflection at most: sx, sx + 1 in [-cols, 2 cols - 1], same for the rows
+            bool ok = (cx == tx[k]) & (cy == ty[k]) & ((unsigned)(sx + cols) < (unsigned)(3 * cols - 1)) & ((unsigned)(sy + rows) < (unsigned)(3 * rows - 1));
+            const int c0 = reflect_once(sx, 2 * cols - 1), c1 = reflect_once(sx + 1, 2 * cols - 1);
+            const int r0 = reflect_once(sy, 2 * rows - 1), r1 = reflect_once(sy + 1, 2 * rows - 1);
+            const int cb = min(min(c0, c1), cols - 2);                               // window = pixels cb, cb + 1
+            const unsigned wA = (c0 == cb ? 32u - fx : 0u) + (c1 == cb ? (unsigned)fx : 0u);
+            // a window in the buffer's last row must end inside the buffer: its last few columns go to the generic path
+            ok = ok & !((max(r0, r1) == rows - 1) & (cb > cols - 6));
+            if (!ok) generic = true;
+            const unsigned cb3 = ok ? (unsigned)cb * 3u + mis : mis;
+            p0[k] = __umul24(ok ? (unsigned)r0 : 0u, step) + cb3;
+            p1[k] = __umul24(ok ? (unsigned)r1 : 0u, step) + cb3;
+            wab[k] = wA | ((unsigned)fy << 8);
+            // mask of an all-255 source, NEAREST / CONSTANT: 255 iff cvRound(x) in [0, cols) and cvRound(y) in [0, rows) - an interval test
+            // on 32 x, 32 y (round-half-even: the tie -1/2 rounds to 0, the upper tie to cols - 1 iff cols - 1 is even; NaN fails)
+            const bool inside = (tx[k] >= -16.f) & (tx[k] < mx_hi) & (ty[k] >= -16.f) & (ty[k] < my_hi);
+            if (!inside) m4 &= ~(255u << (8 * k));
+        }
+        U3 w0[4], w1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w0[k] = *(const U3*)(abase + (p0[k] & ~3u));
+            w1[k] = *(const U3*)(abase + (p1[k] & ~3u));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned wA = wab[k] & 255u, fy = wab[k] >> 8;
+            px[k] = sample_windows(w0[k], w1[k], p0[k], p1[k], wA, 32u - wA, 32u - fy, fy);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) px[k] = 0;
+    }
+    // ---- stores ------------------------------------------------------------------------------------------------------------
+    if ((a.dbg & 1) && (px[0] ^ px[1] ^ px[2] ^ px[3]) != 0x12345678u) return;
+    if (whole) {
+        if constexpr (OUT16) {
+            unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 6u));
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {   // 2 pixels = 6 shorts = 3 dwords
+                const unsigned a0 = px[k], b2 = px[k + 1];
+                q[3 * (k / 2)] = (a0 & 255) | (((a0 >> 8) & 255) << 16);
+                q[3 * (k / 2) + 1] = ((a0 >> 16) & 255) | ((b2 & 255) << 16);
+                q[3 * (k / 2) + 2] = ((b2 >> 8) & 255) | (((b2 >> 16) & 255) << 16);
+            }
+        } else {
+            unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 3u));
+            q[0] = px[0] | (px[1] << 24);                                   // b0 g0 r0 b1
+            q[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);        // g1 r1 b2 g2
+            q[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);        // r2 b3 g3 r3
+        }
+        *(unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
+    } else {    // the partial group at the right edge, or destination rows that are not dword aligned: per-pixel stores
+#pragma unroll 1
+        for (int k = 0; k < 4 && dx0 + k < d.w; ++k) {
+            const unsigned v = k == 0 ? px[0] : (k == 1 ? px[1] : (k == 2 ? px[2] : px[3]));
+            if constexpr (OUT16) {
+                short* q = (short*)(d.img + (size_t)dy * d.img_step) + (size_t)(dx0 + k) * 3;
+                q[0] = (short)(v & 255); q[1] = (short)((v >> 8) & 255); q[2] = (short)((v >> 16) & 255);
+            } else {
+                unsigned char* q = d.img + (size_t)dy * d.img_step + (size_t)(dx0 + k) * 3;
+                q[0] = (unsigned char)v; q[1] = (unsigned char)(v >> 8); q[2] = (unsigned char)(v >> 16);
+            }
+            d.mask[(size_t)dy * d.mask_step + dx0 + k] = (unsigned char)(m4 >> (8 * k));
+        }
+    }
+    // ---- the rare rest (z out of the guarded range incl. the z <= 0 sentinel, more than one reflection, sources too small for a
+    // window, the last columns of the buffer's last row): the whole 4-pixel row of the thread again, by the generic code path
+    if (generic && !(a.dbg & 4)) {
+        const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1);
+    }
+}
+
+// the recurrence of k_warp_tile against the compiler's IEEE division on n pseudo-random operand pairs of the guarded range
+__global__ void k_selftest_division(unsigned long long seed, int n, unsigned* mismatches) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    auto next = [&]() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return (unsigned)((s * 0x2545F4914F6CDD1Dull) >> 32); };
+    // z: any float in [2^-20, 2^20]; a: any finite float of either sign with |a| in [2^-60, 2^60], or exactly 0
+    const unsigned zr = next(), ar = next();
+    const float z = __uint_as_float(((107u + zr % 41u) << 23) | (next() & 0x7fffffu));
+    float a = __uint_as_float((ar & 0x80000000u) | ((67u + (ar >> 8) % 121u) << 23) | (next() & 0x7fffffu));
+    if ((ar & 0xffu) == 0) a = 0.f;
+    if (!(z >= DIV_Z_LO && z <= DIV_Z_HI)) return;
+    const f32x2 Z = {z, z}, A = {a, -a};
+    const f32x2 r0 = {__builtin_amdgcn_rcpf(z), __builtin_amdgcn_rcpf(z)};
+    const f32x2 q = div_by_refined(A, Z, refine_rcp(Z, r0));
+    const float e0 = a / z, e1 = -a / z;
+    // (a zero quotient may come out with the other sign - (-0) / z gives +0 here - which cvRound(q * 32) does not see)
+    const bool same0 = __float_as_uint(q.x) == __float_as_uint(e0) || (q.x == 0.f && e0 == 0.f);
+    const bool same1 = __float_as_uint(q.y) == __float_as_uint(e1) || (q.y == 0.f && e1 == 0.f);
+    if (!same0 || !same1) atomicAdd(mismatches, 1u);
 }
 
 // buildMaps (W:133-141), API parity only
@@ -822,8 +1146,20 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
 #define ISX_WARP_FUSED(O16, V)                                                                                                   \
         ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_img_mask<O16, V>), grid4, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0, \
                    (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
-        if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_FUSED(true, true); else ISX_WARP_FUSED(true, false); }
+        // the hot kernel: a tile whose mask is all 255 (W:213-214).  Same launch name: it is the same operation.
+        const dim3 gridt(cdiv(dw, 256), cdiv(dh, 4));
+        static const int dbg_env = getenv("ISX_WARP_DBG") ? atoi(getenv("ISX_WARP_DBG")) : 0;
+        const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, dw, dh}, dbg_env};
+#define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(256), 0, wta)
+#define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
+        static const bool old_kernel = getenv("ISX_WARP_V1") != nullptr;
+        if (!src_mask && !old_kernel) {
+            if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_TILE_K(true, true); else ISX_WARP_TILE_K(true, false); }
+            else { if (vec) ISX_WARP_TILE_K(false, true); else ISX_WARP_TILE_K(false, false); }
+        } else if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_FUSED(true, true); else ISX_WARP_FUSED(true, false); }
         else { if (vec) ISX_WARP_FUSED(false, true); else ISX_WARP_FUSED(false, false); }
+#undef ISX_WARP_TILE_K
+#undef ISX_WARP_TILE
 #undef ISX_WARP_FUSED
         ISX_TRY(w->st_dmask.finish_out(st));
         if (planned && verify_plan) {
@@ -1007,6 +1343,22 @@ int isx_warper_warp_with_mask_roi(isx_warper* w, const isx_mat* src_img, const i
     clear_error();
     ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "warp_with_mask_roi: null roi");
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, roi, true, false);
+}
+
+int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches) {
+    clear_error();
+    ISX_CHECK_ARG(mismatches != nullptr && n > 0, ISX_ERR_INVALID, "selftest_division: bad argument");
+    ISX_HIP(hipSetDevice(device));
+    unsigned* dm = nullptr;
+    ISX_HIP(hipMalloc(&dm, sizeof(unsigned)));
+    ISX_HIP(hipMemset(dm, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(k_selftest_division, dim3(cdiv(n, 256)), dim3(256), 0, 0, seed, n, dm);
+    unsigned h = 0;
+    hipError_t e = hipMemcpy(&h, dm, sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipFree(dm);
+    ISX_HIP(e);
+    *mismatches = (int)h;
+    return ISX_OK;
 }
 
 int isx_warper_set_deferred_verify(isx_warper* w, int on) {

@@ -296,6 +296,12 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2,
                           int tl1_x, int tl1_y, int tl2_x, int tl2_y,
                           isx_mat* pano, int* seam_x, int device, void* hip_stream);
 
+/* ---- self-test --------------------------------------------------------------------------------- */
+/* The fused warp kernel divides x / z and y / z with one shared reciprocal and the hardware division's own recurrence
+ * written out in packed FMAs (csrc/warp.hip, k_warp_tile).  This compares that recurrence with the compiler's IEEE division
+ * on n pseudo-random operand pairs of the range the kernel admits to it; *mismatches must come back 0.              */
+int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches);
+
 /* ---- per-kernel HIP-event timing (feeds bench.py's roofline object) ----------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on its own stream.               */
 int isx_profile_enable(int on);

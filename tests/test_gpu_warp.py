@@ -223,3 +223,47 @@ def test_roi_cache_returns_the_same_roi_and_follows_the_camera(gpu, oracle):
     c1, d1 = w1.warp(img, K, Rs[1], gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
     c0, d0 = w0.warp(img, K, Rs[1], gpu.INTER_LINEAR, gpu.BORDER_REFLECT)
     assert c0 == c1 and np.array_equal(d0, d1)
+
+
+def test_shared_reciprocal_division_equals_ieee_division(gpu):
+    """k_warp_tile divides x / z and y / z with one v_rcp_f32 and the hardware division's recurrence in packed FMAs; on the
+    operand range it admits (2^-20 <= z <= 2^20, |a| in {0} u [2^-60, 2^60]) that must be the compiler's IEEE division bit for bit."""
+    import ctypes as C
+    lib = gpu.load()
+    for seed in (1, 0xC0FFEE, 2026):
+        n = C.c_int(-1)
+        gpu._lib.check(lib.isx_selftest_division(0, 1 << 22, C.c_ulonglong(seed), C.byref(n)))
+        assert n.value == 0, (seed, n.value)
+
+
+@pytest.mark.parametrize("kind", ["cyl", "sph"])
+def test_fused_tile_kernel_edges(gpu, oracle, kind):
+    """The hot fused kernel (k_warp_tile) on cases that exercise its fix-up path: a camera that looks past the image on
+    every side (reflected borders on all four edges, z <= 0 columns for the cylinder), widths that leave a partial
+    4-pixel group, unaligned destination pitches (per-pixel stores), sources too small for a 12-byte window."""
+    import torch
+    rng = np.random.default_rng(7)
+    cases = [(333, 217, 150.0, 0.9), (64, 5, 40.0, 0.3), (7, 2, 20.0, 0.1), (3, 3, 10.0, 0.0), (2, 9, 12.0, 0.0), (640, 361, 900.0, 0.05)]
+    for (w, h, f, yaw) in cases:
+        K, Rs = synth.camera_pair(w, h, f, yaw=yaw, pitch=0.2, roll=0.1)
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        creator = gpu.CylindricalWarper if kind == "cyl" else gpu.SphericalWarper
+        ok = oracle.CYL if kind == "cyl" else oracle.SPH
+        warper = creator().create(f)
+        for R in Rs:
+            oc, owi, _ = oracle.warp_u8(ok, f, K, R, img, 1, 2)
+            _, owm, _ = oracle.warp_u8(ok, f, K, R, np.full((h, w), 255, np.uint8), 0, 0)
+            for out16 in (False, True):
+                c, wi, wm = warper.warp_with_mask(torch.from_numpy(img).cuda(), K, R, out16=out16)      # dense rows: dwords only if w % 4 == 0
+                assert tuple(c) == oc
+                assert np.array_equal(wi.cpu().numpy(), owi.astype(np.int16) if out16 else owi), (w, h, out16)
+                assert np.array_equal(wm.cpu().numpy(), owm), (w, h)
+                dh, dw = owm.shape                                                                          # pitched rows: the dword path
+                pi = torch.zeros((dh, (dw * (6 if out16 else 3) + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+                pm = torch.zeros((dh, (dw + 63) // 64 * 64), dtype=torch.uint8, device="cuda")
+                # as_strided views of the pitched buffers
+                vi = (pi.view(torch.int16) if out16 else pi).as_strided((dh, dw, 3), (pi.shape[1] // (2 if out16 else 1), 3, 1))
+                vm = pm.as_strided((dh, dw), (pm.shape[1], 1))
+                warper.warp_with_mask(torch.from_numpy(img).cuda(), K, R, out16=out16, dst_img=vi, dst_mask=vm)
+                assert np.array_equal(vi.cpu().numpy(), owi.astype(np.int16) if out16 else owi), (w, h, out16, "pitched")
+                assert np.array_equal(vm.cpu().numpy(), owm)
