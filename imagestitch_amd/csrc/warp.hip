@@ -731,9 +731,12 @@ __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsign
 
 // second pass of the synchronous path: every pixel whose stand-in is within the tolerance of one of the
 // four extrema; the host re-evaluates exactly those with mapForward and its own libm
-__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, float tol_d, float tol_q,
-                                                        int* cand_xy, int cap, int* count) {
+__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, int* cand_xy, int cap, int* count) {
     const float dmin = fkey_inv(keys[0]), qmin = fkey_inv(keys[1]), dmax = fkey_inv(keys[2]), qmax = fkey_inv(keys[3]);
+    // tolerances that cover the few-ulp error of v_rcp / v_rsq and of the host's own atan2f many times over (computed here so that
+    // the host needs no look at the keys between the two kernels: one round trip per detectResultRoi)
+    const float tol_d = 7.62939453125e-06f;                                   // 2^-17 of a (-2, 2] range
+    const float tol_q = 4e-6f * fmaxf(fabsf(qmin), fabsf(qmax)) + 1e-9f;
     const int y0 = blockIdx.y * CAND_ROWS, y1 = min(y0 + CAND_ROWS, sh);
     for (int y = y0; y < y1; ++y)
         for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
@@ -842,6 +845,7 @@ struct isx_warper {
     hipEvent_t ev_warp = nullptr;   // recorded on the main stream after a planned warp: its scan starts behind it
     hipEvent_t ev_scan = nullptr;   // recorded on the side stream after the check: isx_warper_join waits on it
     DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
+    void* pin = nullptr;     // pinned host landing zone of detectResultRoi's {keys, count, first candidates}
     // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
     // queued scans behind the main stream's position AT THAT CALL (e.g. after the last warp of a step, so
     // that they run under the memory-bound pyramid kernels instead of under the next tile's warp)
@@ -867,6 +871,7 @@ struct isx_warper {
 namespace {
 
 constexpr int CAND_CAP = 1 << 16;
+constexpr int CAND_FIRST = 1024;   // candidates that travel with the count in the one copy of detectResultRoi
 
 int set_camera(isx_warper* w, const float K[9], const float R[9]) {
     ISX_CHECK_ARG(K != nullptr && R != nullptr, ISX_ERR_INVALID, "setCameraParams: K and R must be 3x3 CV_32F (got null)");  // W:94-95
@@ -1000,24 +1005,22 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     double px = (double)sw * sh;
     ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
     // The scan ranked the pixels by the stand-ins (d, q).  Collect every pixel whose stand-in is within
-    // a tolerance of one of the four extrema — the tolerance covers the few-ulp error of v_rcp / v_rsq and
-    // of the host's own atan2f many times over — and evaluate mapForward on exactly those with the host's
-    // libm: the result is what the reference code computes on this host.
-    unsigned hk[4];
-    ISX_HIP(hipMemcpyAsync(hk, keys, sizeof(hk), hipMemcpyDeviceToHost, st));
-    ISX_HIP(hipStreamSynchronize(st));
-    const float qmin = fkey_inv(hk[1]), qmax = fkey_inv(hk[3]);
-    const float tol_d = 7.62939453125e-06f;                                   // 2^-17 of a (-2, 2] range
-    const float tol_q = 4e-6f * std::max(std::fabs(qmin), std::fabs(qmax)) + 1e-9f;
-    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(cdiv(sw, 256), cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, keys, tol_d, tol_q, cand, CAND_CAP, count);
-    int n = 0;
-    ISX_HIP(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, st));
-    ISX_HIP(hipStreamSynchronize(st));
+    // a tolerance of one of the four extrema and evaluate mapForward on exactly those with the host's
+    // libm: the result is what the reference code computes on this host.  Scan, candidate pass, the copy of
+    // {count, first candidates} into pinned memory and the re-arming of the keys are enqueued back to back:
+    // ONE stream synchronisation per detectResultRoi (the corner must reach the host, W:148-150,160).
+    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(cdiv(sw, 256), cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, keys, cand, CAND_CAP, count);
+    if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
+    ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
     ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
+    ISX_HIP(hipStreamSynchronize(st));
+    const int n = ((const int*)w->pin)[4];
     ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
     ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the %d x %d source (bad K / R / scale?)", sw, sh);
     w->host_cand.resize((size_t)n * 2);
-    ISX_HIP(hipMemcpy(w->host_cand.data(), cand, (size_t)n * 8, hipMemcpyDeviceToHost));
+    std::memcpy(w->host_cand.data(), (const char*)w->pin + 64, (size_t)std::min(n, CAND_FIRST) * 8);
+    if (n > CAND_FIRST)   // rare: more candidates than the first copy carried
+        ISX_HIP(hipMemcpy(w->host_cand.data() + 2 * (size_t)CAND_FIRST, cand + 2 * (size_t)CAND_FIRST, (size_t)(n - CAND_FIRST) * 8, hipMemcpyDeviceToHost));
     float tl_uf = std::numeric_limits<float>::max(), tl_vf = tl_uf, br_uf = -tl_uf, br_vf = -tl_uf;     // W:66-69
     for (int i = 0; i < n; ++i) {
         float u, v;
@@ -1212,6 +1215,7 @@ int isx_warper_destroy(isx_warper* w) {
     (void)hipSetDevice(w->device);
     (void)hipStreamSynchronize(w->stream);
     if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipEventDestroy(w->ev_warp); (void)hipEventDestroy(w->ev_scan); }   // the side stream is shared per device
+    if (w->pin) (void)hipHostFree(w->pin);
     delete w;
     return ISX_OK;
 }
