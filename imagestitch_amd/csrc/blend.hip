@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <new>
 
@@ -77,6 +78,7 @@ struct Src0 {
     const unsigned char* img_al;
     const unsigned char* mask_al;
     unsigned imis, mmis, iend, mend;
+    int dbg;            // experiments only (ISX_BLEND_DBG): bit 0 = clamp border pairs onto the fast path (wrong pixels, timing only)
 };
 
 // Rectangles of one destination level that earlier feeds have already written.  prepare() does not
@@ -218,7 +220,8 @@ __device__ __forceinline__ RawPair src0_pair_issue(const Src0& s, int x, int y) 
     RawPair r;
     r.v = U3{0u, 0u, 0u}; r.q = U2{0u, 0u}; r.sh = 0u; r.fast = false;
     if constexpr (SK == SK_U8) {
-        const int yr = y - s.top, xr = x - s.left;
+        int yr = y - s.top, xr = x - s.left;
+        if (s.dbg & 1) { yr = min(max(yr, 0), s.rows - 2); xr = min(max(xr, 0), s.cols - 6); }
         if ((unsigned)yr < (unsigned)s.rows && xr >= 0 && xr + 1 < s.cols) {
             const unsigned io = __umul24((unsigned)yr, (unsigned)s.img_step) + __umul24((unsigned)xr, 3u) + s.imis;
             const unsigned mo = __umul24((unsigned)yr, (unsigned)s.mask_step) + (unsigned)xr + s.mmis;
@@ -455,6 +458,40 @@ __device__ __forceinline__ Up4<M> pyr_up_2x2(Px<M> (*ct)[WAVE + 2], int lane, in
     return u;
 }
 
+// The same pyrUp with the fp32 arithmetic packed (v_pk_mul_f32 / v_pk_add_f32 round each half on its own: the bits of pyr_up_2x2).
+// Pairs are chosen so that nothing is shuffled and no half is wasted: (b, g) of a record is a register pair as loaded; the r channel
+// pairs the even-column and odd-column results (t0, t1) of a row, which is exactly what the vertical pass combines alike.
+struct UpPk {
+    f32x2 a[2][2];   // [dy][dx] = (b, g) of fine pixel (dy, dx)
+    f32x2 c[2];      // [dy]     = r of fine pixels (dy, 0) and (dy, 1)
+};
+
+template <int M>
+__device__ __forceinline__ UpPk pyr_up_2x2_pk(Px<M> (*ct)[WAVE + 2], int lane, int wv, int cx, int cw) {
+    static_assert(M != M_I16, "packed pyrUp: float work types only");
+    f32x2 t0a[3], t1a[3], tc[3];      // tc[rr] = (t0, t1) of the r channel
+    const bool edge = cx == 0 || cx == cw - 1;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const Px<M> sm = ct[wv + rr][lane], sc = ct[wv + rr][lane + 1], sp = ct[wv + rr][lane + 2];
+        const f32x2 ma = {sm.c0, sm.c1}, ca = {sc.c0, sc.c1}, pa = {sp.c0, sp.c1};
+        t0a[rr] = (ma + ca * splat2(6.f)) + pa; t1a[rr] = (ca + pa) * splat2(4.f);
+        tc[rr].x = (sm.c2 + sc.c2 * 6.f) + sp.c2; tc[rr].y = (sc.c2 + sp.c2) * 4.f;
+        if (edge) {   // OpenCV's explicit edge formulas (a different fp32 association): two lanes per row
+            if (cw == 1) { t0a[rr] = ca * splat2(8.f); t1a[rr] = t0a[rr]; tc[rr].x = sc.c2 * 8.f; tc[rr].y = tc[rr].x; }
+            else if (cx == 0) { t0a[rr] = ca * splat2(6.f) + pa * splat2(2.f); tc[rr].x = sc.c2 * 6.f + sp.c2 * 2.f; }
+            else { t0a[rr] = ma + ca * splat2(7.f); t1a[rr] = ca * splat2(8.f); tc[rr].x = sm.c2 + sc.c2 * 7.f; tc[rr].y = sc.c2 * 8.f; }
+        }
+    }
+    UpPk u;
+    const f32x2 s64 = splat2(1.f / 64.f);
+    u.a[0][0] = ((t0a[0] + t0a[1] * splat2(6.f)) + t0a[2]) * s64; u.a[0][1] = ((t1a[0] + t1a[1] * splat2(6.f)) + t1a[2]) * s64;
+    u.a[1][0] = ((t0a[1] + t0a[2]) * splat2(4.f)) * s64;          u.a[1][1] = ((t1a[1] + t1a[2]) * splat2(4.f)) * s64;
+    u.c[0] = ((tc[0] + tc[1] * splat2(6.f)) + tc[2]) * s64;
+    u.c[1] = ((tc[1] + tc[2]) * splat2(4.f)) * s64;
+    return u;
+}
+
 // dst += cast(lap * w), dstW += w   (MultiBandBlender::feed accumulate loop)
 template <int M>
 __device__ __forceinline__ void accumulate(const LevelBuf& dst, int x, int y, typename WorkT<M>::t l0,
@@ -598,7 +635,21 @@ struct OutMat {  // the caller's blend() outputs
     int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
 };
 
-template <int M>
+// saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
+// stay below 2^21), so the x86 "integer indefinite" case of cvRound cannot occur and clamping first gives the same integer in three
+// instructions (clamp, round-half-even, convert; NaN clamps to the lower bound as cvRound's INT_MIN saturates to it).
+template <bool BOUNDED>
+__device__ __forceinline__ int f2s16_sat(float v) {
+    if constexpr (BOUNDED) return (int)__builtin_rintf(__builtin_amdgcn_fmed3f(v, -32768.f, 32767.f));
+    else return sat_s16(cvround_x86(v));
+}
+template <bool BOUNDED>
+__device__ __forceinline__ int f2u8_sat(float v) {
+    if constexpr (BOUNDED) return (int)__builtin_rintf(__builtin_amdgcn_fmed3f(v, 0.f, 255.f));
+    else return sat_u8(cvround_x86(v));
+}
+
+template <int M, bool BOUNDED = false>
 __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const Px<M>& d) {
     if (x >= o.cols || y >= o.rows) return;      // crop to dst_roi_final_
     bool on = d.w > WEIGHT_EPS;                  // compare(w0, WEIGHT_EPS, CMP_GT)
@@ -609,9 +660,9 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
         if constexpr (M == M_I16) {
             q[0] = on ? (unsigned char)sat_u8(d.c0) : 0; q[1] = on ? (unsigned char)sat_u8(d.c1) : 0; q[2] = on ? (unsigned char)sat_u8(d.c2) : 0;
         } else {
-            q[0] = on ? (unsigned char)sat_u8(cvround_x86(d.c0)) : 0;
-            q[1] = on ? (unsigned char)sat_u8(cvround_x86(d.c1)) : 0;
-            q[2] = on ? (unsigned char)sat_u8(cvround_x86(d.c2)) : 0;
+            q[0] = on ? (unsigned char)f2u8_sat<BOUNDED>(d.c0) : 0;
+            q[1] = on ? (unsigned char)f2u8_sat<BOUNDED>(d.c1) : 0;
+            q[2] = on ? (unsigned char)f2u8_sat<BOUNDED>(d.c2) : 0;
         }
     } else if (o.img_f32) {
         float* q = (float*)(o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 12u));
@@ -621,20 +672,20 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
         if constexpr (M == M_I16) {
             q[0] = on ? (short)d.c0 : 0; q[1] = on ? (short)d.c1 : 0; q[2] = on ? (short)d.c2 : 0;
         } else {  // saturate_cast<short>(float)
-            q[0] = on ? (short)sat_s16(cvround_x86(d.c0)) : 0;
-            q[1] = on ? (short)sat_s16(cvround_x86(d.c1)) : 0;
-            q[2] = on ? (short)sat_s16(cvround_x86(d.c2)) : 0;
+            q[0] = on ? (short)f2s16_sat<BOUNDED>(d.c0) : 0;
+            q[1] = on ? (short)f2s16_sat<BOUNDED>(d.c1) : 0;
+            q[2] = on ? (short)f2s16_sat<BOUNDED>(d.c2) : 0;
         }
     }
 }
 
 // two horizontally adjacent result pixels (x even): CV_16SC3 = 12 contiguous bytes -> three dword
 // stores when the row is 4-byte aligned (OutMat::vec), mask = one 16-bit store
-template <int M>
+template <int M, bool BOUNDED = false>
 __device__ __forceinline__ void write_final_pair(const OutMat& o, int x, int y, const Px<M>& d0, const Px<M>& d1) {
     if (!o.vec || o.img_f32 || x + 1 >= o.cols) {
-        write_final<M>(o, x, y, d0);
-        write_final<M>(o, x + 1, y, d1);
+        write_final<M, BOUNDED>(o, x, y, d0);
+        write_final<M, BOUNDED>(o, x + 1, y, d1);
         return;
     }
     if (y >= o.rows) return;
@@ -642,8 +693,8 @@ __device__ __forceinline__ void write_final_pair(const OutMat& o, int x, int y, 
     int v[6];
     if constexpr (M == M_I16) { v[0] = d0.c0; v[1] = d0.c1; v[2] = d0.c2; v[3] = d1.c0; v[4] = d1.c1; v[5] = d1.c2; }
     else {
-        v[0] = sat_s16(cvround_x86(d0.c0)); v[1] = sat_s16(cvround_x86(d0.c1)); v[2] = sat_s16(cvround_x86(d0.c2));
-        v[3] = sat_s16(cvround_x86(d1.c0)); v[4] = sat_s16(cvround_x86(d1.c1)); v[5] = sat_s16(cvround_x86(d1.c2));
+        v[0] = f2s16_sat<BOUNDED>(d0.c0); v[1] = f2s16_sat<BOUNDED>(d0.c1); v[2] = f2s16_sat<BOUNDED>(d0.c2);
+        v[3] = f2s16_sat<BOUNDED>(d1.c0); v[4] = f2s16_sat<BOUNDED>(d1.c1); v[5] = f2s16_sat<BOUNDED>(d1.c2);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { if (!on0) v[i] = 0; if (!on1) v[3 + i] = 0; }
@@ -792,12 +843,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
     PT_DECL;
+    // float work types: the accumulators and every stencil operation on (b, g) / (r, -) register pairs (packed fp32, see pyr_up_2x2_pk)
+    constexpr bool PK = M != M_I16;
     WT acc[2][2][3];
+    f32x2 accA[2][2], accC[2], accW[2];     // (b, g) per pixel; r and the weight sum of the two pixels of a fine row
     float accw[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { acc[i][j][0] = 0; acc[i][j][1] = 0; acc[i][j][2] = 0; accw[i][j] = 0.f; }
+        for (int j = 0; j < 2; ++j) { acc[i][j][0] = 0; acc[i][j][1] = 0; acc[i][j][2] = 0; accw[i][j] = 0.f; accA[i][j] = splat2(0.f); accC[i] = splat2(0.f); accW[i] = splat2(0.f); }
     constexpr int NCT = (UP_TY + 2) * (WAVE + 2);
     for (int t0 = 0; t0 < max(ts.n, 1); t0 += G) {
         const bool with_out = t0 + G >= ts.n;
@@ -893,6 +947,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 for (int dy = 0; dy < 2; ++dy)
                     src0_pair_finish<M, SK>(ts.s0[t], 2 * (lx0[s] + lane), 2 * (ly0[s] + wv) + dy, rw[s][dy], gg[s][dy][0], gg[s][dy][1]);
             }
+            if constexpr (PK) {
+                const UpPk u = pyr_up_2x2_pk<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ccl[s]);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {   // acc = acc + (g - pyrUp) * w, accw = accw + w: two values per instruction
+                    const Px<M> g0 = gg[s][dy][0], g1 = gg[s][dy][1];
+                    const f32x2 a0 = {(float)g0.c0, (float)g0.c1}, a1 = {(float)g1.c0, (float)g1.c1}, gc = {(float)g0.c2, (float)g1.c2}, gw = {g0.w, g1.w};
+                    accA[dy][0] = accA[dy][0] + (a0 - u.a[dy][0]) * splat2(g0.w);
+                    accA[dy][1] = accA[dy][1] + (a1 - u.a[dy][1]) * splat2(g1.w);
+                    accC[dy] = accC[dy] + (gc - u.c[dy]) * gw;
+                    accW[dy] = accW[dy] + gw;
+                }
+                continue;
+            }
             Up4<M> u = pyr_up_2x2<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ccl[s]);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
@@ -915,6 +982,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     }
     const int cx = cx0 + lane, cy = cy0 + wv;
     if (cx >= coarse_out.cols || cy >= coarse_out.rows) { PT_FLUSH; return; }
+    // Blends of CV_8UC3 / CV_16SC3 tiles in the last step: every Laplacian is an integer minus a multiple of 2^-30 (a pyrUp of fp32 or
+    // fp16 levels of integer images), every weight a multiple of 2^-8 / 255 or zero, so a normalised numerator is zero or far above
+    // 2^-103 and far below 2^31: the shared-reciprocal division (isx_device.hpp) and the clamp-first conversions are exact.
+    constexpr bool BOUNDED = PK && FINE0 && (SK == SK_U8 || SK == SK_S16);
+    if constexpr (PK) {
+        const UpPk u = pyr_up_2x2_pk<M>(ct[NB - 1], lane, wv, cx, coarse_out.cols);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int fy = 2 * cy + dy;
+            const f32x2 den = accW[dy] + splat2(WEIGHT_EPS);                 // normalizeUsingWeightMap: c / (w + 1e-5f), both pixels of the row
+            f32x2 n0, n1, nc;
+            if constexpr (BOUNDED) {
+                const f32x2 r0 = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                const f32x2 r1 = refine_rcp(den, r0);
+                n0 = div_by_refined(accA[dy][0], splat2(den.x), splat2(r1.x));
+                n1 = div_by_refined(accA[dy][1], splat2(den.y), splat2(r1.y));
+                nc = div_by_refined(accC[dy], den, r1);
+            } else {
+                n0.x = accA[dy][0].x / den.x; n0.y = accA[dy][0].y / den.x; n1.x = accA[dy][1].x / den.y; n1.y = accA[dy][1].y / den.y;
+                nc.x = accC[dy].x / den.x; nc.y = accC[dy].y / den.y;
+            }
+            const f32x2 ra0 = u.a[dy][0] + n0, ra1 = u.a[dy][1] + n1, rc = u.c[dy] + nc;    // restoreImageFromLaplacePyr: pyrUp(out_k) + level
+            Px<M> dd[2];
+            dd[0].c0 = ra0.x; dd[0].c1 = ra0.y; dd[0].c2 = rc.x; dd[0].w = accW[dy].x;
+            dd[1].c0 = ra1.x; dd[1].c1 = ra1.y; dd[1].c2 = rc.y; dd[1].w = accW[dy].y;
+            if constexpr (FINE0) write_final_pair<M, BOUNDED>(out, 2 * cx, fy, dd[0], dd[1]);
+            else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
+        }
+    } else {
     Up4<M> u = pyr_up_2x2<M>(ct[NB - 1], lane, wv, cx, coarse_out.cols);
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
@@ -934,6 +1030,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
         }
         if constexpr (FINE0) write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
         else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
+    }
     }
     PT(10);                     // epilogue: normalise, pyrUp of out, convert, stores issued
     PT_FLUSH;
@@ -1755,6 +1852,7 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     s0.imis = (unsigned)((uintptr_t)s0.img & 3); s0.mmis = (unsigned)((uintptr_t)s0.mask & 3);
     s0.img_al = s0.img - s0.imis; s0.mask_al = s0.mask - s0.mmis;
     s0.iend = 0; s0.mend = 0;
+    { static const int dbg_env = getenv("ISX_BLEND_DBG") ? atoi(getenv("ISX_BLEND_DBG")) : 0; s0.dbg = dbg_env; }
     if (img->type == ISX_8UC3 && (unsigned long long)di.step * img->rows < (1ull << 31) && (unsigned long long)dm.step * img->rows < (1ull << 31) &&
         di.step < (1u << 24) && dm.step < (1u << 24)) {
         s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * 3) + s0.imis;

@@ -65,6 +65,29 @@ __device__ __forceinline__ int sat_s16(int v) { return min(max(v, -32768), 32767
 __device__ __forceinline__ int sat_u8(int v) { return min(max(v, 0), 255); }
 __device__ __forceinline__ int wrap_s16(int v) { return (int)(short)(unsigned short)(unsigned)v; }
 
+// ---- packed fp32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes per instruction, each half rounded on its own, so a packed
+// expression gives the bits of its scalar form) ------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
+
+// IEEE division a / z by the hardware's own recurrence, written out so that several numerators share one reciprocal and two of them
+// ride in one packed FMA:  r1 = r0 + r0 (1 - z r0);  q0 = a r1;  q1 = q0 + r1 (a - z q0);  q = q1 + r1 (a - z q1)   with r0 = v_rcp_f32(z).
+// This is what v_div_scale / v_rcp / v_fma x 5 / v_div_fmas / v_div_fixup compute whenever v_div_scale does not rescale: z and
+// 1 / z normal, the quotient neither denormal nor near overflow, exponent(a) - exponent(z) < 96, |a| >= 2^-103 or a == 0 (then the
+// quotient is a zero, possibly of the other sign).  Callers guarantee that range (isx_selftest_division checks the equality).
+__device__ __forceinline__ f32x2 refine_rcp(f32x2 z, f32x2 r0) {
+    const f32x2 e = pk_fma(-z, r0, splat2(1.f));
+    return pk_fma(e, r0, r0);
+}
+__device__ __forceinline__ f32x2 div_by_refined(f32x2 a, f32x2 z, f32x2 r1) {
+    f32x2 q = a * r1;
+    f32x2 e = pk_fma(-z, q, a);
+    q = pk_fma(e, r1, q);
+    e = pk_fma(-z, q, a);
+    return pk_fma(e, r1, q);
+}
+
 // f16 storage (RNE both ways; conversions are exact widening on load)
 __device__ __forceinline__ unsigned short f2h_bits(float v) { return __half_as_ushort(__float2half_rn(v)); }
 __device__ __forceinline__ float h2f_bits(unsigned short b) { return __half2float(__ushort_as_half(b)); }

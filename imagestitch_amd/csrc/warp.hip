@@ -361,23 +361,6 @@ __global__ __launch_bounds__(256) void k_warp_img_mask(Proj p, MapTabs t, SrcVie
 //  * everything else - reflected borders, z <= 0, the partial thread at the right edge, sources too small for a window - is
 //    fixed up after the row loop by the generic per-byte sampler, kept out of line: the hot loop has no call in it.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
-
-// q = a / z for two pixels, r1 = the refined reciprocal of z (see above): the recurrence the hardware division runs
-__device__ __forceinline__ f32x2 div_by_refined(f32x2 a, f32x2 z, f32x2 r1) {
-    f32x2 q = a * r1;
-    f32x2 e = pk_fma(-z, q, a);
-    q = pk_fma(e, r1, q);
-    e = pk_fma(-z, q, a);
-    return pk_fma(e, r1, q);
-}
-__device__ __forceinline__ f32x2 refine_rcp(f32x2 z, f32x2 r0) {
-    const f32x2 e = pk_fma(-z, r0, splat2(1.f));
-    return pk_fma(e, r0, r0);
-}
-
 constexpr float DIV_Z_LO = 9.5367431640625e-07f;   // 2^-20
 constexpr float DIV_Z_HI = 1048576.f;              // 2^20
 constexpr float RNE_MAGIC = 12582912.f;            // 1.5 * 2^23
