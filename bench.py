@@ -224,6 +224,10 @@ def main():
                     help="spherical (BASELINE config 5) implies --sync-roi: its ROI is a host-side border scan, there is no planned variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
+    ap.add_argument("--gather", default="chunk", choices=["chunk", "single"],
+                    help="N > 1: all-gather the rank's block pair by pair behind each blend (default), or as ONE collective per step")
+    ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx"],
+                    help="N > 1: torch.distributed (RCCL) or the library's own RCCL communicator (isx_gather_*)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cycle", default="deferred", choices=["deferred", "copy", "eager"],
@@ -293,11 +297,14 @@ def main():
     bm = pairs[0].bytes_model()
 
     from imagestitch_amd import mosaic
-    # N > 1 (BASELINE config 4): every rank's blended mosaics are assembled on every rank with ONE all-gather
-    # per step.  The blend writes the 8-bit panorama (blend + convertTo(CV_8U), W:315) straight into the packed
-    # send block (no pack copy); the gather of step i runs on a communication stream under the compute of
-    # step i+1 (two send blocks), because at 4K the gather, not the blend, is the longer of the two.
-    send, gather_buf, comm, ev_compute, ev_gather = None, None, None, None, None
+    # N > 1 (BASELINE config 4): every rank's blended mosaics are assembled on every rank by all-gather over xGMI.  The blend
+    # writes the 8-bit panorama (blend + convertTo(CV_8U), W:315) straight into the packed send block (no pack copy).
+    # --gather chunk (default): the block travels pair by pair - the all-gather of pair p is enqueued on a communication stream
+    # behind pair p's blend, so it runs under the blends of the pairs that follow and, for the last pair, under the next step
+    # (two send blocks); xGMI is point to point, a rank's block crosses each of its links once whatever the schedule, so hiding
+    # the transfer is the lever.  --gather single: ONE all-gather per step, overlapped with the next step only.
+    # --gather-backend torch: torch.distributed (RCCL); isx: the library's own communicator (isx_gather_*, for C++ pipelines).
+    send, gather_buf, comm, ev_pair, ev_gather, chunks, isx_g = None, None, None, None, None, None, None
     if use_dist:
         shapes = [tuple(p.out.shape) for p in pairs]
         # rows of the send block padded to 4 bytes (at most 3 bytes per row more on the wire): the last collapse step then
@@ -307,15 +314,20 @@ def main():
         send = [torch.empty((n_out,), dtype=torch.uint8, device=dev) for _ in range(2)]
         gather_buf = torch.empty((world * n_out,), dtype=torch.uint8, device=dev)
         comm = torch.cuda.Stream(device=dev)
-        ev_compute = [torch.cuda.Event() for _ in range(2)]
+        ev_pair = [[torch.cuda.Event() for _ in pairs] for _ in range(2)]
         ev_gather = [torch.cuda.Event() for _ in range(2)]
-        views = []
+        views, chunks = [], []
         for b in range(2):
             off, vs = 0, []
             for sh, pt in zip(shapes, pitches):
                 n = sh[0] * pt
-                vs.append(send[b][off:off + n].as_strided(sh, (pt, sh[2], 1))); off += n
+                vs.append(send[b][off:off + n].as_strided(sh, (pt, sh[2], 1)))
+                if b == 0:
+                    chunks.append((off, n))
+                off += n
             views.append(vs)
+        if args.gather_backend == "isx":
+            isx_g = mosaic.IsxGather(local)
     if args.graph:
         if use_dist:
             for p, v in zip(pairs, views[0]):
@@ -324,31 +336,58 @@ def main():
             p.capture()
     state = {"i": 0}
 
+    def post_chunk(b, i):
+        """all-gather of pair i's mosaic (chunk i of send[b]) on the communication stream, behind ev_pair[b][i]"""
+        off, n = chunks[i]
+        if isx_g is not None:
+            isx_g.chunk(send[b], off, n, gather_buf, ev_pair[b][i])
+        else:
+            comm.wait_event(ev_pair[b][i])
+            with torch.cuda.stream(comm):
+                mosaic.gather_chunk(send[b], off, n, gather_buf)
+
+    def post_block(b):
+        if isx_g is not None:
+            isx_g.chunk(send[b], 0, n_out, gather_buf, ev_pair[b][-1])
+        else:
+            comm.wait_event(ev_pair[b][-1])
+            with torch.cuda.stream(comm):
+                mosaic.gather_mosaics(send[b], gather_buf)   # ONE all-gather of every rank's blended mosaics
+
+    def gathers_done(b):
+        """record `send[b] has been read by its gathers` for the step that reuses it"""
+        if isx_g is not None:
+            isx_g.wait(comm)
+        ev_gather[b].record(comm)
+
     def step():
         b = state["i"] % 2
         state["i"] += 1
         main = torch.cuda.current_stream()
         if use_dist and not args.graph:
-            main.wait_event(ev_gather[b])          # the gather that last read send[b] (two steps ago) is done
+            main.wait_event(ev_gather[b])          # the gathers that last read send[b] (two steps ago) are done
             for p, v in zip(pairs, views[b]):
                 p.out = v
-        for p in pairs:
+        if args.graph:
+            b = 0                                  # the graphs run on their own streams and always write send[0]
+        for i, p in enumerate(pairs):
             if args.graph:
                 p.replay()
             elif args.sync_roi:
                 p.step_sync()
             else:
                 p.step()
+            if use_dist:
+                ev_pair[b][i].record(p.gstream if args.graph else main)
+                if args.gather == "chunk":
+                    post_chunk(b, i)
         if use_dist:
-            if args.graph:   # the graphs run on their own streams and always write send[0]
-                b = 0
-                for p in pairs:
-                    main.wait_stream(p.gstream)
-            ev_compute[b].record(main)
-            comm.wait_event(ev_compute[b])
-            with torch.cuda.stream(comm):
-                mosaic.gather_mosaics(send[b], gather_buf)   # ONE all-gather of every rank's blended mosaics
-                ev_gather[b].record(comm)
+            if args.gather == "single":
+                if args.graph:
+                    for i in range(len(pairs) - 1):
+                        comm.wait_event(ev_pair[b][i])
+                post_block(b)
+            gathers_done(b)
             if args.graph:
                 for p in pairs:
                     p.gstream.wait_event(ev_gather[b])         # the next replay overwrites send[0]
@@ -413,7 +452,10 @@ def main():
         dt_c = time.perf_counter() - t1
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            mosaic.gather_mosaics(send[0], gather_buf)
+            if isx_g is not None:
+                isx_g.all(send[0], gather_buf)
+            else:
+                mosaic.gather_mosaics(send[0], gather_buf)
         fence()
         dt_g = time.perf_counter() - t1
         t = torch.tensor([dt, dt_c, dt_g], dtype=torch.float64, device=dev)
@@ -440,7 +482,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s%d x (%d x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
                 ("%d x %dx%d tiles, %d tiles/GPU: " % (world * args.pairs * NT, W, H, args.pairs * NT)) if world > 1 else "",
-                args.pairs, NT, W, H, args.kind, F, args.bands, args.precision, ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step" if use_dist else ""),
+                args.pairs, NT, W, H, args.kind, F, args.bands, args.precision, (", u8x3 mosaics all-gathered pair by pair behind each blend (%s)" % args.gather_backend if args.gather == "chunk" else
+                 ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step (%s)" % args.gather_backend) if use_dist else ""),
                 "tiles_per_mosaic": NT,
                 "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
@@ -454,8 +497,9 @@ def main():
             out["multi_gpu"] = {"without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),
                                 "gather_alone_ms": round(dt_g / args.steps * 1e3, 4), "send_bytes_per_rank": nsend,
                                 "gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1),
-                                "note": "value = steps with the gather of step i overlapped with step i+1; the two legs here are timed after it, "
-                                        "each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}
+                                "gather": args.gather, "gather_backend": args.gather_backend,
+                                "note": "value = steps with the gathers overlapped with the blends that follow them; the two legs here are timed after "
+                                        "it, each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}
         if world == 1 and not args.no_dropin:
             for p in pairs:
                 del p

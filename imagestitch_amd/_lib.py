@@ -91,6 +91,15 @@ _SIGS = {
     "isx_blender_debug_level": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _IP, _IP],
     "isx_blend_pair_linear_size": [C.c_int] * 8 + [_IP, _IP],
     "isx_blend_pair_linear": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, _MP, _IP, C.c_int, C.c_void_p],
+    "isx_gather_unique_id": [C.c_char_p],
+    "isx_gather_create": [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)],
+    "isx_gather_destroy": [C.c_void_p],
+    "isx_gather_info": [C.c_void_p, _IP, _IP],
+    "isx_gather_all": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p],
+    "isx_gather_chunk": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p],
+    "isx_gather_chunk_ptr": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)],
+    "isx_gather_wait": [C.c_void_p, C.c_void_p],
+    "isx_gather_synchronize": [C.c_void_p],
     "isx_selftest_division": [C.c_int, C.c_int, C.c_ulonglong, _IP],
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],

@@ -296,6 +296,34 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2,
                           int tl1_x, int tl1_y, int tl2_x, int tl2_y,
                           isx_mat* pano, int* seam_x, int device, void* hip_stream);
 
+/* ---- assembling a batch of mosaics across the GPUs of a node (no counterpart in the reference; BASELINE config 4) ---------------- */
+/* One process per GPU.  The independent pairs of a batch are partitioned across the ranks (no collective while blending); each rank
+ * writes its blended mosaics into ONE packed send block, and every rank ends up with all blocks: an all-gather over RCCL (xGMI).
+ * The library loads librccl.so.1 at the first of these calls (dlopen; inside a torch process that is torch's own copy).
+ *   isx_gather_unique_id : rank 0 creates the 128-byte rendezvous id and hands it to the other ranks by any means it has (a file,
+ *                          a socket, MPI_Bcast, torch.distributed.broadcast_object_list).
+ *   isx_gather_create    : collective over all ranks; `device` is this rank's GPU.
+ *   isx_gather_all       : ONE all-gather of `bytes` bytes from `send` into recv[rank * bytes ...) on `hip_stream`.
+ *   isx_gather_chunk     : the same block gathered chunk by chunk (a chunk = one pair's mosaic, [offset, offset + bytes) of the send
+ *                          block): enqueued on the handle's own communication stream behind `ready_event` (a hipEvent_t the caller
+ *                          recorded after enqueueing that pair's blend; NULL = now), so the transfer of pair p runs under the blends
+ *                          of the pairs after it.  Chunks land rank-major PER CHUNK: isx_gather_chunk_ptr gives the address of
+ *                          (rank, chunk) inside recv_base, which must hold world * block_bytes bytes.  Every rank must post the
+ *                          same chunks in the same order.
+ *   isx_gather_wait      : makes `hip_stream` wait (without blocking the host) for every chunk enqueued so far;
+ *   isx_gather_synchronize blocks the host until they are done.                                                             */
+typedef struct isx_gather isx_gather;
+int isx_gather_unique_id(unsigned char id[128]);
+int isx_gather_create(int world, int rank, const unsigned char id[128], int device, isx_gather** out);
+int isx_gather_destroy(isx_gather* g);
+int isx_gather_info(const isx_gather* g, int* world, int* rank);
+int isx_gather_all(isx_gather* g, const void* send, size_t bytes, void* recv, void* hip_stream);
+int isx_gather_chunk(isx_gather* g, const void* send_base, size_t block_bytes, size_t offset, size_t bytes, void* recv_base,
+                     void* ready_event);
+int isx_gather_chunk_ptr(const isx_gather* g, void* recv_base, size_t offset, size_t bytes, int rank, void** ptr);
+int isx_gather_wait(isx_gather* g, void* hip_stream);
+int isx_gather_synchronize(isx_gather* g);
+
 /* ---- self-test --------------------------------------------------------------------------------- */
 /* The fused warp kernel divides x / z and y / z with one shared reciprocal and the hardware division's own recurrence
  * written out in packed FMAs (csrc/warp.hip, k_warp_tile).  This compares that recurrence with the compiler's IEEE division

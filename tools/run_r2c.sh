@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5)
-python tools/pipeline_probe.py 1 5 2>&1 | grep "ms/pair\|collapse\|pyr_down\|warp"
-python tools/pipeline_probe.py 2 5 2>&1 | grep "ms/pair\|collapse_gather_final"
-python tools/pipeline_probe.py 0 5 2>&1 | grep "ms/pair\|collapse_gather_final"
+(timeout 900 python -m pytest tests/test_gpu_dist.py -x -q 2>&1 | tail -15)
+for g in chunk single; do for be in torch isx; do
+ echo "== gather $g backend $be"; timeout 300 python bench.py --force-dist --pairs 4 --gather $g --gather-backend $be --steps 10 --warmup 3 2>&1 | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['ms_per_step'], d.get('multi_gpu'))"
+done; done
+echo "== graph"; timeout 300 python bench.py --force-dist --pairs 4 --graph --steps 10 --warmup 3 2>&1 | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['ms_per_step'], d['config']['workload'])"
