@@ -163,6 +163,37 @@ def test_linear_pair_blend(gpu, oracle, dy):
     assert np.array_equal(pano, opano, equal_nan=True), np.argwhere(pano != opano)[:5]
 
 
+def test_linear_pair_blend_4k(gpu, oracle):
+    """A13 at the size of a warped 4K pair (3416 x 2170 tiles, 1257-column overlap = 20 of k_lin_seam's 64-column LDS windows, the
+    seam free to wander across them), device mats."""
+    import ctypes as C
+    import torch
+    from imagestitch_amd import _lib
+    rng = np.random.default_rng(41)
+    h1, w1, h2, w2 = 2170, 3416, 2166, 3416
+    yy, xx = np.mgrid[0:h1, 0:w1].astype(np.float32)
+    base = 120.0 + 60.0 * np.sin(xx / 97.0) * np.cos(yy / 61.0)
+    img1 = np.clip(base[..., None] + rng.normal(0, 1, (h1, w1, 3)), 0, 255).astype(np.float32)
+    shifted = np.roll(base, -2159, axis=1)[:h2, :w2]
+    # the two tiles agree along a slanted line through the overlap: the greedy seam (B:268-307) follows it from column 628 to 1167
+    valley = np.minimum(0.8 * np.abs(xx[:h2, :w2] - (628.0 + 0.25 * yy[:h2, :w2])), 60.0)
+    valley[:, 1257:] = 0
+    img2 = np.clip((shifted + valley)[..., None] + rng.normal(0, 1, (h2, w2, 3)), 0, 255).astype(np.float32)
+    img1[:300, -500:] = 2.0; img2[-400:, :350] = 1.0; img2[900:1000, 200:300] = 3.0
+    tl1, tl2 = (-2788, -1085), (-2788 + 2159, -1085 + 4)
+    rc, opano, oseam = oracle.blend_pair_linear(img1, img2, tl1, tl2)
+    assert rc == 0 and (oseam.max() - oseam.min()) > 500      # the greedy seam crosses eight of the 64-column windows
+    lib = _lib.load()
+    t1, t2 = torch.from_numpy(img1).cuda(), torch.from_numpy(img2).cuda()
+    pano = torch.empty(opano.shape, dtype=torch.float32, device="cuda")
+    seam = np.zeros(opano.shape[0], np.int32)
+    m1, m2, mp = _lib.as_mat(t1), _lib.as_mat(t2), _lib.as_mat(pano)
+    _lib.check(lib.isx_blend_pair_linear(C.byref(m1), C.byref(m2), tl1[0], tl1[1], tl2[0], tl2[1], C.byref(mp), seam.ctypes.data_as(_lib._IP), 0, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(seam, oseam)
+    assert np.array_equal(pano.cpu().numpy(), opano, equal_nan=True)
+
+
 def test_blend_on_reference_artefact_crops(gpu, oracle):
     """Inputs: crops of the reference's committed images_warped_f[*].bmp and its real DP-seam masks
     mask_seam[*].bmp (S:1195-1198); blender configured as the reference does (setNumBands(4), W:273)."""

@@ -1,0 +1,18 @@
+"""A 20-second, fixed-seed slice of tools/fuzz_parity.py (the randomised HIP-vs-oracle sweep over every entry point: warps, the fused
+tile kernel, the blenders in all precisions and cycles, mask preparation, the seam finder, the linear pair blend, whole pairs through
+PairStitcher) under -m gpu.  The long soaks are kept as JSON summaries under profiles/."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fuzz_slice_20s(gpu):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import fuzz_parity
+    out = fuzz_parity.run(20.0, 20260928, verbose=True)
+    assert out["mismatches"] == 0, out["failing_seeds"]
+    assert out["cases"] >= 100 and all(v["cases"] > 0 for v in out["per_family"].values()), out["per_family"]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: HIP path vs the CPU oracle on random geometries (run on the GPU box).
-    python tools/fuzz_parity.py [seconds] [seed]
-Every failure prints the seed of the case so that it can be replayed; exit code = number of failing cases."""
+    python tools/fuzz_parity.py [seconds] [seed] [summary.json]
+Every failure prints the seed of the case so that it can be replayed; exit code = number of failing cases.  With a third argument the
+summary (cases, seconds, seed, mismatches per family) is also written as JSON - the file kept under profiles/.
+tests/test_gpu_fuzz_slice.py runs run(20 s, fixed seed) under -m gpu."""
 import os
 import sys
 import time
@@ -189,15 +191,86 @@ def case_find(rng):
         assert np.array_equal(a, b), np.argwhere(a != b)[:3]
 
 
-CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find]
+def case_warp_fused(rng):
+    """The hot fused tile kernel (image LINEAR / REFLECT + mask NEAREST / CONSTANT of an all-255 mask, W:229 + W:232) on device
+    tensors: dense and pitched destinations (per-pixel / dword stores), CV_8UC3 and CV_16SC3 outputs, cameras that look past the
+    image (reflected taps on every side) and far past it (z <= 0 columns), both projectors."""
+    import torch
+    w, h = int(rng.integers(2, 700)), int(rng.integers(2, 500))
+    f = float(rng.uniform(0.25, 3.0) * max(w, h))
+    K = np.array([[f, 0, w / 2 + rng.uniform(-5, 5)], [0, f * rng.uniform(0.9, 1.1), h / 2 + rng.uniform(-5, 5)], [0, 0, 1]], np.float32)
+    R = rot(rng, float(rng.choice([0.2, 0.6, 1.2])))
+    kind = int(rng.integers(0, 2))
+    src = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    roi, _ = O.detect_roi(kind, f, K, R, w, h)
+    dw, dh = int(roi[2]) - int(roi[0]) + 1, int(roi[3]) - int(roi[1]) + 1
+    if dw < 1 or dh < 1 or dw > 60000 or dh > 60000 or dw * dh > 4_000_000:
+        return "skip"
+    out16, pitched = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    wp = (G.CylindricalWarper() if kind == 0 else G.SphericalWarper()).create(f)
+    t = torch.from_numpy(src).cuda()
+    if pitched:
+        es = 2 if out16 else 1
+        pit = (dw * 3 * es + 63) // 64 * 64
+        di = torch.zeros((dh * pit // es,), dtype=torch.int16 if out16 else torch.uint8, device="cuda").as_strided((dh, dw, 3), (pit // es, 3, 1))
+        pm = (dw + 63) // 64 * 64
+        dm = torch.zeros((dh * pm,), dtype=torch.uint8, device="cuda").as_strided((dh, dw), (pm, 1))
+        c, wi, wm = wp.warp_with_mask(t, K, R, dst_img=di, dst_mask=dm)
+    else:
+        c, wi, wm = wp.warp_with_mask(t, K, R, out16=out16)
+    oc, oi, _ = O.warp_u8(kind, f, K, R, src, 1, 2)
+    _, om, _ = O.warp_u8(kind, f, K, R, np.full((h, w), 255, np.uint8), 0, 0)
+    assert tuple(c) == tuple(oc)
+    assert np.array_equal(wi.cpu().numpy(), oi.astype(np.int16) if out16 else oi), np.argwhere(wi.cpu().numpy() != oi)[:3]
+    assert np.array_equal(wm.cpu().numpy(), om)
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def case_linear_pair(rng):
+    """A13, the reference's in-tree linear-ramp pair blend (B:141-717): random sizes (up to several LDS seam windows wide), offsets
+    of either sign, dark regions so that every overlap class occurs."""
+    import ctypes as C
+    from imagestitch_amd import _lib
+    big = rng.random() < 0.15
+    h1, w1 = int(rng.integers(20, 900 if big else 200)), int(rng.integers(40, 1400 if big else 260))
+    h2, w2 = h1 + int(rng.integers(-6, 7)), int(rng.integers(40, 1400 if big else 260))
+    if h2 < 8:
+        return "skip"
+    img1 = rng.random((h1, w1, 3)).astype(np.float32) * 255
+    img2 = rng.random((h2, w2, 3)).astype(np.float32) * 255
+    for im in (img1, img2):                       # dark patches: the 1/0, 0/1 and 1/1 overlap classes (B:332-470)
+        for _ in range(int(rng.integers(0, 4))):
+            y, x = int(rng.integers(0, im.shape[0])), int(rng.integers(0, im.shape[1]))
+            im[y:y + int(rng.integers(2, 40)), x:x + int(rng.integers(2, 60))] = float(rng.uniform(0, 8))
+    ov = int(rng.integers(8, max(9, min(w1, w2) - 4)))
+    tl1 = (int(rng.integers(-50, 50)), int(rng.integers(-50, 50)))
+    tl2 = (tl1[0] + w1 - ov, tl1[1] + int(rng.integers(-6, 7)))
+    rc, opano, oseam = O.blend_pair_linear(img1, img2, tl1, tl2)
+    lib = _lib.load()
+    pr, pc = C.c_int(), C.c_int()
+    _lib.check(lib.isx_blend_pair_linear_size(h1, w1, h2, w2, tl1[0], tl1[1], tl2[0], tl2[1], C.byref(pr), C.byref(pc)))
+    assert (pr.value, pc.value) == opano.shape[:2]
+    pano = np.empty_like(opano)
+    seam = np.zeros(opano.shape[0], np.int32)
+    m1, m2, mp = _lib.as_mat(img1), _lib.as_mat(img2), _lib.as_mat(pano)
+    grc = lib.isx_blend_pair_linear(C.byref(m1), C.byref(m2), tl1[0], tl1[1], tl2[0], tl2[1], C.byref(mp), seam.ctypes.data_as(_lib._IP), 0, None)
+    assert (grc == 0) == (rc == 0), (grc, rc)
+    if rc != 0:
+        return "skip"                            # no overlap: both sides return without a panorama (B:182-183)
+    assert np.array_equal(seam, oseam)
+    assert np.array_equal(pano, opano, equal_nan=True), np.argwhere(pano != opano)[:5]
+
+
+CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
+         case_linear_pair]
+
+
+def run(budget, seed0, verbose=True):
+    """Round-robin over the case families for `budget` seconds; case n uses seed seed0 * 1000003 + n.  Returns the summary dict."""
     G.load()
     t0, n, bad, skipped = time.time(), 0, 0, 0
     counts = {f.__name__: 0 for f in CASES}
+    fails = {f.__name__: 0 for f in CASES}
+    failing_seeds = []
     while time.time() - t0 < budget:
         fn = CASES[n % len(CASES)]
         seed = seed0 * 1000003 + n
@@ -206,19 +279,44 @@ def main():
             skipped += r == "skip"
             counts[fn.__name__] += 1
         except AssertionError:
-            bad += 1
-            print("FAIL", fn.__name__, "seed", seed)
-            traceback.print_exc(limit=2)
+            bad += 1; fails[fn.__name__] += 1; failing_seeds.append([fn.__name__, seed])
+            if verbose:
+                print("FAIL", fn.__name__, "seed", seed)
+                traceback.print_exc(limit=2)
         except Exception as e:   # geometry the reference itself rejects must be rejected the same way on both sides
             try:
                 code = getattr(e, "code", None)
             except Exception:
                 code = None
-            print("EXC ", fn.__name__, "seed", seed, type(e).__name__, code, str(e)[:120])
-            bad += 1
+            if verbose:
+                print("EXC ", fn.__name__, "seed", seed, type(e).__name__, code, str(e)[:120])
+            bad += 1; fails[fn.__name__] += 1; failing_seeds.append([fn.__name__, seed])
         n += 1
-    print("cases", n, counts, "skipped", skipped, "failures", bad, "in %.0f s" % (time.time() - t0))
-    return bad
+    return {"cases": n, "seconds": round(time.time() - t0, 1), "seed": seed0, "mismatches": bad, "skipped_geometries": int(skipped),
+            "per_family": {k: {"cases": counts[k], "mismatches": fails[k]} for k in counts}, "failing_seeds": failing_seeds[:50]}
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    out = run(budget, seed0)
+    print("cases", out["cases"], {k: v["cases"] for k, v in out["per_family"].items()}, "skipped", out["skipped_geometries"],
+          "failures", out["mismatches"], "in %.0f s" % out["seconds"])
+    if len(sys.argv) > 3:
+        import json
+        import subprocess
+        try:
+            out["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            pass
+        try:
+            import torch
+            out["device"] = torch.cuda.get_device_name(0)
+        except Exception:
+            pass
+        with open(sys.argv[3], "w") as f:
+            json.dump(out, f, indent=1)
+    return out["mismatches"]
 
 
 if __name__ == "__main__":

@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests/test_gpu_dist.py -x -q 2>&1 | tail -15)
-for g in chunk single; do for be in torch isx; do
- echo "== gather $g backend $be"; timeout 300 python bench.py --force-dist --pairs 4 --gather $g --gather-backend $be --steps 10 --warmup 3 2>&1 | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['ms_per_step'], d.get('multi_gpu'))"
-done; done
-echo "== graph"; timeout 300 python bench.py --force-dist --pairs 4 --graph --steps 10 --warmup 3 2>&1 | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['ms_per_step'], d['config']['workload'])"
+(timeout 900 python -m pytest tests/test_gpu_blend.py::test_linear_pair_blend_4k tests/test_gpu_fuzz_slice.py -x -q 2>&1 | tail -15)
+mkdir -p gpurun_out/fuzz
+timeout 1000 python tools/fuzz_parity.py 600 7 gpurun_out/fuzz/round2_fuzz_600s_seed7.json 2>&1 | tail -5
