@@ -51,6 +51,7 @@ _SIGS = {
     "isx_warper_camera": [C.c_void_p, _F9, _F9, _F9, _F9],
     "isx_warper_roi": [C.c_void_p, C.c_int, C.c_int, _F9, _F9, _IP, _F9],
     "isx_warper_build_maps": [C.c_void_p, C.c_int, C.c_int, _F9, _F9, _MP, _MP, _IP],
+    "isx_warper_build_maps_roi": [C.c_void_p, _F9, _F9, _IP, _MP, _MP],
     "isx_warper_warp": [C.c_void_p, _MP, _F9, _F9, C.c_int, C.c_int, _MP, _IP],
     "isx_warper_warp_roi": [C.c_void_p, _MP, _F9, _F9, C.c_int, C.c_int, _IP, _MP],
     "isx_warper_warp_with_mask_roi": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],

@@ -1372,6 +1372,28 @@ int fill_uncovered(isx_blender* b, int level) {
     return ISX_OK;
 }
 
+// Level-0 pixels of the rectangle (x, y, w, h) that an earlier feed of this cycle has already written (the union of its intersections
+// with the Cover rectangles): only those are READ by the accumulate kernels - a pixel no earlier feed covered is stored, not
+// read-modified-written - so only those count as read traffic in the kernels' algorithmic bytes.
+double covered_px(const isx_blender* b, int x, int y, int w, int h) {
+    if (b->cleared) return (double)w * h;
+    std::vector<int> xs{x, x + w}, ys{y, y + h};
+    std::vector<int4> r;
+    for (const int4& f : b->fed) {
+        const int x0 = std::max(x, f.x), y0 = std::max(y, f.y), x1 = std::min(x + w, f.x + f.z), y1 = std::min(y + h, f.y + f.w);
+        if (x0 < x1 && y0 < y1) { r.push_back(make_int4(x0, y0, x1, y1)); xs.push_back(x0); xs.push_back(x1); ys.push_back(y0); ys.push_back(y1); }
+    }
+    std::sort(xs.begin(), xs.end()); std::sort(ys.begin(), ys.end());
+    double area = 0.0;
+    for (size_t i = 0; i + 1 < xs.size(); ++i)
+        for (size_t j = 0; j + 1 < ys.size(); ++j) {
+            if (xs[i] == xs[i + 1] || ys[j] == ys[j + 1]) continue;
+            for (const int4& q : r)
+                if (xs[i] >= q.x && xs[i + 1] <= q.z && ys[j] >= q.y && ys[j + 1] <= q.w) { area += (double)(xs[i + 1] - xs[i]) * (ys[j + 1] - ys[j]); break; }
+        }
+    return area;
+}
+
 int src_kind_of(int type) { return type == ISX_8UC3 ? SK_U8 : (type == ISX_16SC3 ? SK_S16 : SK_F32); }
 double src_px_bytes(int sk) { return sk == SK_U8 ? 3.0 : (sk == SK_S16 ? 6.0 : 12.0); }
 
@@ -1394,6 +1416,8 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
         a.s0 = s0; a.L = L; a.x_tl = x_tl; a.y_tl = y_tl; a.cov0 = make_cover(b, 0);
         double bytes = 0.0;
         int nb = 0;
+        // destination records: every one is written, only those an earlier feed covered are read first
+        const double rd_frac = covered_px(b, x_tl, y_tl, g[0].cols, g[0].rows) / ((double)g[0].rows * g[0].cols);
         for (int k = 0; k <= L; ++k) {
             a.g[k] = g[k]; a.dst[k] = b->dst[k];
             a.blk_start[k] = nb;
@@ -1404,11 +1428,11 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
             } else if (k < L) {
                 a.gw[k] = cdiv(g[k + 1].cols, WAVE);
                 nb += a.gw[k] * cdiv(g[k + 1].rows, UP_TY);
-                bytes += px * (gin + 2.0 * alg_d(prec)) + (double)g[k + 1].rows * g[k + 1].cols * alg_g_rgb(prec);
+                bytes += px * (gin + (1.0 + rd_frac) * alg_d(prec)) + (double)g[k + 1].rows * g[k + 1].cols * alg_g_rgb(prec);
             } else {
                 a.gw[k] = cdiv(g[k].cols, 64);
                 nb += a.gw[k] * cdiv(g[k].rows, 4);
-                bytes += px * (gin + 2.0 * alg_d(prec));
+                bytes += px * (gin + (1.0 + rd_frac) * alg_d(prec));
             }
         }
         a.blk_start[L + 1] = nb;
@@ -1416,10 +1440,11 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
         return ISX_OK;
     }
     int xt = x_tl, yt = y_tl;
+    const double rd_frac2 = covered_px(b, x_tl, y_tl, g[0].cols, g[0].rows) / ((double)g[0].rows * g[0].cols);
     for (int k = 0; k < L; ++k) {
         dim3 grid(cdiv(g[k + 1].cols, WAVE), cdiv(g[k + 1].rows, UP_TY));
         double fine_px = (double)g[k].rows * g[k].cols, coarse_px = (double)g[k + 1].rows * g[k + 1].cols;
-        double bytes = fine_px * ((k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + 2.0 * alg_d(prec)) + coarse_px * alg_g_rgb(prec);
+        double bytes = fine_px * ((k == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + (1.0 + rd_frac2) * alg_d(prec)) + coarse_px * alg_g_rgb(prec);
         Cover cov = make_cover(b, k);
         if (k == 0) ISX_LAUNCH("lap_acc_l0", bytes, st, (k_lap_acc<M, SK>), grid, dim3(256), 0, s0, g[0], g[1], b->dst[0], xt, yt, cov);
         else ISX_LAUNCH("lap_acc", bytes, st, (k_lap_acc<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[k], g[k + 1], b->dst[k], xt, yt, cov);
@@ -1428,7 +1453,7 @@ int run_feed(isx_blender* b, const Src0& s0, LevelBuf* g, int L, int x_tl, int y
     {
         dim3 grid(cdiv(g[L].cols, 64), cdiv(g[L].rows, 4));
         double px = (double)g[L].rows * g[L].cols;
-        double bytes = px * ((L == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + 2.0 * alg_d(prec));
+        double bytes = px * ((L == 0 ? src_px_bytes(SK) + 1.0 : alg_g(prec)) + (1.0 + rd_frac2) * alg_d(prec));
         Cover cov = make_cover(b, L);
         if (L == 0) ISX_LAUNCH("top_acc", bytes, st, (k_top_acc<M, SK>), grid, dim3(256), 0, s0, g[0], b->dst[0], xt, yt, g[0].rows, g[0].cols, cov);
         else ISX_LAUNCH("top_acc", bytes, st, (k_top_acc<M, SK_LEVEL>), grid, dim3(256), 0, s0, g[L], b->dst[L], xt, yt, g[L].rows, g[L].cols, cov);
@@ -1671,7 +1696,7 @@ int feather_accumulate(isx_blender* b, const isx_blender::FeatherRec& r) {
     }
     const Cover cov = make_cover(b, 0);
     dim3 grid(cdiv(r.cols, 64), cdiv(r.rows, 4));
-    const double bytes = (double)r.rows * r.cols * ((r.sk == SK_U8 ? 3.0 : 6.0) + 4.0 + 2.0 * 12.0);
+    const double bytes = (double)r.rows * r.cols * ((r.sk == SK_U8 ? 3.0 : 6.0) + 4.0 + 12.0) + covered_px(b, r.dx, r.dy, r.cols, r.rows) * 12.0;
     if (r.sk == SK_U8) ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_U8>), grid, dim3(256), 0, r.img, r.istep, (const float*)r.wgt, r.wpitch, r.rows, r.cols, b->dst[0], r.dx, r.dy, cov);
     else ISX_LAUNCH("feather_acc", bytes, st, (k_feather_acc<SK_S16>), grid, dim3(256), 0, r.img, r.istep, (const float*)r.wgt, r.wpitch, r.rows, r.cols, b->dst[0], r.dx, r.dy, cov);
     if (!b->cleared) b->fed.push_back(make_int4(r.dx, r.dy, r.cols, r.rows));

@@ -1234,15 +1234,15 @@ int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const 
     return detect_roi(w, src_w, src_h, roi, minmax, false, nullptr);
 }
 
-int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4]) {
-    clear_error();
+namespace {
+int build_maps_common(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4], bool given_roi) {
     ISX_CHECK_ARG(w != nullptr && roi != nullptr, ISX_ERR_INVALID, "buildMaps: null argument");
     ISX_TRY(check_mat(xmap, "buildMaps: xmap"));
     ISX_TRY(check_mat(ymap, "buildMaps: ymap"));
     ISX_CHECK_ARG(xmap->type == ISX_32FC1 && ymap->type == ISX_32FC1, ISX_ERR_TYPE, "buildMaps: maps must be CV_32FC1");
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(set_camera(w, K, R));
-    ISX_TRY(detect_roi(w, src_w, src_h, roi, nullptr, false, nullptr));
+    if (!given_roi) ISX_TRY(detect_roi(w, src_w, src_h, roi, nullptr, false, nullptr));
     ISX_TRY(check_roi_sane(roi));
     const int dw = roi[2] - roi[0] + 1, dh = roi[3] - roi[1] + 1;   // W:128-129
     ISX_CHECK_ARG(xmap->rows == dh && xmap->cols == dw && ymap->rows == dh && ymap->cols == dw, ISX_ERR_SIZE,
@@ -1258,6 +1258,19 @@ int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9],
     ISX_TRY(w->st_x.finish_out(st));
     ISX_TRY(w->st_y.finish_out(st));
     return ISX_OK;
+}
+}  // namespace
+
+int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4]) {
+    clear_error();
+    return build_maps_common(w, src_w, src_h, K, R, xmap, ymap, roi, false);
+}
+
+int isx_warper_build_maps_roi(isx_warper* w, const float K[9], const float R[9], const int roi[4], isx_mat* xmap, isx_mat* ymap) {
+    clear_error();
+    ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "buildMaps: null roi");
+    int r[4] = {roi[0], roi[1], roi[2], roi[3]};
+    return build_maps_common(w, 0, 0, K, R, xmap, ymap, r, true);
 }
 
 int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int interp, int border, isx_mat* dst, int device, void* hip_stream) {

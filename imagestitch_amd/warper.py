@@ -73,6 +73,17 @@ class RotationWarper:
             return tuple(roi), np.array(list(mm), np.float32)
         return tuple(roi)
 
+    def buildMapsRoi(self, K, R, roi, like=None):
+        """The map fill of buildMaps (W:133-141) over a given rectangle (tl.x, tl.y, br.x, br.y) -> (xmap, ymap)."""
+        shape = (roi[3] - roi[1] + 1, roi[2] - roi[0] + 1)
+        xm = _empty_like_kind(like, shape, np.float32) if like is not None else np.empty(shape, np.float32)
+        ym = _empty_like_kind(like, shape, np.float32) if like is not None else np.empty(shape, np.float32)
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        mx, my = as_mat(xm), as_mat(ym)
+        check(self._lib.isx_warper_build_maps_roi(self._h, kp, rp, (C.c_int * 4)(*[int(v) for v in roi]), C.byref(mx), C.byref(my)))
+        return xm, ym
+
     def buildMaps(self, src_size, K, R, like=None):
         """buildMaps (W:122-144) -> (roi, xmap, ymap)."""
         roi = self.warpRoi(src_size, K, R)

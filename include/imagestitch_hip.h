@@ -121,6 +121,10 @@ int isx_warper_set_roi_cache(isx_warper* w, int on);
 int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9],
                           isx_mat* xmap, isx_mat* ymap, int roi[4]);
 
+/* The map fill of buildMaps (W:133-141) over a rectangle the caller already has - isx_warper_roi's result for this camera, or the
+ * rectangle of maps it keeps - without the scan: xmap(v - roi[1], u - roi[0]) = mapBackward(u, v).x, same for ymap.               */
+int isx_warper_build_maps_roi(isx_warper* w, const float K[9], const float R[9], const int roi[4], isx_mat* xmap, isx_mat* ymap);
+
 /* Point warp(src,K,R,interp,border,dst) (W:145-161; stock call sites B:105,109): buildMaps +
  * cv::remap (W:157) fused into one gather kernel; the maps are never written to HBM.
  * src: CV_8UC3 / CV_8UC1 (fixed-point bilinear) or CV_32FC3 / CV_32FC1 (float bilinear).

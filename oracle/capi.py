@@ -313,6 +313,20 @@ def blend_pair_linear(img1, img2, tl1, tl2):
     return rc, pano, seam
 
 
+def pair_linear_costv(img1, img2, tl1, tl2):
+    """costV of B:207-261 (what B:265 writes to costV.bmp) -> float32 (interSectHe_, interSectBr_ + 2)."""
+    img1, img2 = _c(img1, np.float32), _c(img2, np.float32)
+    pr, pc = C.c_int(), C.c_int()
+    lib().orc_blend_pair_linear_size(img1.shape[0], img1.shape[1], img2.shape[0], img2.shape[1],
+                                     int(tl1[0]), int(tl1[1]), int(tl2[0]), int(tl2[1]), C.byref(pr), C.byref(pc))
+    ibr = img1.shape[1] - (int(tl2[0]) - int(tl1[0]))
+    pano = np.empty((pr.value, pc.value, 3), np.float32)
+    cost = np.zeros((pr.value, ibr + 2), np.float32)
+    rc = lib().orc_pair_linear_costv(_p(img1), img1.shape[0], img1.shape[1], _p(img2), img2.shape[0], img2.shape[1],
+                                     int(tl1[0]), int(tl1[1]), int(tl2[0]), int(tl2[1]), _p(pano), _p(cost))
+    return rc, cost
+
+
 # ---------------------------------------------------------------- verbatim reference (W:30-63)
 def ref_set(scale, r_kinv, k_rinv):
     r, k = _c(r_kinv, np.float32), _c(k_rinv, np.float32)

@@ -676,6 +676,19 @@ void orc_blend_pair_linear_size(int rows1, int cols1, int rows2, int cols2,
 
 static inline float sqrf(float v) { return v * v; }
 
+/* costV of B:207-261 alone (interSectHe_ x (interSectBr_ + 2) floats, what B:265 writes to costV.bmp): test infrastructure for the
+ * comparison with the reference's committed bitmap */
+static float* g_costv_out = NULL;
+int orc_blend_pair_linear(const float* img1, int rows1, int cols1, const float* img2, int rows2, int cols2,
+                          int tl1x, int tl1y, int tl2x, int tl2y, float* pano, int* seam_out);
+int orc_pair_linear_costv(const float* img1, int rows1, int cols1, const float* img2, int rows2, int cols2,
+                          int tl1x, int tl1y, int tl2x, int tl2y, float* pano_scratch, float* costv_out) {
+    g_costv_out = costv_out;
+    int rc = orc_blend_pair_linear(img1, rows1, cols1, img2, rows2, cols2, tl1x, tl1y, tl2x, tl2y, pano_scratch, NULL);
+    g_costv_out = NULL;
+    return rc;
+}
+
 int orc_blend_pair_linear(const float* img1, int rows1, int cols1,
                           const float* img2, int rows2, int cols2,
                           int tl1x, int tl1y, int tl2x, int tl2y, float* pano, int* seam_out) {
@@ -711,6 +724,7 @@ int orc_blend_pair_linear(const float* img1, int rows1, int cols1,
             p3[x] = ((sqrf(p1[(x + dx2) * 3] - p2[x * 3]) + sqrf(p1[(x + dx2) * 3 + 1] - p2[x * 3 + 1]) + sqrf(p1[(x + dx2) * 3 + 2] - p2[x * 3 + 2])) +
                      (sqrf(p1[(x + dx2 + 1) * 3] - p2[(x - 1) * 3]) + sqrf(p1[(x + dx2 + 1) * 3 + 1] - p2[(x - 1) * 3 + 1]) + sqrf(p1[(x + dx2 + 1) * 3 + 2] - p2[(x - 1) * 3 + 2]))) / 2;
     }
+    if (g_costv_out) memcpy(g_costv_out, costV, (size_t)iHe * cw * sizeof(float));
     /* greedy seam  B:268-307 */
     int* seam = (int*)malloc((size_t)iHe * sizeof(int));
     int px = iBr / 2, py = 0;

@@ -1,5 +1,7 @@
-"""The C++ host-side mirror (include/imagestitch.hpp): the reference's main() lines W:217-233 / W:271-313
-compiled with plain g++ against the C-ABI library, compared with the CPU oracle."""
+"""The C++ host side: the reference's main() lines W:217-233 / W:271-313 compiled with plain g++ against the C-ABI library and compared
+with the CPU oracle - once through the OpenCV-free mirror (include/imagestitch.hpp, tests/cpp/mirror_demo.cpp) and once through the
+OpenCV adapter a maintainer adds (include/imagestitch_cv.hpp: subclasses of cv::detail::RotationWarper / Blender used through base-class
+pointers, tests/cpp/cv_adapter_demo.cpp; compiled against tests/cpp/opencv_stub because this image has no OpenCV)."""
 import os
 import subprocess
 
@@ -12,10 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path):
-    exe = str(tmp_path / "mirror_demo")
+@pytest.mark.parametrize("demo", ["mirror_demo", "cv_adapter_demo"])
+def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path, demo):
+    exe = str(tmp_path / demo)
     lib_dir = os.path.join(ROOT, "imagestitch_amd", "csrc")
-    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mirror_demo.cpp"),
+    inc = ["-I", os.path.join(ROOT, "include")]
+    if demo == "cv_adapter_demo":
+        inc = ["-I", os.path.join(ROOT, "tests", "cpp", "opencv_stub")] + inc
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall"] + inc + [os.path.join(ROOT, "tests", "cpp", demo + ".cpp"),
                            "-o", exe, "-L", lib_dir, "-limagestitch_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     W, H, F = 420, 260, 330.0
     imgs = [synth.make_tile(H, W, 40 + i) for i in range(2)]

@@ -267,3 +267,18 @@ def test_fused_tile_kernel_edges(gpu, oracle, kind):
                 warper.warp_with_mask(torch.from_numpy(img).cuda(), K, R, out16=out16, dst_img=vi, dst_mask=vm)
                 assert np.array_equal(vi.cpu().numpy(), owi.astype(np.int16) if out16 else owi), (w, h, out16, "pitched")
                 assert np.array_equal(vm.cpu().numpy(), owm)
+
+
+def test_buildmaps_reproduces_the_references_xmap_ymap_bitmaps_on_the_gpu(gpu, oracle):
+    """The reference's committed xmap.bmp / ymap.bmp (W:155-156) through the HIP library: isx_warper_build_maps_roi with the camera
+    recovered from them (tests/golden/make_golden_maps.py) gives the oracle's maps bit for bit, hence the bitmaps."""
+    from test_ref_artifact import _maps_artifact, check_maps_against_the_reference_bitmaps
+    D = _maps_artifact()
+    K, R, tl = D["K"], D["R"], D["tl"]
+    roi = [int(tl[0]), int(tl[1]), int(tl[0]) + 1096 - 1, int(tl[1]) + 1102 - 1]
+    warper = gpu.CylindricalWarper().create(float(D["scale"]))
+    xm, ym = warper.buildMapsRoi(K, R, roi)
+    _, _, _, kr = oracle.camera(K, R)
+    oxm, oym = oracle.build_maps(oracle.CYL, float(D["scale"]), kr, roi)
+    assert xm.tobytes() == oxm.tobytes() and ym.tobytes() == oym.tobytes()
+    assert check_maps_against_the_reference_bitmaps(xm, ym) == 14

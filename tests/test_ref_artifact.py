@@ -206,3 +206,67 @@ def test_feather_stage_agrees_with_the_references_pano(oracle):
     no_dilate = _psnr_in_zone(*_demo_blend(feather, oracle.dilate_rect, None, c, 0.1, False), a)
     soft = _psnr_in_zone(*_demo_blend(feather, oracle.dilate_rect, None, c, 0.02, True), a)
     assert ref > 42.0 and no_dilate < ref - 8.0 and soft < ref - 4.0, (ref, no_dilate, soft)
+
+
+def _maps_artifact():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_maps_artifact.npz"))
+
+
+def check_maps_against_the_reference_bitmaps(xm, ym):
+    """saturate_cast<uchar>(cvRound(map)) - what imwrite("xmap.bmp", xmap) stored (W:155-156) - against the committed bitmaps: every one of
+    the 2 x 1102 x 1096 values, except a handful that sit within 1e-4 of a rounding tie (K and R of the author's run are recovered by a
+    fit, tests/golden/make_golden_maps.py, so the last bits of K * R^T are not the author's)."""
+    D = _maps_artifact()
+    total = 0
+    for m, ref in ((xm, D["xmap_u8"]), (ym, D["ymap_u8"])):
+        assert m.shape == ref.shape == (1102, 1096)
+        got = np.clip(np.rint(m), 0, 255).astype(np.int16)
+        bad = got != ref.astype(np.int16)
+        total += int(bad.sum())
+        assert np.abs(got - ref.astype(np.int16)).max() <= 1
+        tie = np.abs((m - np.floor(m)) - 0.5)[bad]
+        assert tie.size == 0 or tie.max() < 1e-4, tie.max()
+        # the saturated parts too: negative coordinates -> 0, coordinates beyond 255 -> 255
+        assert (ref[(m < -0.5)] == 0).all() and (ref[m > 255.5] == 255).all()
+    assert total <= 20, total
+    return total
+
+
+def test_buildmaps_reproduces_the_references_xmap_ymap_bitmaps(oracle):
+    """xmap.bmp / ymap.bmp of the reference (W:155-156: the maps of its last warp() call): setCameraParams (W:90-120: K * R^T), the map
+    fill of buildMaps with mapBackward (W:46-63, 133-141) and the 8-bit conversion reproduce both bitmaps with the camera recovered from
+    them - f = 2707.68 for a scale of 2707.47 (W:30), principal point 550.5 as for the 1101 x 1101 sources."""
+    D = _maps_artifact()
+    K, R, tl = D["K"], D["R"], D["tl"]
+    assert abs(float(K[0, 0]) - 2707.68) < 0.05 and K[0, 2] == 550.5 and K[1, 2] == 550.5
+    _, _, _, kr = oracle.camera(K, R)
+    roi = [int(tl[0]), int(tl[1]), int(tl[0]) + 1096 - 1, int(tl[1]) + 1102 - 1]
+    xm, ym = oracle.build_maps(oracle.CYL, float(D["scale"]), kr, roi)
+    n = check_maps_against_the_reference_bitmaps(xm, ym)
+    assert n == 14   # 6 + 8 values at rounding ties
+
+
+def test_costv_support_matches_the_references_costv_bitmap(oracle):
+    """costV.bmp (B:265) is the SSD cost map of the in-tree pair blend (B:207-261) for a pair whose inputs are not in the reference tree;
+    what it does record is the map's shape, interSectHe_ x (interSectBr_ + 2) = 1105 x 284, and its support: columns 1 .. interSectBr_ - 2
+    (the loop B:223), rows dy .. interSectHe_ - dy.  A pair of that geometry through the restatement has exactly that shape and column
+    support (A13's cost term; the greedy seam B:268-307 reads this array)."""
+    D = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_costv_artifact.npz"))
+    He, cw = [int(v) for v in D["shape"]]
+    assert (He, cw) == (1105, 284)
+    ibr = cw - 2
+    col_any = D["col_any"]
+    assert not col_any[0] and not col_any[ibr - 1:].any() and col_any[1:ibr - 1].all()        # x in [1, interSectBr_ - 1)
+    rng = np.random.default_rng(5)
+    dy = 5
+    h1, w1, h2, w2 = He - dy, 1086, He - dy, 1096                                          # sizes of the kind the demos produce
+    img1 = rng.integers(1, 255, (h1, w1, 3)).astype(np.float32)
+    img2 = rng.integers(1, 255, (h2, w2, 3)).astype(np.float32)
+    tl1, tl2 = (0, 0), (w1 - ibr, dy)
+    rc, cost = oracle.pair_linear_costv(img1, img2, tl1, tl2)
+    assert rc == 0 and cost.shape == (He, cw)
+    assert np.array_equal((cost != 0).any(0), col_any)
+    rows = (cost != 0).any(1)
+    assert not rows[:dy].any() and not rows[He - dy:].any() and rows[dy:He - dy].all()
+    # the artefact's zero rows at the top and bottom are at least the dy band (it also holds rows where both tiles are black)
+    assert not D["row_any"][:dy].any() and not D["row_any"][He - dy:].any()
