@@ -452,7 +452,11 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dx0 = (blockIdx.x * 64 + lane) * 4;
-    const int dy = blockIdx.y * 4 + wv;             // wave-uniform
+    // Row blocks are taken alternately from the top and from the bottom of the tile: the rows near the tile's upper and lower edge are
+    // where waves cross the image border (tier 2 below, the occasional generic pixel) and live several times longer than interior
+    // waves - dispatched first they overlap with the rest of the launch, dispatched last they were its tail (26 -> 22 us per 4K tile).
+    const int by = (blockIdx.y & 1) ? (int)gridDim.y - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1);
+    const int dy = by * 4 + wv;                     // wave-uniform
     if (dy >= d.h || dx0 >= d.w) return;
     const bool whole = VEC && dx0 + 4 <= d.w;       // four real columns and dword-aligned rows: vector stores
     // ---- mapBackward (W:46-63): the transform of the thread's four columns in this row -------------------------------
@@ -540,7 +544,8 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         const float mhx = (float)(32 * cols - 16), mhy = (float)(32 * rows - 16);      // 32 (cols - 1/2): the upper tie of cvRound(x) <= cols - 1
         const float mx_hi = ((cols - 1) & 1) ? mhx : __uint_as_float(__float_as_uint(mhx) + 1u);   // ... rounds to cols - 1 iff that is even
         const float my_hi = ((rows - 1) & 1) ? mhy : __uint_as_float(__float_as_uint(mhy) + 1u);
-        unsigned p0[4], p1[4], wab[4];
+        unsigned p0[4], p1[4], q0[4], q1[4], wab[4];
+        unsigned cornermask = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float cx = __builtin_amdgcn_fmed3f(tx[k], -big, big), cy = __builtin_amdgcn_fmed3f(ty[k], -big, big);
@@ -552,12 +557,16 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             const int r0 = reflect_once(sy, 2 * rows - 1), r1 = reflect_once(sy + 1, 2 * rows - 1);
             const int cb = min(min(c0, c1), cols - 2);                               // window = pixels cb, cb + 1
             const unsigned wA = (c0 == cb ? 32u - fx : 0u) + (c1 == cb ? (unsigned)fx : 0u);
-            // a window in the buffer's last row must end inside the buffer: its last few columns go to the generic path
-            ok = ok & !((max(r0, r1) == rows - 1) & (cb > cols - 6));
+            // a 12-byte window in the buffer's last row must end inside the buffer: the row's last few columns are read byte by byte below
+            const bool corner = ok & (max(r0, r1) == rows - 1) & (cb > cols - 6);
+            cornermask |= corner ? 1u << k : 0u;
             if (!ok) generic = true;
+            const bool win = ok & !corner;
             const unsigned cb3 = ok ? (unsigned)cb * 3u + mis : mis;
-            p0[k] = __umul24(ok ? (unsigned)r0 : 0u, step) + cb3;
-            p1[k] = __umul24(ok ? (unsigned)r1 : 0u, step) + cb3;
+            p0[k] = win ? __umul24((unsigned)r0, step) + cb3 : mis;
+            p1[k] = win ? __umul24((unsigned)r1, step) + cb3 : mis;
+            q0[k] = ok ? __umul24((unsigned)r0, step) + cb3 : mis;       // the taps' true byte offsets (from the aligned base)
+            q1[k] = ok ? __umul24((unsigned)r1, step) + cb3 : mis;
             wab[k] = wA | ((unsigned)fy << 8);
             // mask of an all-255 source, NEAREST / CONSTANT: 255 iff cvRound(x) in [0, cols) and cvRound(y) in [0, rows) - an interval test
             // on 32 x, 32 y (round-half-even: the tie -1/2 rounds to 0, the upper tie to cols - 1 iff cols - 1 is even; NaN fails)
@@ -569,6 +578,19 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         for (int k = 0; k < 4; ++k) {
             w0[k] = *(const U3*)(abase + (p0[k] & ~3u));
             w1[k] = *(const U3*)(abase + (p1[k] & ~3u));
+        }
+        if (cornermask) {       // the last columns of the buffer's last row (a handful of pixels per tile): their six bytes per row one by one
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((cornermask >> k) & 1u)) continue;
+                const unsigned char* a0 = abase + q0[k];
+                const unsigned char* a1 = abase + q1[k];
+                const unsigned b00 = a0[0], b01 = a0[1], b02 = a0[2], b03 = a0[3], b04 = a0[4], b05 = a0[5];
+                const unsigned b10 = a1[0], b11 = a1[1], b12 = a1[2], b13 = a1[3], b14 = a1[4], b15 = a1[5];
+                w0[k] = U3{b00 | (b01 << 8) | (b02 << 16) | (b03 << 24), b04 | (b05 << 8), 0u};
+                w1[k] = U3{b10 | (b11 << 8) | (b12 << 16) | (b13 << 24), b14 | (b15 << 8), 0u};
+                p0[k] = 0; p1[k] = 0;                                     // already aligned to the taps
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -614,7 +636,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     }
     // ---- the rare rest (z out of the guarded range incl. the z <= 0 sentinel, more than one reflection, sources too small for a
     // window, the last columns of the buffer's last row): the whole 4-pixel row of the thread again, by the generic code path
-    if (generic && !(a.dbg & 4)) {
+    if (generic && !(a.dbg & 4) && !(a.dbg & 16)) {
         const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1);
     }
@@ -1056,6 +1078,10 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
             if (w->kind == ISX_WARP_CYLINDRICAL) { ra[i] = v; rb[i] = 0.f; }          // W:52
             else { ra[i] = sinf(PI_F - v); rb[i] = cosf(PI_F - v); }
         }
+        // the padding repeats the last column / row: the fused kernel's partial 4-pixel group at the right edge then computes ordinary
+        // pixels in its unused lanes (zeros would make z = 0 there and send the whole group down the generic path, once per row)
+        for (int i = mw; i < mwp; ++i) { cs[i] = cs[mw - 1]; cc[i] = cc[mw - 1]; }
+        for (int i = mh; i < mhp; ++i) { ra[i] = ra[mh - 1]; rb[i] = rb[mh - 1]; }
         ISX_TRY(e->buf->reserve(n * sizeof(float)));
         ISX_HIP(hipMemcpyAsync(e->buf->p, w->host_tabs.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
         ISX_HIP(hipStreamSynchronize(w->stream));   // host_tabs is rewritten by the next miss

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests/test_gpu_blend.py::test_linear_pair_blend_4k tests/test_gpu_fuzz_slice.py -x -q 2>&1 | tail -15)
-mkdir -p gpurun_out/fuzz
-timeout 1000 python tools/fuzz_parity.py 600 7 gpurun_out/fuzz/round2_fuzz_600s_seed7.json 2>&1 | tail -5
+for dbg in 0 16 4; do ISX_WARP_DBG=$dbg python tools/warp_probe.py 2000 2>&1 | tail -1; done
+(timeout 900 python -m pytest tests/test_gpu_warp.py -x -q 2>&1 | tail -2)
