@@ -347,10 +347,18 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
             }
             Px<M> Am = shfl_up1<M>(A[i]), Bm = shfl_up1<M>(B[i]), Ap = shfl_down1<M>(A[i]);
             Px<M> h;
+            if constexpr (M != M_I16) {   // the [1 4 6 4 1] row filter on (b, g) / (r, w) register pairs: packed fp32, each half rounded on its own
+                const f32x2 a0 = {A[i].c0, A[i].c1}, a1 = {A[i].c2, A[i].w}, b0 = {B[i].c0, B[i].c1}, b1 = {B[i].c2, B[i].w};
+                const f32x2 am0 = {Am.c0, Am.c1}, am1 = {Am.c2, Am.w}, bm0 = {Bm.c0, Bm.c1}, bm1 = {Bm.c2, Bm.w}, ap0 = {Ap.c0, Ap.c1}, ap1 = {Ap.c2, Ap.w};
+                const f32x2 h0 = ((a0 * splat2(6.f) + (bm0 + b0) * splat2(4.f)) + am0) + ap0;    // tap5: c * 6 + (l1 + r1) * 4 + l2 + r2
+                const f32x2 h1 = ((a1 * splat2(6.f) + (bm1 + b1) * splat2(4.f)) + am1) + ap1;
+                h.c0 = h0.x; h.c1 = h0.y; h.c2 = h1.x; h.w = h1.y;
+            } else {
             h.c0 = tap5<WT>(A[i].c0, Bm.c0, B[i].c0, Am.c0, Ap.c0);
             h.c1 = tap5<WT>(A[i].c1, Bm.c1, B[i].c1, Am.c1, Ap.c1);
             h.c2 = tap5<WT>(A[i].c2, Bm.c2, B[i].c2, Am.c2, Ap.c2);
             h.w = tap5<float>(A[i].w, Bm.w, B[i].w, Am.w, Ap.w);
+            }
             hb[r][lane] = h;
         }
     }
@@ -362,6 +370,13 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
         if (oy >= dh) break;
         Px<M> r0 = hb[2 * ty][lane], r1 = hb[2 * ty + 1][lane], r2 = hb[2 * ty + 2][lane], r3 = hb[2 * ty + 3][lane], r4 = hb[2 * ty + 4][lane];
         Px<M> o;
+        if constexpr (M != M_I16) {   // the column filter and the 1/256, packed the same way
+            const f32x2 p0[5] = {{r0.c0, r0.c1}, {r1.c0, r1.c1}, {r2.c0, r2.c1}, {r3.c0, r3.c1}, {r4.c0, r4.c1}};
+            const f32x2 p1[5] = {{r0.c2, r0.w}, {r1.c2, r1.w}, {r2.c2, r2.w}, {r3.c2, r3.w}, {r4.c2, r4.w}};
+            const f32x2 v0 = (((p0[2] * splat2(6.f) + (p0[1] + p0[3]) * splat2(4.f)) + p0[0]) + p0[4]) * splat2(1.f / 256.f);
+            const f32x2 v1 = (((p1[2] * splat2(6.f) + (p1[1] + p1[3]) * splat2(4.f)) + p1[0]) + p1[4]) * splat2(1.f / 256.f);
+            o.c0 = v0.x; o.c1 = v0.y; o.c2 = v1.x; o.w = v1.y;
+        } else {
         WT a0 = tap5<WT>(r2.c0, r1.c0, r3.c0, r0.c0, r4.c0);
         WT a1 = tap5<WT>(r2.c1, r1.c1, r3.c1, r0.c1, r4.c1);
         WT a2 = tap5<WT>(r2.c2, r1.c2, r3.c2, r0.c2, r4.c2);
@@ -369,6 +384,7 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
         if constexpr (M == M_I16) { o.c0 = sat_s16((a0 + 128) >> 8); o.c1 = sat_s16((a1 + 128) >> 8); o.c2 = sat_s16((a2 + 128) >> 8); }
         else { o.c0 = a0 * (1.f / 256.f); o.c1 = a1 * (1.f / 256.f); o.c2 = a2 * (1.f / 256.f); }
         o.w = aw * (1.f / 256.f);
+        }
         store_px<M, false>(dst, ox, oy, o);
     }
 }
@@ -690,18 +706,29 @@ __device__ __forceinline__ void write_final_pair(const OutMat& o, int x, int y, 
     }
     if (y >= o.rows) return;
     const bool on0 = d0.w > WEIGHT_EPS, on1 = d1.w > WEIGHT_EPS;
-    int v[6];
-    if constexpr (M == M_I16) { v[0] = d0.c0; v[1] = d0.c1; v[2] = d0.c2; v[3] = d1.c0; v[4] = d1.c1; v[5] = d1.c2; }
-    else {
-        v[0] = f2s16_sat<BOUNDED>(d0.c0); v[1] = f2s16_sat<BOUNDED>(d0.c1); v[2] = f2s16_sat<BOUNDED>(d0.c2);
-        v[3] = f2s16_sat<BOUNDED>(d1.c0); v[4] = f2s16_sat<BOUNDED>(d1.c1); v[5] = f2s16_sat<BOUNDED>(d1.c2);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { if (!on0) v[i] = 0; if (!on1) v[3 + i] = 0; }
     unsigned* q = (unsigned*)(o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 6u));
-    q[0] = (unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16);
-    q[1] = (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16);
-    q[2] = (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16);
+    if constexpr (BOUNDED && M != M_I16) {
+        // |v| < 2^31 and never NaN: round-half-even, convert, and let v_cvt_pk_i16_i32 saturate and pack two values at once
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const float f[6] = {on0 ? (float)d0.c0 : 0.f, on0 ? (float)d0.c1 : 0.f, on0 ? (float)d0.c2 : 0.f, on1 ? (float)d1.c0 : 0.f, on1 ? (float)d1.c1 : 0.f, on1 ? (float)d1.c2 : 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const s16x2 pk = __builtin_amdgcn_cvt_pk_i16((int)__builtin_rintf(f[2 * i]), (int)__builtin_rintf(f[2 * i + 1]));
+            q[i] = __builtin_bit_cast(unsigned, pk);
+        }
+    } else {
+        int v[6];
+        if constexpr (M == M_I16) { v[0] = d0.c0; v[1] = d0.c1; v[2] = d0.c2; v[3] = d1.c0; v[4] = d1.c1; v[5] = d1.c2; }
+        else {
+            v[0] = f2s16_sat<BOUNDED>(d0.c0); v[1] = f2s16_sat<BOUNDED>(d0.c1); v[2] = f2s16_sat<BOUNDED>(d0.c2);
+            v[3] = f2s16_sat<BOUNDED>(d1.c0); v[4] = f2s16_sat<BOUNDED>(d1.c1); v[5] = f2s16_sat<BOUNDED>(d1.c2);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { if (!on0) v[i] = 0; if (!on1) v[3 + i] = 0; }
+        q[0] = (unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16);
+        q[1] = (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16);
+        q[2] = (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16);
+    }
     if (o.mask) *(unsigned short*)(o.mask + (__umul24((unsigned)y, (unsigned)o.mask_step) + (unsigned)x)) = (unsigned short)((on0 ? 255u : 0u) | (on1 ? 0xff00u : 0u));
 }
 
