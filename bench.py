@@ -16,6 +16,7 @@ cv::detail::Blender gets it - every warp returns its corner to the host (W:160),
 with device mats and with host (cv::Mat-like, PCIe-inclusive) mats; timed after the headline region, never part of `value`.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -224,6 +225,10 @@ def main():
                     help="spherical (BASELINE config 5) implies --sync-roi: its ROI is a host-side border scan, there is no planned variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the pairs of a step are spread over (default: 1 for one pair, min(pairs, 4) otherwise): independent pairs on "
+                         "separate streams overlap - one pair's launch-latency-bound small pyramid levels run under another pair's large kernels "
+                         "(measured: 0.252 -> 0.220 ms per 4K pair with 2-4 streams; one hipGraph per pair does not overlap)")
     ap.add_argument("--gather", default="chunk", choices=["chunk", "single"],
                     help="N > 1: all-gather the rank's block pair by pair behind each blend (default), or as ONE collective per step")
     ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx"],
@@ -252,6 +257,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.pairs is None:
         args.pairs = 1 if world == 1 else 4
+    if args.streams is None:
+        args.streams = 1 if args.pairs == 1 else min(args.pairs, 4)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
@@ -274,6 +281,7 @@ def main():
         args.sync_roi = True
     gen = torch.Generator(device=dev)
     pairs = []
+    pstreams = [None] if (args.streams <= 1 or args.graph) else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
     for p in range(args.pairs):
         gen.manual_seed(synth.SEED0 + 1000 * rank + p)
         # same statistics as synth.make_tile (sinusoid + U{-32..31} noise), generated on the device
@@ -288,7 +296,7 @@ def main():
             imgs.append(torch.stack(chans, dim=2).contiguous())
         if p == 0 and rank == 0:
             host_imgs0 = [im.cpu().numpy() for im in imgs]
-        pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, None, "uint8" if (world > 1 or args.force_dist) else "int16",
+        pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, pstreams[p % len(pstreams)], "uint8" if (world > 1 or args.force_dist) else "int16",
                                   deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle]))
         del yy, xx
     if args.roi_cache:
@@ -371,19 +379,23 @@ def main():
         if args.graph:
             b = 0                                  # the graphs run on their own streams and always write send[0]
         for i, p in enumerate(pairs):
-            if args.graph:
-                p.replay()
-            elif args.sync_roi:
-                p.step_sync()
-            else:
-                p.step()
+            ps = pstreams[i % len(pstreams)]
+            if ps is not None and use_dist and not args.graph:
+                ps.wait_event(ev_gather[b])        # this pair's stream overwrites its chunk of send[b]
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                if args.graph:
+                    p.replay()
+                elif args.sync_roi:
+                    p.step_sync()
+                else:
+                    p.step()
             if use_dist:
-                ev_pair[b][i].record(p.gstream if args.graph else main)
+                ev_pair[b][i].record(p.gstream if args.graph else (ps if ps is not None else main))
                 if args.gather == "chunk":
                     post_chunk(b, i)
         if use_dist:
             if args.gather == "single":
-                if args.graph:
+                if args.graph or pstreams[0] is not None:
                     for i in range(len(pairs) - 1):
                         comm.wait_event(ev_pair[b][i])
                 post_block(b)
@@ -408,6 +420,7 @@ def main():
     lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_reset()
     for p in pairs:
         p.step_sync()
+    torch.cuda.synchronize()
     ent = _lib.profile_entries()
     per_kernel = {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "alg_MB": round(v["alg_bytes"] / 1e6, 2)} for k, v in ent.items()}
     # dominant kernel = the heaviest single launch of the step (largest average launch duration)
@@ -485,7 +498,7 @@ def main():
                 args.pairs, NT, W, H, args.kind, F, args.bands, args.precision, (", u8x3 mosaics all-gathered pair by pair behind each blend (%s)" % args.gather_backend if args.gather == "chunk" else
                  ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step (%s)" % args.gather_backend) if use_dist else ""),
                 "tiles_per_mosaic": NT,
-                "pairs_per_gpu": args.pairs, "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "pairs_per_gpu": args.pairs, "streams": len(pstreams), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
                                   "achieved_GBs": round(bm["total"] / (pair_ms * 1e-3) / 1e9, 1), "frac": round(bm["total"] / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -500,6 +513,27 @@ def main():
                                 "gather": args.gather, "gather_backend": args.gather_backend,
                                 "note": "value = steps with the gathers overlapped with the blends that follow them; the two legs here are timed after "
                                         "it, each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}
+        if world == 1 and args.pairs == 1 and not args.graph and not args.no_dropin:
+            # The same workload with TWO steps in flight: a second stitcher (own buffers, own stream) takes every other step, so one
+            # step's launch-latency-bound small pyramid levels run under the other's large kernels.  Identical mosaics; the latency of
+            # a step is unchanged, the throughput is what a stream of frames sees.  Reported beside `value`, never as `value`: in the
+            # timed region above the kernels run alone, which is what `roofline` needs.
+            s2 = torch.cuda.Stream(device=dev)
+            p2 = PairStitcher(pairs[0].imgs, K, Rs, F, args.kind, args.bands, prec, local, s2, "int16",
+                              deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle])
+            both = [pairs[0], p2]
+            for i in range(4):
+                both[i % 2].step_sync() if args.sync_roi else both[i % 2].step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(2 * args.steps):
+                both[i % 2].step_sync() if args.sync_roi else both[i % 2].step()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t1) / (2 * args.steps)
+            p2.check_plan()
+            same = bool(torch.equal(p2.out, pairs[0].out))
+            out["two_steps_in_flight"] = {"ms_per_step": round(dt2 * 1e3, 4), "Mpix_s": round(NT * W * H / 1e6 / dt2, 1), "identical_mosaics": same}
+            del p2, both
         if world == 1 and not args.no_dropin:
             for p in pairs:
                 del p
