@@ -31,8 +31,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def measured_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of tools/measure_traffic.py (collected in
     their own runs, as the counters require); None when no matching measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
     try:
+        path = os.path.join(ROOT, "profiles", "round2_traffic.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "round1_traffic.json")
         d = json.load(open(path))
         want = ["--precision", args.precision, "--bands", str(args.bands)]
         if d.get("bench_args", []) not in ([], want) and (args.precision != "f32" or args.bands != 5):
@@ -485,7 +487,9 @@ def main():
             bytes_per_launch = e["alg_bytes"] / e["launches"]
             ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dominant, args), "avg_launch_ms": round(avg_ms, 5),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dominant, args),
+                    "traffic_source": "profiles/round2_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command (tools/measure_traffic.py), (2 x FETCH + WRITE) KiB per launch",
+                    "avg_launch_ms": round(avg_ms, 5),
                     "alg_bytes_per_launch": int(bytes_per_launch), "launches": e["launches"], "bracketed_every": SAMPLE}
         pair_ms = dt / args.steps / args.pairs * 1e3
         out = {

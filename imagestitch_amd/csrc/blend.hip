@@ -78,7 +78,6 @@ struct Src0 {
     const unsigned char* img_al;
     const unsigned char* mask_al;
     unsigned imis, mmis, iend, mend;
-    int dbg;            // experiments only (ISX_BLEND_DBG): bit 0 = clamp border pairs onto the fast path (wrong pixels, timing only)
 };
 
 // Rectangles of one destination level that earlier feeds have already written.  prepare() does not
@@ -220,8 +219,7 @@ __device__ __forceinline__ RawPair src0_pair_issue(const Src0& s, int x, int y) 
     RawPair r;
     r.v = U3{0u, 0u, 0u}; r.q = U2{0u, 0u}; r.sh = 0u; r.fast = false;
     if constexpr (SK == SK_U8) {
-        int yr = y - s.top, xr = x - s.left;
-        if (s.dbg & 1) { yr = min(max(yr, 0), s.rows - 2); xr = min(max(xr, 0), s.cols - 6); }
+        const int yr = y - s.top, xr = x - s.left;
         if ((unsigned)yr < (unsigned)s.rows && xr >= 0 && xr + 1 < s.cols) {
             const unsigned io = __umul24((unsigned)yr, (unsigned)s.img_step) + __umul24((unsigned)xr, 3u) + s.imis;
             const unsigned mo = __umul24((unsigned)yr, (unsigned)s.mask_step) + (unsigned)xr + s.mmis;
@@ -1904,7 +1902,6 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     s0.imis = (unsigned)((uintptr_t)s0.img & 3); s0.mmis = (unsigned)((uintptr_t)s0.mask & 3);
     s0.img_al = s0.img - s0.imis; s0.mask_al = s0.mask - s0.mmis;
     s0.iend = 0; s0.mend = 0;
-    { static const int dbg_env = getenv("ISX_BLEND_DBG") ? atoi(getenv("ISX_BLEND_DBG")) : 0; s0.dbg = dbg_env; }
     if (img->type == ISX_8UC3 && (unsigned long long)di.step * img->rows < (1ull << 31) && (unsigned long long)dm.step * img->rows < (1ull << 31) &&
         di.step < (1u << 24) && dm.step < (1u << 24)) {
         s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * 3) + s0.imis;

@@ -420,7 +420,7 @@ __device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t,
 // a DOT instruction and a VALU read of its result) and reads a stale register.
 __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
 
-struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; int dbg; };
+struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; };
 
 // one pixel of the fixed-point bilinear from its two 12-byte windows: window pixel 0 weighs wA, pixel 1 weighs wB (wA + wB = 32),
 // the upper row gy, the lower fy (gy + fy = 32): (sum of the BilinearTab_i products + 2^14) >> 15 == (S + 512) >> 10 with the
@@ -524,19 +524,17 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             fxy[k] = (bx & 31u) | ((by & 31u) << 8);
             o0[k] = mad24(__builtin_amdgcn_ubfe(by, 5, 18), step, mad24(__builtin_amdgcn_ubfe(bx, 5, 18), 3u, addr_c));
         }
-        if (!(a.dbg & 2)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {       // all eight loads in flight together
             v0[k] = *(const U3*)(abase + (o0[k] & ~3u));
             v1[k] = *(const U3*)(abase + ((o0[k] + step) & ~3u));
-        }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned fx = fxy[k] & 255u, fy = fxy[k] >> 8;
             px[k] = sample_windows(v0[k], v1[k], o0[k], o0[k] + step, 32u - fx, fx, 32u - fy, fy);
         }
-    } else if (!(a.dbg & 4)) {
+    } else {
         // ---- tier 2: a wave that crosses the image border.  BORDER_REFLECT keeps the two taps of an axis adjacent (possibly in reverse
         // order) or puts them on the same pixel, so the two 12-byte windows still hold every tap: the window starts at the smaller
         // tap column and the horizontal weights go where the taps landed.  Interior pixels of the wave take the same code.
@@ -597,12 +595,8 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             const unsigned wA = wab[k] & 255u, fy = wab[k] >> 8;
             px[k] = sample_windows(w0[k], w1[k], p0[k], p1[k], wA, 32u - wA, 32u - fy, fy);
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) px[k] = 0;
     }
     // ---- stores ------------------------------------------------------------------------------------------------------------
-    if ((a.dbg & 1) && (px[0] ^ px[1] ^ px[2] ^ px[3]) != 0x12345678u) return;
     if (whole) {
         if constexpr (OUT16) {
             unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 6u));
@@ -636,7 +630,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     }
     // ---- the rare rest (z out of the guarded range incl. the z <= 0 sentinel, more than one reflection, sources too small for a
     // window, the last columns of the buffer's last row): the whole 4-pixel row of the thread again, by the generic code path
-    if (generic && !(a.dbg & 4) && !(a.dbg & 16)) {
+    if (generic) {
         const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1);
     }
@@ -1160,12 +1154,10 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
                    (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
         // the hot kernel: a tile whose mask is all 255 (W:213-214).  Same launch name: it is the same operation.
         const dim3 gridt(cdiv(dw, 256), cdiv(dh, 4));
-        static const int dbg_env = getenv("ISX_WARP_DBG") ? atoi(getenv("ISX_WARP_DBG")) : 0;
-        const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, dw, dh}, dbg_env};
+        const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, dw, dh}};
 #define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(256), 0, wta)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
-        static const bool old_kernel = getenv("ISX_WARP_V1") != nullptr;
-        if (!src_mask && !old_kernel) {
+        if (!src_mask) {
             if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_TILE_K(true, true); else ISX_WARP_TILE_K(true, false); }
             else { if (vec) ISX_WARP_TILE_K(false, true); else ISX_WARP_TILE_K(false, false); }
         } else if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_FUSED(true, true); else ISX_WARP_FUSED(true, false); }

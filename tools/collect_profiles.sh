@@ -1,0 +1,40 @@
+#!/usr/bin/env bash
+# Collects the measurement evidence of a round on the GPU box (run via gpurun from the repo root):
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh round2 [fuzz_seconds]'
+# Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
+TAG=${1:-round2}; FUZZ=${2:-600}
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$TAG; mkdir -p $O
+line() { grep "^{" | tail -1; }
+# 1. HBM traffic per kernel (two PMC passes of their own), then the default line that reads it
+python tools/measure_traffic.py $O/${TAG}_traffic.json > $O/traffic.log 2>&1
+cp $O/${TAG}_traffic.json profiles/${TAG}_traffic.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 2>/dev/null | line > $O/${TAG}_bench_n1.json
+# 2. the same command under the kernel tracer
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin 2>/dev/null | line > $O/${TAG}_bench_under_rocprof.json
+cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats.csv
+# 3. per-kernel VALU utilisation / occupancy
+bash tools/pmc_kernels.sh 1 $TAG/pmc_f32 > $O/${TAG}_pmc_f32.txt 2>&1
+bash tools/pmc_kernels.sh 0 $TAG/pmc_i16 > $O/${TAG}_pmc_i16.txt 2>&1
+# 4. variants
+b() { name=$1; shift; python bench.py --no-cpu-baseline --no-dropin "$@" 2>/dev/null | line > $O/${TAG}_bench_$name.json; }
+b graph --graph
+b i16 --precision i16
+b f16 --precision f16acc32
+b sync_roi --sync-roi
+b cycle_copy_f32 --cycle copy
+b cycle_eager_f32 --cycle eager
+b cycle_copy_i16 --cycle copy --precision i16
+b config3_16pairs_graph --pairs 16 --graph
+b config3_16pairs_streams --pairs 16
+b config4_4pairs_per_gpu_streams --pairs 4
+b config4_forcedist_chunk --force-dist --pairs 4 --gather chunk
+b config4_forcedist_single --force-dist --pairs 4 --gather single
+b config4_forcedist_chunk_isx --force-dist --pairs 4 --gather chunk --gather-backend isx
+b config5_ring8_8k --kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 5 --warmup 2
+b config5_8k_pair --kind spherical --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3
+# 5. fuzz soak
+python tools/fuzz_parity.py $FUZZ 11 $O/${TAG}_fuzz_${FUZZ}s_seed11.json > $O/fuzz.log 2>&1
+tail -3 $O/fuzz.log
+ls $O

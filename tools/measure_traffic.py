@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel launch from rocprofv3 PMC counters (run on the GPU box).
 
-    python tools/measure_traffic.py profiles/round1_traffic.json [-- bench args]
+    python tools/measure_traffic.py profiles/round2_traffic.json [-- bench args]
 
 Runs bench.py twice under `rocprofv3 --kernel-trace --pmc X` — FETCH_SIZE and WRITE_SIZE in SEPARATE
 passes (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2; MI355X_MICROARCH.md "rocprofv3 PMC slots") —
@@ -31,7 +31,7 @@ def short(name):
 
 
 # kernel function name -> the launch name bench.py / the library's profiler reports
-ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_roi_scan": "roi_scan",
+ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_warp_tile": "warp_img_mask", "k_roi_scan": "roi_scan",
          "k_lap_acc_all": "lap_acc_all", "k_pyr_down": None, "k_pyr_down_multi": None, "k_collapse": None}
 
 
@@ -49,7 +49,7 @@ def run_pass(counter, extra):
     d = tempfile.mkdtemp(prefix="isx_pmc_", dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline"] + extra
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-dropin"] + extra
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['two_steps_in_flight'], d['dropin']['device_f32'])"
-for p in 4 16; do python bench.py --pairs $p --steps 20 --warmup 5 --no-cpu-baseline --no-dropin 2>/dev/null | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['config']['pairs_per_gpu'], d['config']['streams'], d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"; done
-python bench.py --force-dist --steps 10 --warmup 3 --pairs 4 2>/dev/null | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print('dist', d['value'], d['ms_per_step'], d['multi_gpu']['without_gather_Mpix_s'])"
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4)
