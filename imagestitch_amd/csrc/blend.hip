@@ -379,7 +379,7 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
         WT a1 = tap5<WT>(r2.c1, r1.c1, r3.c1, r0.c1, r4.c1);
         WT a2 = tap5<WT>(r2.c2, r1.c2, r3.c2, r0.c2, r4.c2);
         float aw = tap5<float>(r2.w, r1.w, r3.w, r0.w, r4.w);
-        if constexpr (M == M_I16) { o.c0 = sat_s16((a0 + 128) >> 8); o.c1 = sat_s16((a1 + 128) >> 8); o.c2 = sat_s16((a2 + 128) >> 8); }
+        if constexpr (M == M_I16) { o.c0 = (a0 + 128) >> 8; o.c1 = (a1 + 128) >> 8; o.c2 = (a2 + 128) >> 8; }   // weights sum to 256: no clamp can act
         else { o.c0 = a0 * (1.f / 256.f); o.c1 = a1 * (1.f / 256.f); o.c2 = a2 * (1.f / 256.f); }
         o.w = aw * (1.f / 256.f);
         }
@@ -462,8 +462,10 @@ __device__ __forceinline__ Up4<M> pyr_up_2x2(Px<M> (*ct)[WAVE + 2], int lane, in
         WT e0 = t0[0][k] + t0[1][k] * 6 + t0[2][k], e1 = t1[0][k] + t1[1][k] * 6 + t1[2][k];
         WT o0 = (t0[1][k] + t0[2][k]) * 4, o1 = (t1[1][k] + t1[2][k]) * 4;
         if constexpr (M == M_I16) {
-            u.v[0][0][k] = sat_s16((e0 + 32) >> 6); u.v[0][1][k] = sat_s16((e1 + 32) >> 6);
-            u.v[1][0][k] = sat_s16((o0 + 32) >> 6); u.v[1][1][k] = sat_s16((o1 + 32) >> 6);
+            // saturate_cast<short>((v + 32) >> 6): the kernel weights of every output sum to 64 (edge formulas included) and the inputs are
+            // shorts, so the result lies in [-32768, 32767] by itself - the clamp OpenCV applies can never act and is not issued
+            u.v[0][0][k] = (e0 + 32) >> 6; u.v[0][1][k] = (e1 + 32) >> 6;
+            u.v[1][0][k] = (o0 + 32) >> 6; u.v[1][1][k] = (o1 + 32) >> 6;
         } else {
             u.v[0][0][k] = e0 * (1.f / 64.f); u.v[0][1][k] = e1 * (1.f / 64.f);
             u.v[1][0][k] = o0 * (1.f / 64.f); u.v[1][1][k] = o1 * (1.f / 64.f);
@@ -991,7 +993,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const Px<M> g = gg[s][dy][dx];
-                    if constexpr (M == M_I16) {
+                    if constexpr (M == M_I16 && FINE0 && SK == SK_U8) {
+                        // CV_8UC3 tiles: g in [0, 255], pyrUp of their Gaussian level in [0, 255], w in [0, 1] - cv::subtract cannot saturate,
+                        // static_cast<short>(lap * w) is a plain truncation of a value within +-255, and the sum over at most 8 tiles cannot
+                        // wrap a short: the three guards of the general form below never act and are not issued
+                        acc[dy][dx][0] = acc[dy][dx][0] + (int)((float)(g.c0 - u.v[dy][dx][0]) * g.w);
+                        acc[dy][dx][1] = acc[dy][dx][1] + (int)((float)(g.c1 - u.v[dy][dx][1]) * g.w);
+                        acc[dy][dx][2] = acc[dy][dx][2] + (int)((float)(g.c2 - u.v[dy][dx][2]) * g.w);
+                    } else if constexpr (M == M_I16) {
                         acc[dy][dx][0] = wrap_s16(acc[dy][dx][0] + f2s_x86((float)sat_s16(g.c0 - u.v[dy][dx][0]) * g.w));
                         acc[dy][dx][1] = wrap_s16(acc[dy][dx][1] + f2s_x86((float)sat_s16(g.c1 - u.v[dy][dx][1]) * g.w));
                         acc[dy][dx][2] = wrap_s16(acc[dy][dx][2] + f2s_x86((float)sat_s16(g.c2 - u.v[dy][dx][2]) * g.w));
@@ -1045,7 +1054,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
         for (int dx = 0; dx < 2; ++dx) {
             Px<M> d;
             d.c0 = acc[dy][dx][0]; d.c1 = acc[dy][dx][1]; d.c2 = acc[dy][dx][2]; d.w = accw[dy][dx];
-            normalise<M>(d);
+            if constexpr (M == M_I16 && FINE0 && SK == SK_U8) {
+                // normalizeUsingWeightMap on integers within +-2040 over a denominator in [1e-5, 8 + 1e-5]: the three divisions share one
+                // reciprocal (isx_device.hpp: the hardware's own recurrence; the numerators are integers, the quotients below 2^28) and
+                // static_cast<short> is truncation + the low 16 bits
+                const float den = d.w + WEIGHT_EPS;
+                const f32x2 z = splat2(den), r1 = refine_rcp(z, splat2(__builtin_amdgcn_rcpf(den)));
+                const f32x2 n01 = div_by_refined(f32x2{(float)d.c0, (float)d.c1}, z, r1), n2 = div_by_refined(f32x2{(float)d.c2, 0.f}, z, r1);
+                d.c0 = wrap_s16((int)n01.x); d.c1 = wrap_s16((int)n01.y); d.c2 = wrap_s16((int)n2.x);
+            } else normalise<M>(d);
             if constexpr (M == M_I16) {
                 d.c0 = sat_s16(u.v[dy][dx][0] + d.c0); d.c1 = sat_s16(u.v[dy][dx][1] + d.c1); d.c2 = sat_s16(u.v[dy][dx][2] + d.c2);
             } else {
