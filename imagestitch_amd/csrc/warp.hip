@@ -542,29 +542,29 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         const float mhx = (float)(32 * cols - 16), mhy = (float)(32 * rows - 16);      // 32 (cols - 1/2): the upper tie of cvRound(x) <= cols - 1
         const float mx_hi = ((cols - 1) & 1) ? mhx : __uint_as_float(__float_as_uint(mhx) + 1u);   // ... rounds to cols - 1 iff that is even
         const float my_hi = ((rows - 1) & 1) ? mhy : __uint_as_float(__float_as_uint(mhy) + 1u);
-        unsigned p0[4], p1[4], q0[4], q1[4], wab[4];
-        unsigned cornermask = 0;
+        // A window is read from its aligned start; at the very end of the buffer that start is pulled back to the buffer's last aligned 12
+        // bytes (end4: the end rounded up to a dword - the dword holding the last valid byte is readable as a whole) and the taps sit up
+        // to six bytes into it: the window's dwords are then rotated by one before the usual byte alignment.
+        const unsigned end4 = ((unsigned)(rows - 1) * step + (unsigned)cols * 3u + mis + 3u) & ~3u;
+        unsigned al0[4], al1[4], wab[4];      // aligned window starts
+        unsigned shifts = 0;                  // byte offset of the taps inside their windows (0 .. 6), three bits per window
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float cx = __builtin_amdgcn_fmed3f(tx[k], -big, big), cy = __builtin_amdgcn_fmed3f(ty[k], -big, big);
             const int isx = (int)(__float_as_uint(cx + RNE_MAGIC) - 0x4B400000u), isy = (int)(__float_as_uint(cy + RNE_MAGIC) - 0x4B400000u);
             const int sx = isx >> 5, sy = isy >> 5, fx = isx & 31, fy = isy & 31;
             // one reflection at most: sx, sx + 1 in [-cols, 2 cols - 1], same for the rows
-            bool ok = (cx == tx[k]) & (cy == ty[k]) & ((unsigned)(sx + cols) < (unsigned)(3 * cols - 1)) & ((unsigned)(sy + rows) < (unsigned)(3 * rows - 1));
+            const bool ok = (cx == tx[k]) & (cy == ty[k]) & ((unsigned)(sx + cols) < (unsigned)(3 * cols - 1)) & ((unsigned)(sy + rows) < (unsigned)(3 * rows - 1));
             const int c0 = reflect_once(sx, 2 * cols - 1), c1 = reflect_once(sx + 1, 2 * cols - 1);
             const int r0 = reflect_once(sy, 2 * rows - 1), r1 = reflect_once(sy + 1, 2 * rows - 1);
             const int cb = min(min(c0, c1), cols - 2);                               // window = pixels cb, cb + 1
             const unsigned wA = (c0 == cb ? 32u - fx : 0u) + (c1 == cb ? (unsigned)fx : 0u);
-            // a 12-byte window in the buffer's last row must end inside the buffer: the row's last few columns are read byte by byte below
-            const bool corner = ok & (max(r0, r1) == rows - 1) & (cb > cols - 6);
-            cornermask |= corner ? 1u << k : 0u;
             if (!ok) generic = true;
-            const bool win = ok & !corner;
             const unsigned cb3 = ok ? (unsigned)cb * 3u + mis : mis;
-            p0[k] = win ? __umul24((unsigned)r0, step) + cb3 : mis;
-            p1[k] = win ? __umul24((unsigned)r1, step) + cb3 : mis;
-            q0[k] = ok ? __umul24((unsigned)r0, step) + cb3 : mis;       // the taps' true byte offsets (from the aligned base)
-            q1[k] = ok ? __umul24((unsigned)r1, step) + cb3 : mis;
+            const unsigned q0 = ok ? __umul24((unsigned)r0, step) + cb3 : mis, q1 = ok ? __umul24((unsigned)r1, step) + cb3 : mis;   // the taps' byte offsets
+            const unsigned a0 = min(q0 & ~3u, end4 - 12u), a1 = min(q1 & ~3u, end4 - 12u);
+            al0[k] = a0; al1[k] = a1;
+            shifts |= ((q0 - a0) << (6 * k)) | ((q1 - a1) << (6 * k + 3));
             wab[k] = wA | ((unsigned)fy << 8);
             // mask of an all-255 source, NEAREST / CONSTANT: 255 iff cvRound(x) in [0, cols) and cvRound(y) in [0, rows) - an interval test
             // on 32 x, 32 y (round-half-even: the tie -1/2 rounds to 0, the upper tie to cols - 1 iff cols - 1 is even; NaN fails)
@@ -574,26 +574,16 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         U3 w0[4], w1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            w0[k] = *(const U3*)(abase + (p0[k] & ~3u));
-            w1[k] = *(const U3*)(abase + (p1[k] & ~3u));
-        }
-        if (cornermask) {       // the last columns of the buffer's last row (a handful of pixels per tile): their six bytes per row one by one
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((cornermask >> k) & 1u)) continue;
-                const unsigned char* a0 = abase + q0[k];
-                const unsigned char* a1 = abase + q1[k];
-                const unsigned b00 = a0[0], b01 = a0[1], b02 = a0[2], b03 = a0[3], b04 = a0[4], b05 = a0[5];
-                const unsigned b10 = a1[0], b11 = a1[1], b12 = a1[2], b13 = a1[3], b14 = a1[4], b15 = a1[5];
-                w0[k] = U3{b00 | (b01 << 8) | (b02 << 16) | (b03 << 24), b04 | (b05 << 8), 0u};
-                w1[k] = U3{b10 | (b11 << 8) | (b12 << 16) | (b13 << 24), b14 | (b15 << 8), 0u};
-                p0[k] = 0; p1[k] = 0;                                     // already aligned to the taps
-            }
+            w0[k] = *(const U3*)(abase + al0[k]);
+            w1[k] = *(const U3*)(abase + al1[k]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned wA = wab[k] & 255u, fy = wab[k] >> 8;
-            px[k] = sample_windows(w0[k], w1[k], p0[k], p1[k], wA, 32u - wA, 32u - fy, fy);
+            const unsigned s0 = (shifts >> (6 * k)) & 7u, s1 = (shifts >> (6 * k + 3)) & 7u;
+            if (s0 & 4u) w0[k] = U3{w0[k].y, w0[k].z, 0u};
+            if (s1 & 4u) w1[k] = U3{w1[k].y, w1[k].z, 0u};
+            px[k] = sample_windows(w0[k], w1[k], s0, s1, wA, 32u - wA, 32u - fy, fy);
         }
     }
     // ---- stores ------------------------------------------------------------------------------------------------------------
