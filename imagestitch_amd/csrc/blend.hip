@@ -880,6 +880,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc[i][j][0] = 0; acc[i][j][1] = 0; acc[i][j][2] = 0; accw[i][j] = 0.f; accA[i][j] = splat2(0.f); accC[i] = splat2(0.f); accW[i] = splat2(0.f); }
     constexpr int NCT = (UP_TY + 2) * (WAVE + 2);
+    int rnd = 0;                                           // rounds executed so far
     for (int t0 = 0; t0 < max(ts.n, 1); t0 += G) {
         const bool with_out = t0 + G >= ts.n;
         bool touch[G], mine[G];
@@ -908,7 +909,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
             }
         }
         PT(t0 == 0 ? 0 : 4);    // descriptors
-        const int b0 = DMA_T ? ((t0 / G) & 1) * G : 0;     // this round's tile buffers
+        // A round none of whose tiles reaches this block is skipped altogether (block-uniform: no staging, no barrier) unless it is the
+        // one that stages out_k - with two tiles side by side that is the first round of every block right of the overlap.
+        {
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < G; ++s) any = any | touch[s];
+            if (!any && !with_out) continue;
+        }
+        const int b0 = DMA_T ? (rnd & 1) * G : 0;          // this round's tile buffers: they alternate between EXECUTED rounds
+        const bool later_round = rnd > 0;
+        ++rnd;
         Px<M> sv[G + 1][2];                                // staging registers of whatever is not staged by DMA
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -948,7 +959,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
                 }
             }
         if constexpr (!DMA_T || !DMA_O) {
-            if constexpr (!DMA_T) { if (t0 > 0) __syncthreads(); }     // the previous round's readers are done with the (single) tile buffers
+            if constexpr (!DMA_T) { if (later_round) __syncthreads(); }     // the previous round's readers are done with the (single) tile buffers
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int i = threadIdx.x + 256 * it;

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1500 python -m pytest tests/test_gpu_warp.py tests/test_gpu_configs.py tests/test_gpu_fuzz_slice.py -x -q 2>&1 | tail -3)
-python tools/warp_probe.py 2000 2>&1 | tail -1
+(timeout 1500 python -m pytest tests/test_gpu_blend.py tests/test_gpu_configs.py tests/test_gpu_config5.py tests/test_gpu_fuzz_slice.py -x -q 2>&1 | tail -3)
+VARS="V0 V1" bash tools/ab_bench.sh
