@@ -53,13 +53,19 @@ int check_mat(const isx_mat* m, const char* what) {
     return ISX_OK;
 }
 
+static int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);     // the staging buffer lives on the device the caller selected (hipSetDevice precedes every use)
+    return dev;
+}
+
 int MatStage::use_in(const isx_mat* m, hipStream_t s, const char* what) {
     ISX_TRY(check_mat(m, what));
     host = nullptr;
     if (m->device >= 0) { d = *m; return ISX_OK; }
     size_t row = (size_t)m->cols * mat_elem_size(m->type);
     ISX_TRY(buf.reserve(row * m->rows));
-    d = *m; d.data = buf.p; d.step = row; d.device = 0;
+    d = *m; d.data = buf.p; d.step = row; d.device = current_device();
     // a continuous mat (cv::Mat::isContinuous(), what imread / create produce) is ONE linear copy: the runtime's pitched 2-D copy
     // moves a 4K CV_8UC3 image row by row at about 1.6 GB/s, the linear one at the link's rate
     if (m->step == row) ISX_HIP(hipMemcpyAsync(buf.p, m->data, row * (size_t)m->rows, hipMemcpyHostToDevice, s));
@@ -76,7 +82,7 @@ int MatStage::use_out(isx_mat* m, hipStream_t s, const char* what) {
     if (m->device >= 0) { d = *m; return ISX_OK; }
     size_t row = (size_t)m->cols * mat_elem_size(m->type);
     ISX_TRY(buf.reserve(row * m->rows));
-    d = *m; d.data = buf.p; d.step = row; d.device = 0;
+    d = *m; d.data = buf.p; d.step = row; d.device = current_device();
     host = m;
     return ISX_OK;
 }

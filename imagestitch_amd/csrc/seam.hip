@@ -200,6 +200,34 @@ __global__ __launch_bounds__(SEAM_NT) void k_seam_dp(const float4* ra, const flo
     if (threadIdx.x == 0) *found = reach[cur * n + (horiz ? dy : dx)] ? 1 : 0;   // S:918
 }
 
+// The same programme for wavefront steps too long for LDS (more than 15 360 cells: a component side beyond 15 K pixels): the previous
+// step's cost / reachability ping-pong in global memory, one __syncthreads() (a workgroup-scope release / acquire) per step.  The
+// reference has no such limit (S:806-957); this path keeps the call working, at global-memory speed.
+__global__ __launch_bounds__(SEAM_NT) void k_seam_dp_global(const float4* ra, const float2* rb, int rw, int n, int horiz, int sx, int sy, int dx, int dy,
+                                                            unsigned char* control, int* found, float* cost, unsigned char* reach) {
+    for (int i = threadIdx.x; i < n; i += SEAM_NT) { cost[i] = 0.f; reach[i] = (i == (horiz ? sy : sx)) ? 1 : 0; }   // S:850-851
+    const int first = (horiz ? sx : sy) + 1, last = horiz ? dx : dy;
+    __syncthreads();
+    int cur = 0;
+    for (int s = first; s <= last; ++s) {
+        const float* pc = cost + (size_t)cur * n;
+        const unsigned char* pr = reach + (size_t)cur * n;
+        float* nc = cost + (size_t)(cur ^ 1) * n;
+        unsigned char* nr = reach + (size_t)(cur ^ 1) * n;
+        const size_t row = (size_t)(s - first) * n;
+        for (int i = threadIdx.x; i < n; i += SEAM_NT) {
+            float best; int dir;
+            seam_cell(pc, pr, i, n, ra[row + i], rb[row + i], best, dir);
+            if (dir) control[horiz ? (size_t)i * rw + s : (size_t)s * rw + i] = (unsigned char)dir;
+            nc[i] = best;
+            nr[i] = dir ? 255 : 0;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (threadIdx.x == 0) *found = reach[(size_t)cur * n + (horiz ? dy : dx)] ? 1 : 0;   // S:918
+}
+
 struct SeamScratch { MatStage stages[3]; DevBuf scratch; int device = -1; };
 SeamScratch& seam_scratch() {
     static thread_local SeamScratch* s = new SeamScratch();   // never destroyed at thread exit (the HIP runtime may be gone by then)
@@ -246,7 +274,7 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
     if (horiz ? sx > dx : sy > dy) { std::swap(sx, dx); std::swap(sy, dy); swapped = true; }  // S:829-842
     if (is_horizontal) *is_horizontal = horiz ? 1 : 0;
     const int n = horiz ? rh : rw;
-    ISX_CHECK_ARG((size_t)n * 10 <= 150 * 1024, ISX_ERR_UNSUPPORTED, "seam_estimate: %d cells per wavefront step exceed the LDS-resident limit (15360)", n);
+    const bool lds_fits = (size_t)n * 10 <= 150 * 1024;   // one step's cost + reachability, both generations, in one workgroup's LDS
 
     ISX_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)hip_stream;
@@ -272,7 +300,8 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
                  ct_b = ((size_t)rh * rw + 255) & ~(size_t)255;
     const int first = (horiz ? sx : sy) + 1, nsteps = std::max((horiz ? dx : dy) - first + 1, 0);
     const size_t ra_b = ((size_t)std::max(nsteps, 1) * n * 16 + 255) & ~(size_t)255, rb_b = ((size_t)std::max(nsteps, 1) * n * 8 + 255) & ~(size_t)255;
-    ISX_TRY(scratch.reserve(cv_b + ch_b + ct_b + 256 + ra_b + rb_b));
+    const size_t gl_b = lds_fits ? 0 : (((size_t)n * 10 + 255) & ~(size_t)255);
+    ISX_TRY(scratch.reserve(cv_b + ch_b + ct_b + 256 + ra_b + rb_b + gl_b));
     float* costV = (float*)scratch.p;
     float* costH = (float*)((char*)scratch.p + cv_b);
     unsigned char* control = (unsigned char*)scratch.p + cv_b + ch_b;
@@ -292,7 +321,12 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
     if (nsteps > 0)
         ISX_LAUNCH("seam_pack", (double)nsteps * n * 48.0, st, k_seam_pack, dim3(cdiv(n, 256), nsteps), dim3(256), 0, g, (const float*)costV, (const float*)costH,
                    horiz ? 1 : 0, first, nsteps, n, ra, rb);
-    if (n <= SEAM_NT) ISX_SEAM_DP(1);
+    if (!lds_fits) {
+        float* gcost = (float*)((char*)rb + rb_b);
+        unsigned char* greach = (unsigned char*)gcost + (size_t)8 * n;
+        ISX_LAUNCH("seam_dp", (double)nsteps * n * 25.0, st, k_seam_dp_global, dim3(1), dim3(SEAM_NT), 0, (const float4*)ra, (const float2*)rb, rw, n, horiz ? 1 : 0,
+                   sx, sy, dx, dy, control, found, gcost, greach);
+    } else if (n <= SEAM_NT) ISX_SEAM_DP(1);
     else if (n <= 2 * SEAM_NT) ISX_SEAM_DP(2);
     else ISX_SEAM_DP(4);
 #undef ISX_SEAM_DP

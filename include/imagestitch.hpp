@@ -97,7 +97,7 @@ public:
         check(isx_warper_roi(h_, src_size.width, src_size.height, K, R, roi, nullptr));
         xmap.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, ISX_32FC1);   // W:128
         ymap.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, ISX_32FC1);   // W:129
-        check(isx_warper_build_maps(h_, src_size.width, src_size.height, K, R, xmap.c(), ymap.c(), roi));
+        check(isx_warper_build_maps_roi(h_, K, R, roi, xmap.c(), ymap.c()));   // the fill W:133-141 over the ROI just computed: one scan per call
         Rect r; r.x = roi[0]; r.y = roi[1]; r.width = roi[2] - roi[0]; r.height = roi[3] - roi[1];   // Rect(tl, br)  W:143
         return r;
     }

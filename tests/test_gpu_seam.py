@@ -50,6 +50,15 @@ def test_seam_wide_roi_and_device_views(gpu, oracle):
     assert np.array_equal(got, ref)
 
 
+def test_seam_step_longer_than_lds(gpu, oracle):
+    """16 300 cells per wavefront step (a component 16 300 pixels wide crossed top to bottom): more than one workgroup's LDS holds
+    (15 360), so the programme ping-pongs its state in global memory.  The reference has no size limit (S:806-957)."""
+    c = make_case(77, size1=(14, 16500), size2=(13, 16400), tl1=(0, 0), tl2=(100, 1), holes=True)
+    assert c["roi"][2] > 15360
+    ref = _both(gpu, oracle, c)
+    assert len(ref) > 0
+
+
 def test_seam_errors(gpu):
     c = make_case(1)
     with pytest.raises(gpu.IsxError) as e:
