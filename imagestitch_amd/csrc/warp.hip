@@ -450,13 +450,16 @@ __device__ __forceinline__ int reflect_once(int p, int n2m1) {
 template <int KIND, bool OUT16, bool VEC>
 __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dx0 = (blockIdx.x * 64 + lane) * 4;
+    // A wave is 64 pixels wide and 4 rows tall (16 lanes x 4 pixels per row), a block 64 x 16: the band of border pixels along the
+    // left and right edge of the warped tile is a few dozen pixels wide, so with 256 x 1 waves every row's first and last wave crossed
+    // it (tier 2); with 64 x 4 waves a quarter as many do.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dx0 = (blockIdx.x * 16 + (lane & 15)) * 4;
     // Row blocks are taken alternately from the top and from the bottom of the tile: the rows near the tile's upper and lower edge are
     // where waves cross the image border (tier 2 below, the occasional generic pixel) and live several times longer than interior
-    // waves - dispatched first they overlap with the rest of the launch, dispatched last they were its tail (26 -> 22 us per 4K tile).
+    // waves - dispatched first they overlap with the rest of the launch, dispatched last they were its tail.
     const int by = (blockIdx.y & 1) ? (int)gridDim.y - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1);
-    const int dy = by * 4 + wv;                     // wave-uniform
+    const int dy = by * 16 + wv * 4 + (lane >> 4);
     if (dy >= d.h || dx0 >= d.w) return;
     const bool whole = VEC && dx0 + 4 <= d.w;       // four real columns and dword-aligned rows: vector stores
     // ---- mapBackward (W:46-63): the transform of the thread's four columns in this row -------------------------------
@@ -1143,7 +1146,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_img_mask<O16, V>), grid4, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0, \
                    (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
         // the hot kernel: a tile whose mask is all 255 (W:213-214).  Same launch name: it is the same operation.
-        const dim3 gridt(cdiv(dw, 256), cdiv(dh, 4));
+        const dim3 gridt(cdiv(dw, 64), cdiv(dh, 16));
         const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, dw, dh}};
 #define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(256), 0, wta)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
