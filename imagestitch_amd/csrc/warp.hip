@@ -465,34 +465,37 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     // ---- mapBackward (W:46-63): the transform of the thread's four columns in this row -------------------------------
     const float4 cs4 = *(const float4*)(t.col_s + dx0), cc4 = *(const float4*)(t.col_c + dx0);   // tables are padded to 4 floats
     const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
+    // The x and y rows of k_rinv carry the factor 32 of cv::remap's fixed-point coordinate cvRound(32 x): a power of two commutes with
+    // every rounding on the way (products, sums, the division), so (32 k) . v / z has the bits of 32 (k . v / z).
+    const float kx0 = p.k_rinv[0] * 32.f, kx1 = p.k_rinv[1] * 32.f, kx2 = p.k_rinv[2] * 32.f, ky0 = p.k_rinv[3] * 32.f, ky1 = p.k_rinv[4] * 32.f, ky2 = p.k_rinv[5] * 32.f;
     f32x2 X[2], Y[2], Z[2];
     if constexpr (KIND == ISX_WARP_CYLINDRICAL) {
         const float ra = t.row_a[dy];                                                            // y_ = v / scale  W:49,52
-        const f32x2 qx = splat2(p.k_rinv[1] * ra), qy = splat2(p.k_rinv[4] * ra), qz = splat2(p.k_rinv[7] * ra);
+        const f32x2 qx = splat2(kx1 * ra), qy = splat2(ky1 * ra), qz = splat2(p.k_rinv[7] * ra);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            X[h] = (splat2(p.k_rinv[0]) * cs[h] + qx) + splat2(p.k_rinv[2]) * cc[h];             // W:56
-            Y[h] = (splat2(p.k_rinv[3]) * cs[h] + qy) + splat2(p.k_rinv[5]) * cc[h];             // W:57
+            X[h] = (splat2(kx0) * cs[h] + qx) + splat2(kx2) * cc[h];                             // W:56 (x 32)
+            Y[h] = (splat2(ky0) * cs[h] + qy) + splat2(ky2) * cc[h];                             // W:57 (x 32)
             Z[h] = (splat2(p.k_rinv[6]) * cs[h] + qz) + splat2(p.k_rinv[8]) * cc[h];             // W:58
         }
     } else {
         const float ra = t.row_a[dy], rb = t.row_b[dy];                                         // sinf(pi - v), cosf(pi - v)
-        const f32x2 qx = splat2(p.k_rinv[1] * rb), qy = splat2(p.k_rinv[4] * rb), qz = splat2(p.k_rinv[7] * rb);
+        const f32x2 qx = splat2(kx1 * rb), qy = splat2(ky1 * rb), qz = splat2(p.k_rinv[7] * rb);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x2 x_ = splat2(ra) * cs[h], z_ = splat2(ra) * cc[h];
-            X[h] = (splat2(p.k_rinv[0]) * x_ + qx) + splat2(p.k_rinv[2]) * z_;
-            Y[h] = (splat2(p.k_rinv[3]) * x_ + qy) + splat2(p.k_rinv[5]) * z_;
+            X[h] = (splat2(kx0) * x_ + qx) + splat2(kx2) * z_;
+            Y[h] = (splat2(ky0) * x_ + qy) + splat2(ky2) * z_;
             Z[h] = (splat2(p.k_rinv[6]) * x_ + qz) + splat2(p.k_rinv[8]) * z_;
         }
     }
-    // x / z, y / z (W:60) times 32: cvRound of these is cv::remap's fixed-point coordinate
+    // 32 x / z, 32 y / z (W:60): cvRound of these is cv::remap's fixed-point coordinate
     float tx[4], ty[4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const f32x2 r0 = {__builtin_amdgcn_rcpf(Z[h].x), __builtin_amdgcn_rcpf(Z[h].y)};
         const f32x2 r1 = refine_rcp(Z[h], r0);
-        const f32x2 ax = div_by_refined(X[h], Z[h], r1) * splat2(32.f), ay = div_by_refined(Y[h], Z[h], r1) * splat2(32.f);
+        const f32x2 ax = div_by_refined(X[h], Z[h], r1), ay = div_by_refined(Y[h], Z[h], r1);
         tx[2 * h] = ax.x; tx[2 * h + 1] = ax.y; ty[2 * h] = ay.x; ty[2 * h + 1] = ay.y;
     }
     // z of the four pixels inside the division's guarded range?  (A NaN slips through min / max and is caught below: its quotient

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1500 python -m pytest tests/test_gpu_warp.py tests/test_gpu_configs.py tests/test_gpu_seam.py -x -q 2>&1 | tail -3)
-VARS="V0 V1" bash tools/ab_bench.sh
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4)
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['kernels_ms_one_step']['warp_img_mask'], d['two_steps_in_flight'], d['dropin']['device_f32'], d['dropin']['device_i16'])"
