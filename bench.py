@@ -17,6 +17,7 @@ with device mats and with host (cv::Mat-like, PCIe-inclusive) mats; timed after 
 """
 import argparse
 import contextlib
+import gc
 import json
 import os
 import sys
@@ -416,7 +417,10 @@ def main():
     # stream, no side-stream overlap) with every kernel bracketed by HIP events: isolated durations, from which the
     # dominant kernel is chosen.  In the live planned step the ROI verification runs concurrently on a side stream and
     # would be charged to whichever kernel it overlaps.
-    for _ in range(max(args.warmup - 1, 0)):
+    # It is the SECOND warm-up step (the first creates the plans), so that the remaining warm-up steps run at full rate
+    # right before the timed region: the serialised step leaves the GPU mostly idle, and a 20-step region is only 5 ms long.
+    gc.collect()
+    if args.warmup > 1:
         step()
     fence()
     lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_reset()
@@ -440,12 +444,20 @@ def main():
                 p.step()
         ent_graph = _lib.profile_entries()
         lib.isx_profile_enable(0)
+    # as timeit does: no Python garbage collection inside the timed region (a generation-2 pass over torch's and numpy's objects
+    # takes ~35 ms here - the whole region of a 20-step run is 5 ms - and lands wherever the allocation counters happen to trip).
+    # The collection itself ran before the warm-up: any idle stretch in front of the region starts it on a colder clock
+    # (tools/probes/region_probe.py: 20 steps right after 5 ms of idle GPU run 3 % slower per step than after none).
+    gc.disable()
+    for _ in range(max(args.warmup - 2, 0)):   # the rest of the W warm-up steps, exactly as the timed ones
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     ent = ent_graph if args.graph else _lib.profile_entries()
     lib.isx_profile_enable(0)
     lib.isx_profile_sample(1)
