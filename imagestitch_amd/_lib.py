@@ -19,6 +19,7 @@ BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_1
 WARP_CYLINDRICAL, WARP_SPHERICAL = 0, 1
 BLEND_NO, BLEND_FEATHER, BLEND_MULTI_BAND = 0, 1, 2
 PREC_I16, PREC_F32, PREC_F16ACC32 = 0, 1, 2
+WINDOW_GRANULE = 128       # ISX_WINDOW_GRANULE: a column window of blend() starts on a multiple of it
 
 STATUS_NAMES = {0: "ISX_OK", 1: "ISX_ERR_INVALID", 2: "ISX_ERR_TYPE", 3: "ISX_ERR_STATE", 4: "ISX_ERR_HIP",
                 5: "ISX_ERR_NOMEM", 6: "ISX_ERR_UNSUPPORTED", 7: "ISX_ERR_SIZE", 8: "ISX_ERR_PLAN"}
@@ -65,6 +66,7 @@ _SIGS = {
     "isx_warper_verify": [C.c_void_p],
     "isx_warper_verify_after": [C.c_void_p, C.c_void_p],
     "isx_blender_set_mark_event": [C.c_void_p, C.c_void_p, C.c_int],
+    "isx_blender_set_window": [C.c_void_p, C.c_int, C.c_int],
     "isx_blender_create": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "isx_blender_destroy": [C.c_void_p],
     "isx_blender_set_stream": [C.c_void_p, C.c_void_p],

@@ -66,6 +66,13 @@ class MultiBandBlender:
     def set_overlap(self, on=True):
         check(self._lib.isx_blender_set_overlap(self._h, int(bool(on))))
 
+    def set_window(self, x0=0, x1=0):
+        """blend() of a deferred cycle produces the result's columns [x0, x1) only (x0 a multiple of WINDOW_GRANULE), into mats
+        x1 - x0 wide, bit-identical to the same columns of the whole blend: one strip of a panorama that is cut across GPUs
+        (isx_blender_set_window; mosaic.strip_windows / tiles_for_window).  (0, 0) removes the window."""
+        check(self._lib.isx_blender_set_window(self._h, int(x0), int(x1)))
+        self._window = (int(x0), int(x1)) if x1 > x0 else None
+
     def setNumBands(self, n):
         check(self._lib.isx_blender_set_num_bands(self._h, int(n)))
 
@@ -116,6 +123,8 @@ class MultiBandBlender:
     def blend(self, dst=None, dst_mask=None, out_f32=False, out_u8=False):
         """blend(result, result_mask) (W:313) -> (result, result_mask).  out_u8: + result.convertTo(CV_8U)."""
         w, h = self.result_size()
+        if getattr(self, "_window", None):
+            w = self._window[1] - self._window[0]
         like = self._like if (self._like is not None and _is_tensor(self._like)) else np.empty(0)
         if dst is None:
             dst = _empty_like_kind(like, (h, w, 3), np.uint8 if out_u8 else (np.float32 if out_f32 else np.int16))

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBu
 // OpenCV's explicit edge formulas so the clamped value is never used).
 // ------------------------------------------------------------------------------------------------
 constexpr int UP_TY = 4;
+static_assert(ISX_WINDOW_GRANULE == 2 * WAVE, "a window starts on a block column of the last collapse step");
 
 template <int M>
 struct Up4 { typename WorkT<M>::t v[2][2][3]; };  // [dy][dx][channel]
@@ -649,6 +650,7 @@ struct OutMat {  // the caller's blend() outputs
     unsigned char* mask; size_t mask_step;
     int rows, cols;  // dst_roi_final_ size
     int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
+    int bx0;         // column window (isx_blender_set_window): first block column of this launch, 0 without a window
 };
 
 // saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     constexpr int NB = DMA_T ? 2 * G + 1 : G + 1;     // the last buffer is out_k's
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cx0 = blockIdx.x * WAVE, cy0 = blockIdx.y * UP_TY;
+    const int cx0 = (blockIdx.x + out.bx0) * WAVE, cy0 = blockIdx.y * UP_TY;
     PT_DECL;
     // float work types: the accumulators and every stencil operation on (b, g) / (r, -) register pairs (packed fp32, see pyr_up_2x2_pk)
     constexpr bool PK = M != M_I16;
@@ -1347,6 +1349,7 @@ struct isx_blender {
     bool prepared = false;
     int rx = 0, ry = 0, rw = 0, rh = 0;  // dst_roi_ (padded)
     int fw = 0, fh = 0;                  // dst_roi_final_ size
+    int win_x0 = 0, win_x1 = 0;          // isx_blender_set_window: blend() produces columns [win_x0, win_x1) only (0, 0 = everything)
     LevelBuf dst[MAX_LEVELS];
     DevBuf dst_arena, tile_arena;
     DevBuf out_arena;                    // I16, deferred cycle: the collapsed levels out_k as 16-byte register records
@@ -1647,8 +1650,23 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     //    record read once, every output written once; the destination pyramid of the eager path and of
     //    SURVEY's model does not exist here)
     // 3. collapse chain; each step gathers the tiles' Laplacians of its fine level in registers
+    // Column window (isx_blender_set_window): the step that produces level k - 1 runs only the block columns that hold the columns of
+    // level k - 1 the window needs: need_0 = the window, need_k = need_{k-1} halved and widened by the one coarse column pyrUp reads on
+    // either side.  Whatever else those blocks compute (and whatever they read outside need_k: levels left over from an earlier cycle)
+    // reaches no pixel of the window - every input of a pixel of need_{k-1} lies in need_k by construction - so the window's pixels
+    // are those of the whole mosaic, bit for bit, and a mosaic can be cut into column strips computed on different GPUs.
+    int need_lo[MAX_LEVELS], need_hi[MAX_LEVELS];
+    const bool windowed = b->win_x1 > b->win_x0;
+    need_lo[0] = windowed ? b->win_x0 : 0; need_hi[0] = windowed ? std::min(b->win_x1, b->fw) : d[0].cols;
+    for (int k = 1; k <= L; ++k) {
+        need_lo[k] = windowed ? std::max(need_lo[k - 1] / 2 - 1, 0) : 0;
+        need_hi[k] = windowed ? std::min((need_hi[k - 1] - 1) / 2 + 2, d[k].cols) : d[k].cols;
+    }
     for (int k = L; k >= 1; --k) {
         TileSet ts = base(k - 1);
+        const int gx_all = cdiv(d[k].cols, WAVE);
+        const int bx_lo = need_lo[k - 1] / (2 * WAVE), bx_hi = std::min(cdiv(need_hi[k - 1], 2 * WAVE), gx_all);
+        const double frac = (double)(bx_hi - bx_lo) / gx_all;                                  // share of the level this launch works on
         double bytes = k == L ? 0.0 : (double)d[k].rows * d[k].cols * alg_d_rgb(prec);      // out_k as pyrUp source (k = L: gathered from G_L)
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
@@ -1657,15 +1675,17 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
                    + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
         }
-        dim3 grid(cdiv(d[k].cols, WAVE), cdiv(d[k].rows, UP_TY));
+        dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
+        OutMat o = out;
+        o.bx0 = bx_lo;
         if (k == 1) {
-            bytes += (double)out.rows * out.cols * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));                  // result + mask
-            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], out);
-            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, false>), grid, dim3(256), 0, ts, d[1], d[0], out);
+            bytes = bytes * frac + (double)out.rows * (need_hi[0] - need_lo[0]) * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));   // result + mask
+            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
+            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, false>), grid, dim3(256), 0, ts, d[1], d[0], o);
         } else {
-            bytes += (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec);                   // out_{k-1}
-            if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, true>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
-            else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], out);
+            bytes = (bytes + (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec)) * frac;  // + out_{k-1}
+            if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, true>), grid, dim3(256), 0, ts, d[k], d[k - 1], o);
+            else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], o);
         }
     }
     return ISX_OK;
@@ -2046,6 +2066,15 @@ int isx_blender_set_deferred_level0(isx_blender* b, int on) {
     return ISX_OK;
 }
 
+int isx_blender_set_window(isx_blender* b, int x0, int x1) {
+    clear_error();
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "set_window: null blender");
+    ISX_CHECK_ARG((x0 == 0 && x1 == 0) || (x0 >= 0 && x1 > x0 && x0 % ISX_WINDOW_GRANULE == 0), ISX_ERR_INVALID,
+                  "set_window: columns [%d, %d): the first must be a non-negative multiple of %d and below the second (0, 0 = no window)", x0, x1, ISX_WINDOW_GRANULE);
+    b->win_x0 = x0; b->win_x1 = x1;
+    return ISX_OK;
+}
+
 int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_mark_event: null blender");
     b->mark_event = (hipEvent_t)hip_event;
@@ -2163,12 +2192,20 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     ISX_TRY(check_mat(dst, "blend: dst"));
     ISX_CHECK_ARG(dst->type == ISX_16SC3 || dst->type == ISX_8UC3 || (dst->type == ISX_32FC3 && b->prec != ISX_PREC_I16), ISX_ERR_TYPE,
                   "blend: dst must be CV_16SC3, CV_8UC3%s, got %s", b->prec != ISX_PREC_I16 ? " or CV_32FC3" : "", type_name(dst->type));
-    ISX_CHECK_ARG(dst->rows == b->fh && dst->cols == b->fw, ISX_ERR_SIZE, "blend: dst is %dx%d, result is %dx%d", dst->cols, dst->rows, b->fw, b->fh);
+    const bool windowed = b->win_x1 > b->win_x0;
+    const int out_cols = windowed ? b->win_x1 - b->win_x0 : b->fw;   // a window's mats hold its columns only
+    if (windowed) {
+        ISX_CHECK_ARG(b->type == ISX_BLEND_MULTI_BAND && b->level0_pending, ISX_ERR_UNSUPPORTED,
+                      "blend: a column window needs the deferred MultiBandBlender cycle (isx_blender_set_deferred_level0) with every tile still recorded");
+        ISX_CHECK_ARG(b->win_x0 < b->fw, ISX_ERR_SIZE, "blend: the window starts at column %d, the result is %d wide", b->win_x0, b->fw);
+    }
+    ISX_CHECK_ARG(dst->rows == b->fh && dst->cols == out_cols, ISX_ERR_SIZE, "blend: dst is %dx%d, result%s is %dx%d", dst->cols, dst->rows,
+                  windowed ? " window" : "", out_cols, b->fh);
     if (dst_mask) {
         ISX_TRY(check_mat(dst_mask, "blend: dst_mask"));
         ISX_CHECK_ARG(dst_mask->type == ISX_8UC1, ISX_ERR_TYPE, "blend: dst_mask must be CV_8U, got %s", type_name(dst_mask->type));
-        ISX_CHECK_ARG(dst_mask->rows == b->fh && dst_mask->cols == b->fw, ISX_ERR_SIZE, "blend: dst_mask is %dx%d, result is %dx%d",
-                      dst_mask->cols, dst_mask->rows, b->fw, b->fh);
+        ISX_CHECK_ARG(dst_mask->rows == b->fh && dst_mask->cols == out_cols, ISX_ERR_SIZE, "blend: dst_mask is %dx%d, result%s is %dx%d",
+                      dst_mask->cols, dst_mask->rows, windowed ? " window" : "", out_cols, b->fh);
     }
     ISX_HIP(hipSetDevice(b->device));
     ISX_TRY(b->st_out.use_out(dst, b->stream, "blend: dst"));
@@ -2182,7 +2219,16 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
-    o.rows = b->fh; o.cols = b->fw;
+    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0;
+    if (windowed) {
+        // the kernels keep addressing the mosaic's columns: the mats' origins move left by the window's first column (a multiple of
+        // ISX_WINDOW_GRANULE, so every alignment is kept and a block of the last step starts exactly there), the right crop is the
+        // window's end; columns of the mats past the mosaic's right edge (a last strip padded to its peers' width) are left as they are
+        const size_t px = dst->type == ISX_32FC3 ? 12 : (dst->type == ISX_8UC3 ? 3 : 6);
+        o.img -= (size_t)b->win_x0 * px;
+        if (o.mask) o.mask -= (size_t)b->win_x0;
+        o.cols = std::min(b->win_x1, b->fw);
+    }
     o.vec = ((uintptr_t)o.img % 4 == 0) && (o.img_step % 4 == 0) && (!o.mask || (((uintptr_t)o.mask % 2 == 0) && (o.mask_step % 2 == 0)));
     int rc = ISX_OK;
     if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend

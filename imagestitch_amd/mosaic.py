@@ -59,6 +59,80 @@ def chunk_view(out, world, offset, count, rank):
     return out.view(-1)[world * offset + rank * count: world * offset + (rank + 1) * count]
 
 
+# ---- one panorama cut into column strips ------------------------------------------------------------
+# A panorama of many tiles is not a batch of independent pairs: neighbouring tiles meet in the mosaic.  It still shards without any
+# exchange before the final gather: rank r produces the columns [x0_r, x1_r) of the result (MultiBandBlender.set_window) and, for
+# that, warps and feeds only the tiles that can reach those columns - its own and the neighbours' that overlap its strip (the halo
+# is recomputed, not exchanged).  Every strip pixel equals the same pixel of the whole blend bit for bit, so the all-gather of the
+# strips IS the panorama, stored strip-major; assemble_strips gives the row-major view.
+
+def strip_windows(width, world, granule=128):
+    """Column windows [(x0, x1)] * world of a result `width` wide: equal widths (all-gather needs equal counts), a multiple of
+    `granule` (ISX_WINDOW_GRANULE); windows that start past the right edge are empty ((x0, x0)), the last non-empty one may
+    extend past it (those columns are never written)."""
+    sw = -(-width // (world * granule)) * granule
+    return [(r * sw, (r + 1) * sw) if r * sw < width else (r * sw, r * sw) for r in range(world)], sw
+
+
+def feed_rect(roi, num_bands, tl, size):
+    """The rectangle MultiBandBlender::feed works on for a tile at `tl` of `size` (A11: the tile widened by gap = 3 * 2^L, clipped to
+    dst_roi, snapped to 2^L, padded to a multiple of 2^L, shifted back inside dst_roi) as (x, y, w, h) RELATIVE to dst_roi's corner."""
+    rx, ry, rw, rh = roi
+    L, m = num_bands, 1 << num_bands
+    gap = 3 * m
+    tlx, tly = max(rx, tl[0] - gap), max(ry, tl[1] - gap)
+    brx, bry = min(rx + rw, tl[0] + size[0] + gap), min(ry + rh, tl[1] + size[1] + gap)
+    tlx = rx + (((tlx - rx) >> L) << L)
+    tly = ry + (((tly - ry) >> L) << L)
+    w, h = brx - tlx, bry - tly
+    w += (m - w % m) % m
+    h += (m - h % m) % m
+    tlx -= max(tlx + w - (rx + rw), 0)
+    tly -= max(tly + h - (ry + rh), 0)
+    return tlx - rx, tly - ry, w, h
+
+
+def window_needs(num_bands, x0, x1, level_cols):
+    """Columns [lo, hi) of every level that the result's columns [x0, x1) depend on: level k - 1 is pyrUp of level k, which reads
+    one coarse column on either side (the recursion blend() itself uses to pick its blocks)."""
+    lo, hi = [x0], [min(x1, level_cols[0])]
+    for k in range(1, num_bands + 1):
+        lo.append(max(lo[-1] // 2 - 1, 0))
+        hi.append(min((hi[-1] - 1) // 2 + 2, level_cols[k]))
+    return lo, hi
+
+
+def tiles_for_window(corners, sizes, num_bands, x0, x1):
+    """Indices of the tiles a rank must warp and feed to produce the result's columns [x0, x1) exactly: those whose fed rectangle
+    meets, at some pyramid level, the columns of that level the window depends on."""
+    import numpy as np
+    c = np.asarray(corners).reshape(-1, 2)
+    s = np.asarray(sizes).reshape(-1, 2)
+    tl, br = c.min(0), (c + s).max(0)
+    w, h = int(br[0] - tl[0]), int(br[1] - tl[1])
+    L = min(num_bands, int(np.ceil(np.log(float(max(w, h))) / np.log(2.0))))
+    m = 1 << L
+    roi = (int(tl[0]), int(tl[1]), w + (m - w % m) % m, h + (m - h % m) % m)
+    cols = [roi[2]]
+    for k in range(L):
+        cols.append((cols[-1] + 1) // 2)
+    lo, hi = window_needs(L, x0, min(x1, w), cols)
+    keep = []
+    for i in range(len(c)):
+        fx, _, fw, _ = feed_rect(roi, L, (int(c[i][0]), int(c[i][1])), (int(s[i][0]), int(s[i][1])))
+        if any((fx >> k) < hi[k] and ((fx + fw) >> k) > lo[k] for k in range(L + 1)):
+            keep.append(i)
+    return keep
+
+
+def assemble_strips(gathered, rows, strip_cols, width, channels=3):
+    """(world, rows * strip_cols * channels) strips as the all-gather leaves them -> the (rows, width, channels) panorama
+    (a permuted view made contiguous: one device copy; consumers that can take strips use `gathered` as it is)."""
+    world = gathered.shape[0]
+    v = gathered.reshape(world, rows, strip_cols, channels).permute(1, 0, 2, 3).reshape(rows, world * strip_cols, channels)
+    return v[:, :width].contiguous()
+
+
 class IsxGather:
     """The same collective through the C-ABI (isx_gather_*: an RCCL communicator owned by the library, for pipelines without
     torch).  The 128-byte rendezvous id travels over whatever the caller has; here: torch.distributed's object broadcast."""

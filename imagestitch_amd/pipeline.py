@@ -72,7 +72,11 @@ class PairStitcher:
     tensors).  At most 8 tiles stay on the deferred blender cycle (isx_blender_set_deferred_level0)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
-                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1):
+                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1, window=None):
+        """window = (x0, x1): this object produces only the columns [x0, x1) of the mosaic (x0 a multiple of _lib.WINDOW_GRANULE,
+        counted from the mosaic's left edge) - one strip of a panorama cut across GPUs (mosaic.strip_windows).  It then warps and
+        feeds only the tiles that can reach those columns (self.active; `imgs` may hold None for the others), prepare() still gets
+        every tile's rectangle, and self.out is x1 - x0 columns wide: bit for bit the same columns as the unwindowed mosaic."""
         import torch
         self.torch = torch
         self.imgs, self.K, self.Rs = imgs, K, Rs
@@ -90,20 +94,33 @@ class PairStitcher:
         self.precision, self.num_bands = precision, num_bands
         dev = torch.device("cuda", device)
         # plan: ROI per tile (detectResultRoi), output buffers, seam masks
-        self.rois = [self.warper.warpRoi((im.shape[1], im.shape[0]), K, R) for im, R in zip(imgs, Rs)]
+        src_size = next((im.shape[1], im.shape[0]) for im in imgs if im is not None)   # one rig: every tile has the same size
+        self.rois = [self.warper.warpRoi(src_size if im is None else (im.shape[1], im.shape[0]), K, R) for im, R in zip(imgs, Rs)]
         self.sizes = [(r[2] - r[0] + 1, r[3] - r[1] + 1) for r in self.rois]
         self.corners = [(r[0], r[1]) for r in self.rois]
+        self.window = None if window is None else (int(window[0]), int(window[1]))
+        self.active = list(range(len(imgs)))
+        if self.window is not None:
+            from . import mosaic
+            self.active = mosaic.tiles_for_window(self.corners, self.sizes, num_bands, *self.window)
+            if any(imgs[i] is None for i in self.active):
+                raise ValueError("window %s needs tiles %s" % (self.window, self.active))
         # cv::Mat-style pitched buffers (row pitch a multiple of 64 B) so that the warp kernel can store dwords
         def pitched(h, row_bytes, shape, strides):
             pitch = (row_bytes + 63) // 64 * 64
             return torch.empty((h * pitch,), dtype=torch.uint8, device=dev).as_strided(shape, (pitch,) + strides)
-        self.warped = [pitched(h, w * 3, (h, w, 3), (3, 1)) for (w, h) in self.sizes]
-        self.wmasks = [pitched(h, w, (h, w), (1,)) for (w, h) in self.sizes]
-        for i in range(len(imgs)):
+        act = set(self.active)
+        self.warped = [pitched(h, w * 3, (h, w, 3), (3, 1)) if i in act else None for i, (w, h) in enumerate(self.sizes)]
+        self.wmasks = [pitched(h, w, (h, w), (1,)) if i in act else None for i, (w, h) in enumerate(self.sizes)]
+        for i in self.active:
             self.warper.warp_with_mask(imgs[i], K, Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
-        seam = synth.seam_masks(self.corners, [m.cpu().numpy() for m in self.wmasks])
-        self.seam = [torch.from_numpy(s).to(dev) for s in seam]
+        seam = synth.seam_masks(self.corners, [None if m is None else m.cpu().numpy() for m in self.wmasks], self.sizes)
+        self.seam = [None if s is None else torch.from_numpy(s).to(dev) for s in seam]
         self.roi_pad, (fw, fh), self.L = prepare_geometry(self.corners, self.sizes, num_bands)
+        self.mosaic_size = (fw, fh)
+        if self.window is not None:
+            self.blender.set_window(*self.window)
+            fw = self.window[1] - self.window[0]
         # Where the ROI verification scans of a planned step start.  verify_at < 0: right after the last warp (they then
         # run under the level-0 pyrDown, which they slow down by more than their own length).  verify_at = k >= 0:
         # inside blend(), behind the pyrDown launch of level k — from there to the last collapse step the launches are
@@ -125,19 +142,18 @@ class PairStitcher:
         """Steady-state step without host round trips: the ROI scan (detectResultRoi) still runs on the
         GPU for every warp and is compared ON THE DEVICE with the ROI planned in __init__; a mismatch
         raises the sticky flag read by check_plan().  Everything else is the reference's call sequence."""
-        n = len(self.imgs)
         if self.interleave:   # warp(t), feed(t), warp(t+1), ...: tile t's Gaussian chain runs under tile t+1's warp
             self.blender.prepare(self.corners, self.sizes)
-            for i in range(n):
+            for i in self.active:
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
                 self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
         else:
-            for i in range(n):
+            for i in self.active:
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
             if self.mark is None:
                 self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
-            for i in range(n):
+            for i in self.active:
                 self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
         self.blender.blend(self.out, self.out_mask)
         if self.mark is not None and not self.interleave:
@@ -174,20 +190,20 @@ class PairStitcher:
     def step_sync(self):
         """Exactly the reference's call sequence; the warper returns the corner to the host on every call
         (one stream synchronisation per tile), as cv::detail::RotationWarper::warp does."""
-        cs = []
-        for i in range(len(self.imgs)):
+        cs = list(self.corners)   # the tiles this strip does not hold keep their planned corner
+        for i in self.active:
             c, _, _ = self.warper.warp_with_mask(self.imgs[i], self.K, self.Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
-            cs.append(c)
+            cs[i] = c
         self.blender.prepare(cs, self.sizes)
-        for i in range(len(self.imgs)):
+        for i in self.active:
             self.blender.feed_u8(self.warped[i], self.seam[i], cs[i])
         self.blender.blend(self.out, self.out_mask)
         return self.out, self.out_mask
 
     def bytes_model(self):
-        src_px = [im.shape[0] * im.shape[1] for im in self.imgs]
-        warped_px = [w * h for (w, h) in self.sizes]
-        base = [np.prod(feed_geometry(self.roi_pad, self.L, c, s)) for c, s in zip(self.corners, self.sizes)]
+        src_px = [self.imgs[i].shape[0] * self.imgs[i].shape[1] for i in self.active]
+        warped_px = [self.sizes[i][0] * self.sizes[i][1] for i in self.active]
+        base = [np.prod(feed_geometry(self.roi_pad, self.L, self.corners[i], self.sizes[i])) for i in self.active]
         mosaic = self.roi_pad[2] * self.roi_pad[3]
         out = model_bytes(src_px, warped_px, [float(b) for b in base], float(mosaic), self.precision, self.L)
         out.update({"src_px": src_px, "warped_px": warped_px, "tile_base_px": [int(b) for b in base], "mosaic_px": int(mosaic)})

@@ -48,21 +48,25 @@ def camera_ring(width, height, focal, n, yaw_step, pitch=0.010, roll=0.005):
     return K, Rs
 
 
-def seam_masks(corners, warped_masks):
+def seam_masks(corners, warped_masks, sizes=None):
     """Seam-finder stand-in for a row of n >= 2 tiles: between neighbours (in order of their corner x) the
     seam x_s(y) = x_mid + round(40 sin(2 pi y / 512)) runs through the centre of their overlap; tile i keeps
     warped_i & (x_s[i-1] <= X < x_s[i]) (X, y in panorama coordinates).  For a pair: mask0 = warped0 & (X < x_s),
-    mask1 = warped1 & (X >= x_s)."""
+    mask1 = warped1 & (X >= x_s).  `sizes` ((w, h) per tile) lets entries of warped_masks be None: those tiles get no mask (a
+    rank that blends one strip of the panorama holds only the tiles near it; the seams still depend on every tile's rectangle)."""
     n = len(corners)
+    widths = [warped_masks[i].shape[1] if sizes is None else sizes[i][0] for i in range(n)]
     order = sorted(range(n), key=lambda i: corners[i][0])
     mids = []
     for a, b in zip(order[:-1], order[1:]):
         ov_l = max(corners[a][0], corners[b][0])
-        ov_r = min(corners[a][0] + warped_masks[a].shape[1], corners[b][0] + warped_masks[b].shape[1])
+        ov_r = min(corners[a][0] + widths[a], corners[b][0] + widths[b])
         mids.append((ov_l + ov_r) // 2)
     out = [None] * n
     for pos, i in enumerate(order):
         (cx, cy), m = corners[i], warped_masks[i]
+        if m is None:
+            continue
         Y = cy + np.arange(m.shape[0])[:, None]
         X = cx + np.arange(m.shape[1])[None, :]
         wob = np.rint(40.0 * np.sin(2 * np.pi * Y / 512.0)).astype(np.int64)

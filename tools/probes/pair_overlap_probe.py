@@ -1,5 +1,6 @@
 """Two independent 4K pairs on two streams: do their steps overlap?  (run on the GPU box)  Modes: eager on one stream, eager on two
 streams, one hipGraph per pair on its own stream.  Reports ms per pair and the host's enqueue time per step."""
+import gc
 import os
 import sys
 import time
@@ -33,6 +34,7 @@ def run(n):
 
 
 run(3); torch.cuda.synchronize()
+gc.collect(); gc.disable()   # a generation-2 collection (~35 ms) inside a timed loop looks like a stalled GPU
 n = 30
 t0 = time.perf_counter(); run(n); th = time.perf_counter() - t0; torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("%d pairs, eager, %d streams: %.3f ms per pair (host enqueue %.3f ms per pair)" % (NP, NS, dt / n / NP * 1e3, th / n / NP * 1e3))
@@ -56,12 +58,7 @@ if len(sys.argv) > 3:
         torch.cuda.synchronize()
     print("  step() enqueue ms with the GPU idle: median %.3f" % (np.median(ts2) * 1e3))
     # the host kept at most DEPTH whole iterations ahead of the GPU (an event per iteration, waited on DEPTH iterations later)
-    lib = _lib.load() if hasattr(_lib, "load") else None
-    import imagestitch_amd
-    lib = imagestitch_amd.load()
-    for depth in (2, 2, 2):
-        if os.environ.get("PROBE_PROFILE"):
-            lib.isx_profile_enable(1); lib.isx_profile_filter(b"collapse_final"); lib.isx_profile_sample(4)
+    for depth in (1, 2, 4):
         evs = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
