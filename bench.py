@@ -232,6 +232,12 @@ def main():
                     help="HIP streams the pairs of a step are spread over (default: 1 for one pair, min(pairs, 4) otherwise): independent pairs on "
                          "separate streams overlap - one pair's launch-latency-bound small pyramid levels run under another pair's large kernels "
                          "(measured: 0.252 -> 0.220 ms per 4K pair with 2-4 streams; one hipGraph per pair does not overlap)")
+    ap.add_argument("--shard", default="pairs", choices=["pairs", "strips"],
+                    help="N > 1: pairs = every rank blends its own independent pairs (BASELINE config 4); strips = ONE panorama of --tiles tiles "
+                         "per step, cut into N column strips: rank r warps and feeds only the tiles near its strip, blends the strip "
+                         "(isx_blender_set_window) and the all-gather of the strips is the panorama (strong scaling: the work per step is fixed)")
+    ap.add_argument("--strip-of", default=None, metavar="R/W",
+                    help="one GPU, no gather: run what rank R of W would run under --shard strips (its share of the compute, measurable here)")
     ap.add_argument("--gather", default="chunk", choices=["chunk", "single"],
                     help="N > 1: all-gather the rank's block pair by pair behind each blend (default), or as ONE collective per step")
     ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx"],
@@ -284,9 +290,29 @@ def main():
         args.sync_roi = True
     gen = torch.Generator(device=dev)
     pairs = []
+    # --shard strips: this rank's column window of the panorama, from the rig alone (every rank derives the same strips)
+    strip_rank, strip_world, window, fw_all = rank, world, None, None
+    if args.strip_of:
+        strip_rank, strip_world = (int(v) for v in args.strip_of.split("/"))
+        args.shard = "strips"
+    strips = args.shard == "strips" and strip_world > 1
+    if args.strip_of:
+        args.no_dropin = args.no_cpu_baseline = True      # those legs describe the whole single-GPU job, not one rank's share
+    if strips:
+        from imagestitch_amd import mosaic as _mosaic
+        from imagestitch_amd.pipeline import prepare_geometry
+        from imagestitch_amd.warper import CylindricalWarper, SphericalWarper
+        wp = (CylindricalWarper if args.kind == "cylindrical" else SphericalWarper)(local, None).create(F)
+        rois = [wp.warpRoi((W, H), K, R) for R in Rs]
+        _, (fw_all, _), _ = prepare_geometry([(r[0], r[1]) for r in rois], [(r[2] - r[0] + 1, r[3] - r[1] + 1) for r in rois], args.bands)
+        windows, strip_cols = _mosaic.strip_windows(fw_all, strip_world, _lib.WINDOW_GRANULE)
+        window = windows[strip_rank]
+        if window[1] == window[0]:
+            raise SystemExit("--shard strips: %d ranks are more than this %d-column panorama has strips of %d columns" % (strip_world, fw_all, strip_cols))
+        del wp
     pstreams = [None] if (args.streams <= 1 or args.graph) else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
     for p in range(args.pairs):
-        gen.manual_seed(synth.SEED0 + 1000 * rank + p)
+        gen.manual_seed(synth.SEED0 + p + (0 if strips else 1000 * rank))     # strips: every rank holds the SAME panorama's tiles
         # same statistics as synth.make_tile (sinusoid + U{-32..31} noise), generated on the device
         yy, xx = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
         imgs = []
@@ -300,7 +326,7 @@ def main():
         if p == 0 and rank == 0:
             host_imgs0 = [im.cpu().numpy() for im in imgs]
         pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, pstreams[p % len(pstreams)], "uint8" if (world > 1 or args.force_dist) else "int16",
-                                  deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle]))
+                                  deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle], window=window))
         del yy, xx
     if args.roi_cache:
         for p in pairs:
@@ -491,7 +517,8 @@ def main():
         split = (dt_c, dt_g, int(send[0].numel()))
 
     if rank == 0:
-        mpix_step = world * args.pairs * NT * W * H / 1e6
+        # strips: the unit of work is the panorama, whichever ranks touch a tile (neighbours' tiles are recomputed, not counted twice)
+        mpix_step = (1 if strips else world) * args.pairs * NT * W * H / 1e6
         roof = None
         if dominant and ent.get(dominant, {}).get("launches", 0) > 0:
             e = ent[dominant]
@@ -507,13 +534,15 @@ def main():
         out = {
             "metric": "Mpix/s warp+5-band-blend @4K pair", "value": round(mpix_step * args.steps / dt, 1), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
+            "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%s%d x (%d x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
+            "config": {"workload": ("ONE panorama per step cut into %d column strips, strip %d here: " % (strip_world, strip_rank) if strips else "") + "%s%d x (%d x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
                 ("%d x %dx%d tiles, %d tiles/GPU: " % (world * args.pairs * NT, W, H, args.pairs * NT)) if world > 1 else "",
                 args.pairs, NT, W, H, args.kind, F, args.bands, args.precision, (", u8x3 mosaics all-gathered pair by pair behind each blend (%s)" % args.gather_backend if args.gather == "chunk" else
                  ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step (%s)" % args.gather_backend) if use_dist else ""),
                 "tiles_per_mosaic": NT,
+                **({"shard": "strips", "strip": "%d/%d" % (strip_rank, strip_world), "window": list(window), "panorama_cols": fw_all,
+                    "tiles_this_rank": pairs[0].active} if strips else {}),
                 "pairs_per_gpu": args.pairs, "streams": len(pstreams), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),

@@ -801,6 +801,7 @@ struct TileSet {                 // per-tile views of one pyramid level pair, in
     LevelBuf fine[DEF_MAX];      // G_{k-1,t}  (unused when the fine level is level 0)
     LevelBuf coarse[DEF_MAX];    // G_{k,t}
     int x_tl[DEF_MAX], y_tl[DEF_MAX], w[DEF_MAX], h[DEF_MAX];   // tile rectangle at the FINE level, dst_roi_ coordinates
+    int bx_lo[DEF_MAX], bx_hi[DEF_MAX];                          // k_pyr_down_multi: block columns of the tile's destination level to produce (column window)
 };
 
 template <int M, int SK>
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
-    if (blockIdx.x * PD_OW >= dst.cols || blockIdx.y * PD_TY >= dst.rows) return;
+    if (blockIdx.x * PD_OW >= dst.cols || blockIdx.y * PD_TY >= dst.rows || (int)blockIdx.x < ts.bx_lo[t] || (int)blockIdx.x >= ts.bx_hi[t]) return;
     pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y);
 }
 
@@ -1618,9 +1619,25 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             ts.s0[t] = r.s0;
             ts.x_tl[t] = r.x_tl >> k_fine; ts.y_tl[t] = r.y_tl >> k_fine;
             ts.w[t] = r.g[k_fine].cols; ts.h[t] = r.g[k_fine].rows;
+            ts.bx_lo[t] = 0; ts.bx_hi[t] = 1 << 30;
         }
         return ts;
     };
+    // Column window (see step 3): the columns of every level the window's pixels depend on, need_k, and from them the columns of the
+    // tiles' Gaussian levels that have to be PRODUCED: prod_L = need_L, prod_k = need_k widened by what pyrDown reads for prod_{k+1}
+    // (columns 2c - 2 .. 2c + 2).  A tile's chain runs only the blocks that hold them; the rest of its levels keeps whatever it held.
+    int need_lo[MAX_LEVELS], need_hi[MAX_LEVELS], prod_lo[MAX_LEVELS], prod_hi[MAX_LEVELS];
+    const bool windowed = b->win_x1 > b->win_x0;
+    need_lo[0] = windowed ? b->win_x0 : 0; need_hi[0] = windowed ? std::min(b->win_x1, b->fw) : d[0].cols;
+    for (int k = 1; k <= L; ++k) {
+        need_lo[k] = windowed ? std::max(need_lo[k - 1] / 2 - 1, 0) : 0;
+        need_hi[k] = windowed ? std::min((need_hi[k - 1] - 1) / 2 + 2, d[k].cols) : d[k].cols;
+    }
+    prod_lo[L] = need_lo[L]; prod_hi[L] = need_hi[L];
+    for (int k = L - 1; k >= 0; --k) {
+        prod_lo[k] = std::max(std::min(need_lo[k], 2 * prod_lo[k + 1] - 2), 0);
+        prod_hi[k] = std::min(std::max(need_hi[k], 2 * (prod_hi[k + 1] - 1) + 3), d[k].cols);
+    }
     const double gin0 = src_px_bytes(SK) + 1.0;
     // 1. Gaussian chains: one launch per level for all tiles.  (Per-tile chains on side streams, started
     //    by feed() to overlap with the next tile's VALU-bound warp, were measured: no gain — a kernel that
@@ -1636,7 +1653,14 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             const isx_blender::TileRec& r = b->tiles[t];
             ts.fine[t] = r.g[k]; ts.coarse[t] = r.g[k + 1];
             maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
-            bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
+            double share = 1.0;
+            if (windowed) {   // the tile's columns of level k + 1 inside prod_{k+1}, as block columns of its own grid
+                const int x_t = r.x_tl >> (k + 1), nbx = cdiv(r.g[k + 1].cols, PD_OW);
+                const int c0 = std::max(prod_lo[k + 1] - x_t, 0), c1 = std::min(prod_hi[k + 1] - x_t, r.g[k + 1].cols);
+                ts.bx_lo[t] = c1 > c0 ? c0 / PD_OW : 0; ts.bx_hi[t] = c1 > c0 ? cdiv(c1, PD_OW) : 0;
+                share = (double)(ts.bx_hi[t] - ts.bx_lo[t]) / nbx;
+            }
+            bytes += share * ((double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec));
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
         if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
@@ -1655,13 +1679,6 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     // either side.  Whatever else those blocks compute (and whatever they read outside need_k: levels left over from an earlier cycle)
     // reaches no pixel of the window - every input of a pixel of need_{k-1} lies in need_k by construction - so the window's pixels
     // are those of the whole mosaic, bit for bit, and a mosaic can be cut into column strips computed on different GPUs.
-    int need_lo[MAX_LEVELS], need_hi[MAX_LEVELS];
-    const bool windowed = b->win_x1 > b->win_x0;
-    need_lo[0] = windowed ? b->win_x0 : 0; need_hi[0] = windowed ? std::min(b->win_x1, b->fw) : d[0].cols;
-    for (int k = 1; k <= L; ++k) {
-        need_lo[k] = windowed ? std::max(need_lo[k - 1] / 2 - 1, 0) : 0;
-        need_hi[k] = windowed ? std::min((need_hi[k - 1] - 1) / 2 + 2, d[k].cols) : d[k].cols;
-    }
     for (int k = L; k >= 1; --k) {
         TileSet ts = base(k - 1);
         const int gx_all = cdiv(d[k].cols, WAVE);

@@ -369,6 +369,7 @@ struct TileDst {
     unsigned char* img; unsigned img_step;
     unsigned char* mask; unsigned mask_step;
     int w, h;
+    int bx0;        // first 64-column block of this launch (isx_warper_set_dst_columns), 0 = the whole tile
 };
 
 // The rows of a thread that did not qualify for the fast path (bit i of `slow`: the thread's four pixels of row row0 + i),
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     // left and right edge of the warped tile is a few dozen pixels wide, so with 256 x 1 waves every row's first and last wave crossed
     // it (tier 2); with 64 x 4 waves a quarter as many do.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int dx0 = (blockIdx.x * 16 + (lane & 15)) * 4;
+    const int dx0 = ((blockIdx.x + d.bx0) * 16 + (lane & 15)) * 4;
     // Row blocks are taken alternately from the top and from the bottom of the tile: the rows near the tile's upper and lower edge are
     // where waves cross the image border (tier 2 below, the occasional generic pixel) and live several times longer than interior
     // waves - dispatched first they overlap with the rest of the launch, dispatched last they were its tail.
@@ -856,11 +857,15 @@ struct isx_warper {
     std::vector<int> host_cand;
     float k[9], rinv[9];
     Proj proj;
+    int col0 = 0, col1 = 0;            // isx_warper_set_dst_columns: the warped tile's columns the next fused warps produce (0, 0 = all)
     // isx_warper_set_roi_cache: detectResultRoi is a pure function of (projection, source size); a fixed rig asks for the
     // same few again and again.  Opt-in: remembered results are returned without the scan and its host round trip.
-    struct RoiEntry { Proj proj; int sw, sh; int roi[4]; float mm[4]; };
+    struct RoiEntry { Proj proj; int sw, sh; int roi[4]; float mm[4]; float k[9], rinv[9]; };
     std::vector<RoiEntry> roi_cache;
     bool roi_cache_on = false;
+    // The spherical ROI is a scan of the source's border on the HOST (0.3 ms for an 8K tile): a pure function with no device work and
+    // no synchronisation to preserve, so its results are always remembered (per projection and source size, 32 entries).
+    std::vector<RoiEntry> sph_memo;
 };
 
 namespace {
@@ -951,6 +956,12 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     int* cand = (int*)((char*)w->scan.p + 64);
     if (w->kind == ISX_WARP_SPHERICAL) {
         ISX_CHECK_ARG(!sync_free, ISX_ERR_UNSUPPORTED, "planned warp: spherical ROI is computed on the host; use isx_warper_warp_with_mask");
+        for (const auto& e : w->sph_memo)
+            if (e.sw == sw && e.sh == sh && memcmp(&e.proj, &w->proj, sizeof(Proj)) == 0 && memcmp(e.k, w->k, sizeof(e.k)) == 0 && memcmp(e.rinv, w->rinv, sizeof(e.rinv)) == 0) {
+                std::copy(e.roi, e.roi + 4, roi);
+                if (mm) std::copy(e.mm, e.mm + 4, mm);
+                return ISX_OK;
+            }
         float tl_u = std::numeric_limits<float>::max(), tl_v = tl_u, br_u = -tl_u, br_v = -tl_u, u, v;
         auto upd = [&](float x, float y) {
             map_forward_host(w->proj, x, y, u, v);
@@ -977,6 +988,13 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         }
         if (mm) { mm[0] = tl_u; mm[1] = tl_v; mm[2] = br_u; mm[3] = br_v; }
         roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
+        if (w->sph_memo.size() >= 32) w->sph_memo.erase(w->sph_memo.begin());
+        isx_warper::RoiEntry e;
+        e.proj = w->proj; e.sw = sw; e.sh = sh;
+        std::copy(w->k, w->k + 9, e.k); std::copy(w->rinv, w->rinv + 9, e.rinv);
+        std::copy(roi, roi + 4, e.roi);
+        e.mm[0] = tl_u; e.mm[1] = tl_v; e.mm[2] = br_u; e.mm[3] = br_v;
+        w->sph_memo.push_back(e);
         return ISX_OK;
     }
     if (!sync_free && w->roi_cache_on)
@@ -1028,6 +1046,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     if (w->roi_cache_on) {
         if (w->roi_cache.size() >= 16) w->roi_cache.erase(w->roi_cache.begin());
         isx_warper::RoiEntry e;
+        memset(&e, 0, sizeof(e));
         e.proj = w->proj; e.sw = sw; e.sh = sh;
         std::copy(roi, roi + 4, e.roi);
         e.mm[0] = tl_uf; e.mm[1] = tl_vf; e.mm[2] = br_uf; e.mm[3] = br_vf;
@@ -1149,8 +1168,15 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_img_mask<O16, V>), grid4, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0, \
                    (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
         // the hot kernel: a tile whose mask is all 255 (W:213-214).  Same launch name: it is the same operation.
-        const dim3 gridt(cdiv(dw, 64), cdiv(dh, 16));
-        const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, dw, dh}};
+        // isx_warper_set_dst_columns: only the 64-column blocks that hold columns [col0, col1) of the warped tile are computed; the
+        // kernel's right crop is the range's end, its left end the block boundary at or below col0
+        int bx0 = 0, wcrop = dw;
+        if (w->col1 > w->col0 && !src_mask) {
+            bx0 = std::min(w->col0, dw - 1) / 64; wcrop = std::min(w->col1, dw);
+            bytes *= (double)(cdiv(wcrop, 64) - bx0) / cdiv(dw, 64);
+        }
+        const dim3 gridt(cdiv(wcrop, 64) - bx0, cdiv(dh, 16));
+        const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0}};
 #define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(256), 0, wta)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
         if (!src_mask) {
@@ -1227,6 +1253,14 @@ int isx_warper_set_roi_cache(isx_warper* w, int on) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_roi_cache: null warper");
     w->roi_cache_on = on != 0;
     if (!on) w->roi_cache.clear();
+    return ISX_OK;
+}
+
+int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_dst_columns: null warper");
+    ISX_CHECK_ARG((col0 == 0 && col1 == 0) || (col0 >= 0 && col1 > col0), ISX_ERR_INVALID, "isx_warper_set_dst_columns: columns [%d, %d)", col0, col1);
+    w->col0 = col0; w->col1 = col1;
     return ISX_OK;
 }
 

@@ -125,6 +125,51 @@ def tiles_for_window(corners, sizes, num_bands, x0, x1):
     return keep
 
 
+def _reflect(p, n):
+    """cv::borderInterpolate(p, n, BORDER_REFLECT) on an integer array"""
+    import numpy as np
+    p = np.array(p, dtype=np.int64)
+    if n == 1:
+        return np.zeros_like(p)
+    while True:
+        neg, big = p < 0, p >= n
+        if not (neg.any() or big.any()):
+            return p
+        p = np.where(neg, -p - 1, np.where(big, 2 * n - p - 1, p))
+
+
+def tile_columns_for_window(corners, sizes, num_bands, x0, x1):
+    """{tile: (col0, col1)}: the columns of each listed tile's WARPED image that the columns [x0, x1) of the result depend on (for
+    isx_warper_set_dst_columns).  The levels of the tile's Gaussian pyramid are needed on the columns blend() picks its blocks by
+    (window_needs), producing level k + 1 there takes level k on columns 2c - 2 .. 2c + 2, and level 0 is the tile behind
+    copyMakeBorder(BORDER_REFLECT): the columns of the padded rectangle map back into the tile by reflection."""
+    import numpy as np
+    c = np.asarray(corners).reshape(-1, 2)
+    s = np.asarray(sizes).reshape(-1, 2)
+    tl, br = c.min(0), (c + s).max(0)
+    w, h = int(br[0] - tl[0]), int(br[1] - tl[1])
+    L = min(num_bands, int(np.ceil(np.log(float(max(w, h))) / np.log(2.0))))
+    m = 1 << L
+    roi = (int(tl[0]), int(tl[1]), w + (m - w % m) % m, h + (m - h % m) % m)
+    cols = [roi[2]]
+    for k in range(L):
+        cols.append((cols[-1] + 1) // 2)
+    lo, hi = window_needs(L, x0, min(x1, w), cols)
+    plo, phi = lo[L], hi[L]
+    for k in range(L - 1, -1, -1):
+        plo, phi = max(min(lo[k], 2 * plo - 2), 0), min(max(hi[k], 2 * (phi - 1) + 3), cols[k])
+    out = {}
+    for i in tiles_for_window(corners, sizes, num_bands, x0, x1):
+        fx, _, fw, _ = feed_rect(roi, L, (int(c[i][0]), int(c[i][1])), (int(s[i][0]), int(s[i][1])))
+        a, b = max(plo, fx), min(phi, fx + fw)                      # level-0 columns of the padded rectangle (dst_roi coordinates)
+        if b <= a:
+            a, b = fx, fx + 1                                       # reached at a coarser level only: any one column keeps the call valid
+        left = int(c[i][0]) - roi[0] - fx                           # copyMakeBorder's left border
+        t = _reflect(np.arange(a, b) - fx - left, int(s[i][0]))
+        out[i] = (int(t.min()), int(t.max()) + 1)
+    return out
+
+
 def assemble_strips(gathered, rows, strip_cols, width, channels=3):
     """(world, rows * strip_cols * channels) strips as the all-gather leaves them -> the (rows, width, channels) panorama
     (a permuted view made contiguous: one device copy; consumers that can take strips use `gathered` as it is)."""

@@ -99,12 +99,15 @@ class PairStitcher:
         self.sizes = [(r[2] - r[0] + 1, r[3] - r[1] + 1) for r in self.rois]
         self.corners = [(r[0], r[1]) for r in self.rois]
         self.window = None if window is None else (int(window[0]), int(window[1]))
+        self.tile_cols = None
         self.active = list(range(len(imgs)))
         if self.window is not None:
             from . import mosaic
             self.active = mosaic.tiles_for_window(self.corners, self.sizes, num_bands, *self.window)
             if any(imgs[i] is None for i in self.active):
                 raise ValueError("window %s needs tiles %s" % (self.window, self.active))
+            # ... and of those tiles only the columns the strip depends on are warped in a step
+            self.tile_cols = mosaic.tile_columns_for_window(self.corners, self.sizes, num_bands, *self.window)
         # cv::Mat-style pitched buffers (row pitch a multiple of 64 B) so that the warp kernel can store dwords
         def pitched(h, row_bytes, shape, strides):
             pitch = (row_bytes + 63) // 64 * 64
@@ -149,7 +152,11 @@ class PairStitcher:
                 self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
         else:
             for i in self.active:
+                if self.tile_cols is not None:
+                    self.warper.set_dst_columns(*self.tile_cols[i])
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+            if self.tile_cols is not None:
+                self.warper.set_dst_columns(0, 0)
             if self.mark is None:
                 self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
@@ -192,8 +199,12 @@ class PairStitcher:
         (one stream synchronisation per tile), as cv::detail::RotationWarper::warp does."""
         cs = list(self.corners)   # the tiles this strip does not hold keep their planned corner
         for i in self.active:
+            if self.tile_cols is not None:
+                self.warper.set_dst_columns(*self.tile_cols[i])
             c, _, _ = self.warper.warp_with_mask(self.imgs[i], self.K, self.Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
             cs[i] = c
+        if self.tile_cols is not None:
+            self.warper.set_dst_columns(0, 0)
         self.blender.prepare(cs, self.sizes)
         for i in self.active:
             self.blender.feed_u8(self.warped[i], self.seam[i], cs[i])

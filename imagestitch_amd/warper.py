@@ -149,6 +149,10 @@ class RotationWarper:
         """Opt-in: remember detectResultRoi per (K, R, scale, source size); repeated calls skip the scan and its host sync."""
         check(self._lib.isx_warper_set_roi_cache(self._h, int(bool(on))))
 
+    def set_dst_columns(self, col0=0, col1=0):
+        """The fused warps that follow produce only the columns [col0, col1) of the warped tile (isx_warper_set_dst_columns)."""
+        check(self._lib.isx_warper_set_dst_columns(self._h, int(col0), int(col1)))
+
     def set_deferred_verify(self, on=True):
         check(self._lib.isx_warper_set_deferred_verify(self._h, int(bool(on))))
 

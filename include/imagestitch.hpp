@@ -147,15 +147,21 @@ public:
     void blend(Mat& dst, Mat& dst_mask) {   // W:313
         int w, h;
         check(isx_blender_result_size(h_, &w, &h));
+        if (win_x1_ > win_x0_) w = win_x1_ - win_x0_;   // setWindow: the mats hold the window's columns only
         if (dst.empty() || dst.rows() != h || dst.cols() != w) dst.create(h, w, ISX_16SC3);
         dst_mask.create(h, w, ISX_8UC1);
         check(isx_blender_blend(h_, dst.c(), dst_mask.c()));
     }
     void setStream(void* hip_stream) { check(isx_blender_set_stream(h_, hip_stream)); }
+    // Not in the reference (see imagestitch_hip.h): the deferred cycle (1: fed device mats stay valid until blend(); 2: feed() copies
+    // them, OpenCV's contract) and the column window of a panorama that is cut into strips across GPUs.
+    void setDeferredLevel0(int mode) { check(isx_blender_set_deferred_level0(h_, mode)); }
+    void setWindow(int x0, int x1) { check(isx_blender_set_window(h_, x0, x1)); win_x0_ = x0; win_x1_ = x1; }
     isx_blender* handle() { return h_; }
 protected:
     Blender() = default;
     isx_blender* h_ = nullptr;
+    int win_x0_ = 0, win_x1_ = 0;
 };
 
 class MultiBandBlender : public Blender {

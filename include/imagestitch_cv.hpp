@@ -96,6 +96,7 @@ public:
     void blend(cv::InputOutputArray dst, cv::InputOutputArray dst_mask) override {
         int w = 0, h = 0;
         isx::check(isx_blender_result_size(blender().handle(), &w, &h));
+        if (win_x1_ > win_x0_) w = win_x1_ - win_x0_;   // HipMultiBandBlender::setWindow: the strip's columns only
         dst.create(h, w, CV_16SC3);
         dst_mask.create(h, w, CV_8U);
         cv::Mat d = dst.getMat(), m = dst_mask.getMat();
@@ -104,6 +105,7 @@ public:
     }
 protected:
     virtual isx::Blender& blender() = 0;
+    int win_x0_ = 0, win_x1_ = 0;
 };
 
 class HipMultiBandBlender : public HipBlenderBase {             // Blender::createDefault(Blender::MULTI_BAND, false)  W:271
@@ -115,6 +117,9 @@ public:
     }
     int numBands() { return b_.numBands(); }
     void setNumBands(int val) { b_.setNumBands(val); }          // mb->setNumBands(4)  W:273
+    // not in OpenCV: blend() produces the result's columns [x0, x1) only (x0 a multiple of ISX_WINDOW_GRANULE) - one strip of a
+    // panorama that is cut across GPUs; feed only the tiles near the strip (isx_blender_set_window in imagestitch_hip.h)
+    void setWindow(int x0, int x1) { b_.setWindow(x0, x1); win_x0_ = x0; win_x1_ = x1; }
 protected:
     isx::Blender& blender() override { return b_; }
 private:

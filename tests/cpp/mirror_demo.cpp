@@ -84,6 +84,26 @@ int main(int argc, char** argv) {
         blender->blend(result, result_mask);                                            // W:313
         dump(argv[6], "result", result);
         dump(argv[6], "result_mask", result_mask);
+        // the same mosaic cut into two column strips (isx_blender_set_window): what two GPUs would each compute of ONE panorama
+        for (int strip = 0; strip < 2; ++strip) {
+            blender->prepare(corners, sizes);
+            blender->setDeferredLevel0(2);
+            blender->setWindow(strip * 3 * ISX_WINDOW_GRANULE, (strip + 1) * 3 * ISX_WINDOW_GRANULE);
+            for (int k = 0; k < num_images; ++k) {
+                isx::Mat img_s(images_warped[k].rows(), images_warped[k].cols(), ISX_16SC3);
+                for (int y = 0; y < img_s.rows(); ++y) {
+                    const unsigned char* s = images_warped[k].ptr<unsigned char>(y);
+                    short* d = img_s.ptr<short>(y);
+                    for (int x = 0; x < img_s.cols() * 3; ++x) d[x] = s[x];
+                }
+                blender->feed(img_s, masks_warped[k], corners[k]);
+            }
+            isx::Mat part, part_mask;
+            blender->blend(part, part_mask);
+            dump(argv[6], strip == 0 ? "strip0" : "strip1", part);
+            dump(argv[6], strip == 0 ? "stripmask0" : "stripmask1", part_mask);
+        }
+        blender->setWindow(0, 0);
         // error behaviour: feed after blend must throw like a CV_Assert would
         try { blender->feed(result, result_mask, isx::Point(0, 0)); printf("no-throw\n"); return 4; }
         catch (const isx::Exception& e) { printf("throws %d\n", e.code); }

@@ -64,6 +64,15 @@ def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path, demo):
     got = np.fromfile(str(tmp_path / "o_result.raw"), np.int16).reshape(r, c, 3)
     gm = np.fromfile(str(tmp_path / "o_result_mask.raw"), np.uint8).reshape(r, c)
     assert np.array_equal(got, od) and np.array_equal(gm, om)
+    if demo == "mirror_demo":     # the mosaic again as two column strips of 384 (Blender::setWindow): each holds its columns of the whole
+        assert c > 384
+        for k in range(2):
+            sr, sc, _ = info["strip%d" % k]
+            part = np.fromfile(str(tmp_path / ("o_strip%d.raw" % k)), np.int16).reshape(sr, sc, 3)
+            pm = np.fromfile(str(tmp_path / ("o_stripmask%d.raw" % k)), np.uint8).reshape(sr, sc)
+            x0, xe = 384 * k, min(384 * (k + 1), c)
+            assert (sr, sc) == (r, 384)
+            assert np.array_equal(part[:, :xe - x0], od[:, x0:xe]) and np.array_equal(pm[:, :xe - x0], om[:, x0:xe])
 
 
 def test_cpp_mirror_default_demo_stage(gpu, oracle, tmp_path):

@@ -54,6 +54,10 @@ def test_strips_equal_the_whole_blend(gpu, prec_name, bands):
             st = _stitcher(torch, imgs, K, Rs, bands, prec, window=(x0, x1))
             fewer += len(st.active) < N_TILES
             st.out.fill_(-7); st.out_mask.fill_(7)            # columns past the mosaic's edge must stay as they are
+            for i in st.active:                                # a step re-warps only the columns the strip depends on: whatever
+                st.warped[i].fill_(171)                        # else the tiles hold must not matter
+                c0, c1 = st.tile_cols[i]
+                assert 0 <= c0 < c1 <= st.sizes[i][0]
             out, mask = [t.cpu().numpy() for t in st.step()]
             out2 = st.step()[0].cpu().numpy()                  # the planned step replayed: same strip
             st.check_plan()
