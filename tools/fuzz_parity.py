@@ -260,8 +260,55 @@ def case_linear_pair(rng):
     assert np.array_equal(pano, opano, equal_nan=True), np.argwhere(pano != opano)[:5]
 
 
+def case_strip(rng):
+    """One column strip of a row of tiles (isx_blender_set_window) against the ORACLE's whole blend: random tiles, bands, precision,
+    input type and window; only the tiles mosaic.tiles_for_window lists are fed to the HIP blender."""
+    from imagestitch_amd import mosaic
+    n = int(rng.integers(1, 7))
+    sizes = [(int(rng.integers(40, 260)), int(rng.integers(8, 90))) for _ in range(n)]
+    x, corners = int(rng.integers(-50, 50)), []
+    for w, _ in sizes:
+        corners.append((x, int(rng.integers(-12, 12))))
+        x += int(rng.integers(max(w // 4, 1), w + 20))
+    bands, prec = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+    as_f32 = prec != 0 and bool(rng.integers(0, 2))
+    imgs, masks = [], []
+    for w, h in sizes:
+        imgs.append((rng.random((h, w, 3)) * 300 - 20).astype(np.float32) if as_f32 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        m = (rng.random((h, w)) > 0.15).astype(np.uint8) * 255
+        masks.append(m)
+    ob = O.MultiBand(bands, prec)
+    ob.prepare(corners, sizes)
+    for im, m, c in zip(imgs, masks, corners):
+        ob.feed(im if as_f32 else im.astype(np.int16), m, c)
+    out_f32 = prec != 0 and bool(rng.integers(0, 2))
+    od, om = ob.blend(out_f32)
+    fw = od.shape[1]
+    x0 = int(rng.integers(0, (fw - 1) // 128 + 1)) * 128
+    x1 = x0 + int(rng.integers(1, 4)) * 128 if rng.integers(0, 2) else x0 + int(rng.integers(1, 400))
+    act = mosaic.tiles_for_window(corners, sizes, bands, x0, x1)
+    mb = G.MultiBandBlender(False, bands, prec)
+    mb.set_deferred_level0(True)
+    mb.set_window(x0, x1)
+    mb.prepare(corners, sizes)
+    if not act:
+        return "skip"
+    as_u8 = bool(rng.integers(0, 2))      # one input type per cycle: a tile of another type ends the deferred cycle, and with it the window
+    for i in act:
+        if as_f32:
+            mb.feed(imgs[i], masks[i], corners[i])
+        elif as_u8:
+            mb.feed_u8(imgs[i], masks[i], corners[i])
+        else:
+            mb.feed(imgs[i].astype(np.int16), masks[i], corners[i])
+    d, m = mb.blend(out_f32=out_f32)
+    xe = min(x1, fw)
+    assert d.shape[1] == x1 - x0
+    assert np.array_equal(m[:, :xe - x0], om[:, x0:xe]) and np.array_equal(d[:, :xe - x0], od[:, x0:xe]), (n, bands, prec, x0, x1, act)
+
+
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair]
+         case_linear_pair, case_strip]
 
 
 def run(budget, seed0, verbose=True):
