@@ -158,11 +158,13 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
         for _ in range(2):
             ps.step_sync()
         torch.cuda.synchronize()
+        gc.collect(); gc.disable()      # as in the headline region: a generation-2 collection costs more than the whole loop
         t0 = time.perf_counter()
         for _ in range(steps):
             ps.step_sync()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        gc.enable()
         out["device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1)}
         seam_host = [m.cpu().numpy() for m in ps.seam]
         corners, sizes, shape_out = ps.corners, ps.sizes, tuple(ps.out.shape)
@@ -196,10 +198,12 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
                 blender.blend(res, res_mask)
             n_host = max(3, steps // 4)
             host_step()
+            gc.collect(); gc.disable()
             t0 = time.perf_counter()
             for _ in range(n_host):
                 host_step()
             dt = (time.perf_counter() - t0) / n_host
+            gc.enable()
             h2d = sum(a.nbytes for a in src) + sum(a.nbytes for a in wimg) + sum(a.nbytes for a in seam)
             d2h = sum(a.nbytes for a in wimg) + sum(a.nbytes for a in wmsk) + res.nbytes + res_mask.nbytes
             out["%s_%s" % (mem, pname)] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),

@@ -857,6 +857,7 @@ struct isx_warper {
     std::vector<int> host_cand;
     float k[9], rinv[9];
     Proj proj;
+    hipStream_t roi_stream = nullptr;  // the synchronous ROI scans' stream (roi_stream_of)
     int col0 = 0, col1 = 0;            // isx_warper_set_dst_columns: the warped tile's columns the next fused warps produce (0, 0 = all)
     // isx_warper_set_roi_cache: detectResultRoi is a pure function of (projection, source size); a fixed rig asks for the
     // same few again and again.  Opt-in: remembered results are returned without the scan and its host round trip.
@@ -943,8 +944,26 @@ int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
 
 // detectResultRoi.  Cylindrical: full scan on the GPU (W:72-81) + host refinement of u.
 // Spherical: OpenCV's detectResultRoiByBorder + pole tests — O(W+H) points, evaluated on the host.
+// The stream the synchronous ROI scans run on: one per device, shared by every warper on it (see flush_verify on why not one each).
+// detectResultRoi is a function of the projection and the source SIZE - it reads no image - so it need not queue behind whatever
+// the handle's stream still holds (the previous blend, typically): the host gets its corner after the scan alone, W:160 is kept,
+// and the strict call sequence stops being bound by one full GPU drain per warp.
+int roi_stream_of(isx_warper* w, hipStream_t* out) {
+    if (!w->roi_stream) {
+        static std::mutex mu;
+        static hipStream_t shared[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        const int d = w->device >= 0 && w->device < 64 ? w->device : 0;
+        if (!shared[d]) ISX_HIP(hipStreamCreateWithFlags(&shared[d], hipStreamNonBlocking));
+        w->roi_stream = shared[d];
+    }
+    *out = w->roi_stream;
+    return ISX_OK;
+}
+
 int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync_free, const int* planned) {
     hipStream_t st = w->stream;
+    if (w->kind != ISX_WARP_SPHERICAL && !sync_free) ISX_TRY(roi_stream_of(w, &st));
     size_t need = 64 + (size_t)CAND_CAP * 8;
     if (!w->scan.p) {   // keys armed once here; every consumer re-arms them (k_warp_img_mask / k_roi_rearm)
         ISX_TRY(w->scan.reserve(need));
