@@ -34,6 +34,24 @@ b config4_forcedist_single --force-dist --pairs 4 --gather single
 b config4_forcedist_chunk_isx --force-dist --pairs 4 --gather chunk --gather-backend isx
 b config5_ring8_8k --kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 5 --warmup 2
 b config5_8k_pair --kind spherical --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3
+# 4b. config 5 as ONE panorama in column strips: every rank's share at 2 / 4 / 8 ranks, each alone on this GPU (no gather)
+C5="--kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3"
+mkdir -p $O/strips
+for w in 2 4 8; do for r in $(seq 0 $((w-1))); do python bench.py $C5 --strip-of $r/$w 2>/dev/null | line > $O/strips/config5_strip_${r}_of_$w.json; done; done
+python - "$O" "$TAG" <<'PY'
+import json, sys
+O, TAG = sys.argv[1], sys.argv[2]
+whole = json.load(open("%s/%s_bench_config5_ring8_8k.json" % (O, TAG)))
+out = {"what": "BASELINE config 5 as ONE panorama cut into N column strips: the time of every rank's share, each measured alone on one MI355X with "
+               "`python bench.py <config 5 flags> --strip-of R/N` (no gather; a one-GPU box cannot run N ranks)",
+       "whole_on_one_gpu": {"ms_per_step": whole["ms_per_step"], "Mpix_s": whole["value"]}, "ranks": {}}
+for w in (2, 4, 8):
+    rs = [json.load(open("%s/strips/config5_strip_%d_of_%d.json" % (O, r, w))) for r in range(w)]
+    out["ranks"][str(w)] = {"ms_per_step": [r["ms_per_step"] for r in rs], "tiles": [r["config"]["tiles_this_rank"] for r in rs],
+                            "window": [r["config"]["window"] for r in rs], "panorama_cols": rs[0]["config"]["panorama_cols"],
+                            "compute_speedup_vs_one_gpu": round(whole["ms_per_step"] / max(r["ms_per_step"] for r in rs), 2)}
+json.dump(out, open("%s/%s_strips_config5.json" % (O, TAG), "w"), indent=1)
+PY
 # 5. fuzz soak
 python tools/fuzz_parity.py $FUZZ 11 $O/${TAG}_fuzz_${FUZZ}s_seed11.json > $O/fuzz.log 2>&1
 tail -3 $O/fuzz.log
