@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
 // read back by blend) never exists in HBM.  Operations and their order per pixel are those of the
 // eager path (0 + a == a exactly), so the results are identical.
 // ------------------------------------------------------------------------------------------------
-constexpr int DEF_MAX = 8;
+constexpr int DEF_MAX = 20;     // kernel arguments hold one TileSet: 20 tiles keep a launch's argument block below the 4 KB limit
 struct TileSet {                 // per-tile views of one pyramid level pair, indexed by the (uniform) tile id
     int n;
     Src0 s0[DEF_MAX];            // level-0 view (used where the fine / source level is level 0)
@@ -803,6 +803,8 @@ struct TileSet {                 // per-tile views of one pyramid level pair, in
     int x_tl[DEF_MAX], y_tl[DEF_MAX], w[DEF_MAX], h[DEF_MAX];   // tile rectangle at the FINE level, dst_roi_ coordinates
     int bx_lo[DEF_MAX], bx_hi[DEF_MAX];                          // k_pyr_down_multi: block columns of the tile's destination level to produce (column window)
 };
+
+static_assert(sizeof(TileSet) + 2 * sizeof(LevelBuf) + sizeof(OutMat) <= 4096, "k_collapse_gather's arguments exceed the kernel-argument limit");
 
 template <int M, int SK>
 __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {

@@ -214,7 +214,7 @@ int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask,
  * feed()/feed_u8() must stay valid and unmodified until blend() returns (OpenCV's feed() consumes
  * its inputs immediately — the reference clears the fed images before blend(), W:305-308 — so this
  * is not the default).  Host mats are staged in per-tile device buffers owned by the blender:
- * nothing changes for them.  At most 8 tiles of one type are deferred; beyond that, and when
+ * nothing changes for them.  At most 20 tiles of one type are deferred; beyond that, and when
  * isx_blender_debug_level is called, the recorded tiles are replayed through the eager path.
  * on = 2 keeps OpenCV's contract: feed() takes a private copy of every DEVICE mat it records (one device-to-device
  * pass on the handle's stream, 4 B/px for a CV_8UC3 tile + mask), so the caller may release or overwrite the fed

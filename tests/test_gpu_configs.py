@@ -102,7 +102,7 @@ def test_config3_sixteen_4k_pairs_as_graphs(gpu, oracle):
 
 def test_config5_ring_of_8_tiles_quarter_scale_against_oracle(gpu, oracle):
     """BASELINE config 5 at 1/4 scale: 8 x 1920x1080 tiles in ONE mosaic, spherical warp f = 1500, yaw step 0.55 rad,
-    7 bands, fp16 pyramid with fp32 accumulate — through the deferred cycle at its tile limit (DEF_MAX = 8), through the
+    7 bands, fp16 pyramid with fp32 accumulate — through the deferred cycle (8 of the at most 20 tiles it holds), through the
     copying deferred cycle and through the eager cycle; warps, masks and the blended mosaic bit-exact vs the oracle."""
     import torch
     from imagestitch_amd.pipeline import MosaicStitcher

@@ -93,6 +93,42 @@ def test_the_whole_blend_of_the_ring_equals_the_oracle(gpu):
     assert np.array_equal(full, ref) and np.array_equal(full_mask, ref_mask)
 
 
+def test_twelve_tile_ring_whole_and_strips(gpu):
+    """more tiles than round 1's deferred cycle held (8): the whole 12-tile mosaic equals the oracle's, every strip equals the whole"""
+    import torch
+    import imagestitch_amd as I
+    from imagestitch_amd import mosaic, synth
+    from imagestitch_amd.pipeline import MosaicStitcher
+    from oracle import capi as O
+    n, w, h, f, step = 12, 320, 180, 300.0, 0.45
+    K, Rs = synth.camera_ring(w, h, f, n, step)
+    imgs = [synth.make_tile(h, w, 500 + i) for i in range(n)]
+    dev = torch.device("cuda:0")
+    dimgs = [torch.from_numpy(im).to(dev) for im in imgs]
+    whole = MosaicStitcher(dimgs, K, Rs, f, "cylindrical", 4, I.PREC_I16, 0, None, "int16")
+    full, full_mask = [t.cpu().numpy() for t in whole.step()]
+    corners, warped, wmasks = [], [], []
+    for im, R in zip(imgs, Rs):
+        c, wi, _ = O.warp_u8(O.CYL, f, K, R, im, O.LINEAR, O.BORDER_REFLECT)
+        _, wm, _ = O.warp_u8(O.CYL, f, K, R, np.full((h, w), 255, np.uint8), O.NEAREST, O.BORDER_CONSTANT)
+        corners.append(c); warped.append(wi); wmasks.append(wm)
+    seam = synth.seam_masks(corners, wmasks)
+    mb = O.MultiBand(4, O.I16)
+    mb.prepare(corners, [(m.shape[1], m.shape[0]) for m in wmasks])
+    for wi, sm, c in zip(warped, seam, corners):
+        mb.feed(wi.astype(np.int16), sm, c)
+    ref, ref_mask = mb.blend(False)
+    assert np.array_equal(full, ref) and np.array_equal(full_mask, ref_mask)
+    fw, fh = whole.mosaic_size
+    windows, sw = mosaic.strip_windows(fw, 4)
+    for x0, x1 in windows:
+        st = MosaicStitcher(dimgs, K, Rs, f, "cylindrical", 4, I.PREC_I16, 0, None, "int16", window=(x0, x1))
+        assert len(st.active) < n
+        out = st.step()[0].cpu().numpy()
+        xe = min(x1, fw)
+        assert np.array_equal(out[:, :xe - x0], full[:, x0:xe])
+
+
 def test_a_strip_needs_only_its_neighbourhood(gpu):
     """tiles_for_window is tight enough to matter and safe: dropping a tile it lists changes the strip, and it never lists all 6."""
     import torch
