@@ -1298,7 +1298,7 @@ struct FeatherSet {
 
 template <int SK>
 __global__ __launch_bounds__(256) void k_feather_gather(FeatherSet fs, OutMat out) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = (blockIdx.x + out.bx0) * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= out.cols || y >= out.rows) return;
     Px<M_I16> d; d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f;
     for (int t = 0; t < fs.n; ++t) {
@@ -2214,8 +2214,8 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     const bool windowed = b->win_x1 > b->win_x0;
     const int out_cols = windowed ? b->win_x1 - b->win_x0 : b->fw;   // a window's mats hold its columns only
     if (windowed) {
-        ISX_CHECK_ARG(b->type == ISX_BLEND_MULTI_BAND && b->level0_pending, ISX_ERR_UNSUPPORTED,
-                      "blend: a column window needs the deferred MultiBandBlender cycle (isx_blender_set_deferred_level0) with every tile still recorded");
+        ISX_CHECK_ARG(b->type == ISX_BLEND_FEATHER ? !b->ftiles.empty() : b->level0_pending, ISX_ERR_UNSUPPORTED,
+                      "blend: a column window needs the deferred cycle (isx_blender_set_deferred_level0) with every tile still recorded");
         ISX_CHECK_ARG(b->win_x0 < b->fw, ISX_ERR_SIZE, "blend: the window starts at column %d, the result is %d wide", b->win_x0, b->fw);
     }
     ISX_CHECK_ARG(dst->rows == b->fh && dst->cols == out_cols, ISX_ERR_SIZE, "blend: dst is %dx%d, result%s is %dx%d", dst->cols, dst->rows,
@@ -2253,10 +2253,14 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend
         dim3 grid(cdiv(b->dst[0].cols, 64), cdiv(b->dst[0].rows, 4));
         if (!b->ftiles.empty()) {   // deferred cycle: gather over the recorded tiles
+            if (windowed) {         // a pixel of the result depends on the tiles that cover it and on nothing else: the window's block columns
+                o.bx0 = b->win_x0 / 64;
+                grid.x = cdiv(o.cols, 64) - o.bx0;
+            }
             FeatherSet fs;
             memset(&fs, 0, sizeof(fs));
             fs.n = (int)b->ftiles.size();
-            double bytes = (double)b->fw * b->fh * 7.0;
+            double bytes = (double)(windowed ? o.cols - b->win_x0 : b->fw) * b->fh * 7.0;
             for (int t = 0; t < fs.n; ++t) {
                 const auto& r = b->ftiles[t];
                 fs.img[t] = r.img; fs.istep[t] = r.istep; fs.wgt[t] = r.wgt; fs.wpitch[t] = r.wpitch;

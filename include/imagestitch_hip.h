@@ -231,12 +231,13 @@ int isx_blender_set_overlap(isx_blender* b, int on);
 int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level);
 /* Column window (one panorama of many tiles cut into column strips, a strip per GPU, no exchange before the final
  * gather).  Nothing in the reference corresponds to it.  With a window [x0, x1) set - columns of the result, 0 = the left edge of
- * dst_roi, x0 a multiple of ISX_WINDOW_GRANULE - blend() of a deferred MultiBandBlender cycle computes and writes those columns
+ * dst_roi, x0 a multiple of ISX_WINDOW_GRANULE - blend() of a deferred cycle (MultiBandBlender or FeatherBlender) computes and writes those columns
  * only, into mats that are x1 - x0 wide (columns past the result's right edge, when x1 exceeds its width, are not touched); every
  * pixel equals the same pixel of the whole blend, bit for bit.  prepare() still gets EVERY tile's corner and size (dst_roi is the
  * whole panorama's); only the tiles that can reach the window need to be fed: those whose fed rectangle - the tile widened by the
  * gap 3 * 2^num_bands on either side, as MultiBandBlender::feed does - comes within 2^(num_bands + 1) columns of the window
- * (imagestitch_amd/mosaic.py: tiles_for_window).  The window stays set until changed; (0, 0) removes it.                  */
+ * (imagestitch_amd/mosaic.py: tiles_for_window; for the FeatherBlender simply the tiles that overlap the window).  The window stays
+ * set until changed; (0, 0) removes it.                                                                                       */
 #define ISX_WINDOW_GRANULE 128
 int isx_blender_set_window(isx_blender* b, int x0, int x1);
 

@@ -210,6 +210,20 @@ def test_window_error_contract(gpu):
         b.blend()
 
 
+def test_feather_and_multiband_strip_fuzz_slice(gpu):
+    """a few hundred random strips of random tile rows against the ORACLE's whole blends (tools/fuzz_parity.py: case_strip,
+    case_strip_feather), every precision and input type"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity as F
+    F.G.load()
+    ran = 0
+    for n in range(200):
+        ran += F.case_strip(np.random.default_rng(4242000 + n)) != "skip"
+        ran += F.case_strip_feather(np.random.default_rng(4343000 + n)) != "skip"
+    assert ran > 300
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -307,8 +307,48 @@ def case_strip(rng):
     assert np.array_equal(m[:, :xe - x0], om[:, x0:xe]) and np.array_equal(d[:, :xe - x0], od[:, x0:xe]), (n, bands, prec, x0, x1, act)
 
 
+def case_strip_feather(rng):
+    """One column strip of a FeatherBlender mosaic against the oracle's whole blend; only the tiles that overlap the strip are fed."""
+    n = int(rng.integers(1, 7))
+    sizes = [(int(rng.integers(30, 260)), int(rng.integers(8, 90))) for _ in range(n)]
+    x, corners = int(rng.integers(-50, 50)), []
+    for w, _ in sizes:
+        corners.append((x, int(rng.integers(-12, 12))))
+        x += int(rng.integers(max(w // 4, 1), w + 20))
+    sharp = float(rng.choice([0.02, 0.1, 0.5]))
+    u8 = bool(rng.integers(0, 2))
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if u8 else rng.integers(-300, 600, (h, w, 3)).astype(np.int16) for w, h in sizes]
+    masks = []
+    for w, h in sizes:
+        m = np.full((h, w), 255, np.uint8)
+        m[rng.random((h, w)) < rng.choice([0.0, 0.002, 0.3])] = 0
+        masks.append(m)
+    ob = O.Feather(sharp)
+    ob.prepare(corners, sizes)
+    for im, m, c in zip(imgs, masks, corners):
+        ob.feed(im.astype(np.int16), m, c)
+    od, om = ob.blend()
+    fw = od.shape[1]
+    x0 = int(rng.integers(0, (fw - 1) // 128 + 1)) * 128
+    x1 = x0 + int(rng.integers(1, 400))
+    rx = min(c[0] for c in corners)
+    act = [i for i in range(n) if corners[i][0] - rx < x1 and corners[i][0] - rx + sizes[i][0] > x0]
+    if not act:
+        return "skip"
+    fb = G.FeatherBlender(False, sharp)
+    fb.set_deferred_level0(True)
+    fb.set_window(x0, x1)
+    fb.prepare(corners, sizes)
+    for i in act:
+        (fb.feed_u8 if u8 else fb.feed)(imgs[i], masks[i], corners[i])
+    d, m = fb.blend()
+    xe = min(x1, fw)
+    assert d.shape[1] == x1 - x0
+    assert np.array_equal(m[:, :xe - x0], om[:, x0:xe]) and np.array_equal(d[:, :xe - x0], od[:, x0:xe]), (n, x0, x1, act)
+
+
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair, case_strip]
+         case_linear_pair, case_strip, case_strip_feather]
 
 
 def run(budget, seed0, verbose=True):
