@@ -651,6 +651,11 @@ struct OutMat {  // the caller's blend() outputs
     int rows, cols;  // dst_roi_final_ size
     int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
     int bx0;         // column window (isx_blender_set_window): first block column of this launch, 0 without a window
+    // XCD-aware block order of the collapse steps (grp > 0: a 1-D launch): workgroups are handed to the 8 XCDs round robin, so block
+    // L runs on XCD L % 8.  The blocks of one XCD walk groups of `grp` block rows column by column - vertical neighbours, which share
+    // two of their six staged coarse rows, are dispatched back to back on the same XCD and meet in its L2 - and the groups are dealt
+    // to the XCDs round robin (group g of XCD k = block rows (8 g + k) grp ...), which keeps the XCDs' shares of the mosaic even.
+    int grp, gx, gy;
 };
 
 // saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
@@ -873,7 +878,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     constexpr int NB = DMA_T ? 2 * G + 1 : G + 1;     // the last buffer is out_k's
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cx0 = (blockIdx.x + out.bx0) * WAVE, cy0 = blockIdx.y * UP_TY;
+    int bxi = blockIdx.x, byi = blockIdx.y;
+    if (out.grp > 0) {
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (unsigned)(out.grp * out.gx);
+        const unsigned g = j / per, r = j - g * per;
+        bxi = (int)(r / (unsigned)out.grp);
+        byi = (int)((g * 8u + xcd) * (unsigned)out.grp + (r - (unsigned)bxi * (unsigned)out.grp));
+        if (byi >= out.gy) return;
+    }
+    const int cx0 = (bxi + out.bx0) * WAVE, cy0 = byi * UP_TY;
     PT_DECL;
     // float work types: the accumulators and every stencil operation on (b, g) / (r, -) register pairs (packed fp32, see pyr_up_2x2_pk)
     constexpr bool PK = M != M_I16;
@@ -1697,6 +1710,15 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
         OutMat o = out;
         o.bx0 = bx_lo;
+        // last step: XCD-aware block order in groups of 2 block rows (see OutMat).  Measured on the 4K pair (tools/measure_traffic.py,
+        // profiles/round2_xcd_order.txt): fabric traffic per launch 383 MB in plain row-major order, 282 MB with groups of 2, 268 with 4,
+        // 262 with 8 (algorithmic: 229); launch time 67.1 / 65.7 / 68.3 / 73.5 us - larger groups leave the XCDs uneven shares.
+        constexpr int XCD_GRP = 2;
+        if (k == 1 && (int)grid.y >= 8 * XCD_GRP) {
+            o.grp = XCD_GRP; o.gx = (int)grid.x; o.gy = (int)grid.y;
+            const int groups = cdiv((int)grid.y, XCD_GRP), per_xcd = cdiv(groups, 8);
+            grid = dim3((unsigned)(8 * per_xcd * XCD_GRP) * grid.x, 1);
+        }
         if (k == 1) {
             bytes = bytes * frac + (double)out.rows * (need_hi[0] - need_lo[0]) * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));   // result + mask
             if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
@@ -2238,7 +2260,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
-    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0;
+    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0;
     if (windowed) {
         // the kernels keep addressing the mosaic's columns: the mats' origins move left by the window's first column (a multiple of
         // ISX_WINDOW_GRANULE, so every alignment is kept and a block of the last step starts exactly there), the right crop is the
