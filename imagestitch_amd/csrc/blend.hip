@@ -651,11 +651,7 @@ struct OutMat {  // the caller's blend() outputs
     int rows, cols;  // dst_roi_final_ size
     int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
     int bx0;         // column window (isx_blender_set_window): first block column of this launch, 0 without a window
-    // XCD-aware block order of the collapse steps (grp > 0: a 1-D launch): workgroups are handed to the 8 XCDs round robin, so block
-    // L runs on XCD L % 8.  The blocks of one XCD walk groups of `grp` block rows column by column - vertical neighbours, which share
-    // two of their six staged coarse rows, are dispatched back to back on the same XCD and meet in its L2 - and the groups are dealt
-    // to the XCDs round robin (group g of XCD k = block rows (8 g + k) grp ...), which keeps the XCDs' shares of the mosaic even.
-    int grp, gx, gy;
+    int grp, gx, gy; // grp > 0: a 1-D launch in the XCD-aware block order of isx_device.hpp (xcd_block) over gx x gy blocks
 };
 
 // saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
@@ -879,13 +875,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 :
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int bxi = blockIdx.x, byi = blockIdx.y;
-    if (out.grp > 0) {
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per = (unsigned)(out.grp * out.gx);
-        const unsigned g = j / per, r = j - g * per;
-        bxi = (int)(r / (unsigned)out.grp);
-        byi = (int)((g * 8u + xcd) * (unsigned)out.grp + (r - (unsigned)bxi * (unsigned)out.grp));
-        if (byi >= out.gy) return;
-    }
+    if (out.grp > 0 && !xcd_block(blockIdx.x, out.grp, out.gx, out.gy, bxi, byi)) return;
     const int cx0 = (bxi + out.bx0) * WAVE, cy0 = byi * UP_TY;
     PT_DECL;
     // float work types: the accumulators and every stencil operation on (b, g) / (r, -) register pairs (packed fp32, see pyr_up_2x2_pk)
@@ -1716,8 +1706,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         constexpr int XCD_GRP = 2;
         if (k == 1 && (int)grid.y >= 8 * XCD_GRP) {
             o.grp = XCD_GRP; o.gx = (int)grid.x; o.gy = (int)grid.y;
-            const int groups = cdiv((int)grid.y, XCD_GRP), per_xcd = cdiv(groups, 8);
-            grid = dim3((unsigned)(8 * per_xcd * XCD_GRP) * grid.x, 1);
+            grid = dim3(xcd_grid_blocks(XCD_GRP, o.gx, o.gy), 1);
         }
         if (k == 1) {
             bytes = bytes * frac + (double)out.rows * (need_hi[0] - need_lo[0]) * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));   // result + mask

@@ -71,6 +71,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
 
+// XCD-aware block order for 2-D stencil / gather grids.  MI355X hands the workgroups of a launch to its 8 XCDs round robin (block L of
+// a 1-D launch runs on XCD L % 8), and each XCD has its own L2: in a plain row-major grid neighbouring blocks - which share halo rows,
+// or the cache lines their row segments straddle - always sit on different XCDs, and every XCD fetches the shared lines from the
+// fabric itself.  Here the blocks of one XCD walk groups of `grp` block rows column by column (vertical and horizontal neighbours are
+// dispatched back to back on the same XCD and meet in its L2), and the groups are dealt to the XCDs round robin, which keeps their
+// shares of the image even.  Launch xcd_grid_blocks(grp, gx, gy) blocks; false = a padding block.
+__device__ __forceinline__ bool xcd_block(unsigned L, int grp, int gx, int gy, int& bx, int& by) {
+    const unsigned xcd = L & 7u, j = L >> 3, per = (unsigned)(grp * gx);
+    const unsigned g = j / per, r = j - g * per;
+    bx = (int)(r / (unsigned)grp);
+    by = (int)((g * 8u + xcd) * (unsigned)grp + (r - (unsigned)bx * (unsigned)grp));
+    return by < gy;
+}
+
 // IEEE division a / z by the hardware's own recurrence, written out so that several numerators share one reciprocal and two of them
 // ride in one packed FMA:  r1 = r0 + r0 (1 - z r0);  q0 = a r1;  q1 = q0 + r1 (a - z q0);  q = q1 + r1 (a - z q1)   with r0 = v_rcp_f32(z).
 // This is what v_div_scale / v_rcp / v_fma x 5 / v_div_fmas / v_div_fixup compute whenever v_div_scale does not rescale: z and
