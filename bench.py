@@ -29,20 +29,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def measured_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of tools/measure_traffic.py (collected in
-    their own runs, as the counters require); None when no matching measurement is committed."""
+def measured_traffic(kernel, args, live=True):
+    """HBM (fabric) bytes per launch of `kernel` from rocprofv3's PMC counters, (2 x FETCH_SIZE + WRITE_SIZE) KiB with FETCH and WRITE in
+    separate passes (tools/measure_traffic.py; the factor 2 is calibrated for the kernels' access shapes, profiles/round2_fetch_calib.txt).
+    live: collected NOW, by two short child runs of this command under `rocprofv3 --kernel-trace --pmc X` (about 30 s); when rocprofv3 is
+    missing or a pass fails, the committed measurement of the same command (profiles/round2_traffic.json) is returned instead.
+    Returns (bytes or None, source)."""
+    import shutil
+    import subprocess
+    import tempfile
+    extra = ["--precision", args.precision, "--bands", str(args.bands), "--width", str(args.width), "--height", str(args.height),
+             "--focal", str(args.focal), "--kind", args.kind, "--tiles", str(args.tiles), "--cycle", args.cycle]
+    if live and shutil.which("rocprofv3"):
+        try:
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                out = os.path.join(td, "traffic.json")
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "measure_traffic.py"), out, "--"] + extra, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300)
+                d = json.load(open(out))
+            k = d["kernels"][kernel]
+            return k["traffic_bytes"], ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate child passes of this "
+                                        "command (tools/measure_traffic.py), (2 x %.0f + %.0f) KiB per launch" % (k["FETCH_SIZE_KiB"], k["WRITE_SIZE_KiB"]))
+        except Exception:
+            pass
     try:
         path = os.path.join(ROOT, "profiles", "round2_traffic.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "round1_traffic.json")
         d = json.load(open(path))
-        want = ["--precision", args.precision, "--bands", str(args.bands)]
-        if d.get("bench_args", []) not in ([], want) and (args.precision != "f32" or args.bands != 5):
-            return None
-        return d["kernels"][kernel]["traffic_bytes"]
+        if d.get("bench_args", []) != [] or args.precision != "f32" or args.bands != 5 or args.tiles != 2 or args.width != 3840 or args.kind != "cylindrical":
+            return None, "no PMC measurement of this command"
+        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round2_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
+                                                      "rocprofv3 was not usable in this run)")
     except Exception:
-        return None
+        return None, "no PMC measurement of this command"
 
 
 def cpu_pair_seconds(width, height, focal, bands, precision, kind="cylindrical", tiles=2, yaw=0.36):
@@ -231,6 +249,8 @@ def main():
     ap.add_argument("--kind", default="cylindrical", choices=["cylindrical", "spherical"],
                     help="spherical (BASELINE config 5) implies --sync-roi: its ROI is a host-side border scan, there is no planned variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not collect roofline.traffic now (two child runs under rocprofv3 --pmc, ~30 s); report the committed measurement")
     ap.add_argument("--graph", action="store_true", help="capture each pair's planned step into a hipGraph and replay it (BASELINE config 3)")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the pairs of a step are spread over (default: 1 for one pair, min(pairs, 4) otherwise): independent pairs on "
@@ -529,9 +549,13 @@ def main():
             avg_ms = e["ms"] / e["launches"]
             bytes_per_launch = e["alg_bytes"] / e["launches"]
             ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            # collected live only in the full default line (what the driver runs), never inside a run that is itself being profiled
+            profiled = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+            live_ok = (world == 1 and args.pairs == 1 and not args.graph and not args.no_live_traffic and not args.no_dropin
+                       and not args.no_cpu_baseline and not profiled)
+            traffic, traffic_source = measured_traffic(dominant, args, live=live_ok)
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dominant, args),
-                    "traffic_source": "profiles/round2_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command (tools/measure_traffic.py), (2 x FETCH + WRITE) KiB per launch",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 5),
                     "alg_bytes_per_launch": int(bytes_per_launch), "launches": e["launches"], "bracketed_every": SAMPLE}
         pair_ms = dt / args.steps / args.pairs * 1e3

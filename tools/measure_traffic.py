@@ -46,10 +46,10 @@ def launch_name(kname, full):
 
 
 def run_pass(counter, extra):
-    d = tempfile.mkdtemp(prefix="isx_pmc_", dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+    d = tempfile.mkdtemp(prefix="isx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-dropin"] + extra
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-dropin", "--no-live-traffic"] + extra
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -57,6 +57,8 @@ def run_pass(counter, extra):
             k = short(r["Kernel_Name"])
             if k and r["Counter_Name"] == counter:
                 acc[launch_name(k, r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
