@@ -688,12 +688,17 @@ __device__ __forceinline__ void forward_proxy(const Proj& p, float x, float y, f
 // keys[0..3] = min d, min q, max d, max q (as fkey).  One block scans a band of ROI_ROWS rows, reduces
 // through shuffles + LDS and touches the four global keys only when it improves them (520 K contended
 // atomics cost 3 ms on this part; a few hundred cost nothing).
-constexpr int ROI_ROWS = 128;    // rows per block of k_roi_scan (few long-lived waves: see DESIGN.md §6)
+// rows: rows per block.  ROI_ROWS for the verification scans of planned warps, which run on a side stream under the step's own kernels
+// (few long-lived waves disturb those least: DESIGN.md §6); SYNC_ROWS for the synchronous form, where the host waits for the result
+// (eight times the waves: 15 -> 6 us for a 4K source).  blk (optional): every block's own four extrema, which let the candidate pass
+// skip the blocks that cannot hold a candidate.
+constexpr int ROI_ROWS = 128;
+constexpr int SYNC_ROWS = 32;
 constexpr int CAND_ROWS = 16;    // rows per block of k_roi_candidates
-__global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsigned* keys) {
+__global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsigned* keys, int rows, float4* blk) {
     __shared__ float red[4][4];
     float tl_u = 3.402823466e+38f, tl_v = 3.402823466e+38f, br_u = -3.402823466e+38f, br_v = -3.402823466e+38f;
-    const int y0 = blockIdx.y * ROI_ROWS, y1 = min(y0 + ROI_ROWS, sh);
+    const int y0 = blockIdx.y * rows, y1 = min(y0 + rows, sh);
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x < sw) {
 #pragma unroll 4
@@ -712,7 +717,10 @@ __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsign
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][wv] = tl_u; red[1][wv] = tl_v; red[2][wv] = br_u; red[3][wv] = br_v; }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (blk != nullptr && threadIdx.x == 0)
+        blk[blockIdx.y * gridDim.x + blockIdx.x] = make_float4(fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3])), fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3])),
+                                                               fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3])), fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3])));
+    if (keys != nullptr && threadIdx.x < 4) {     // (same-address atomics serialise at the memory side: affordable from a few hundred blocks only)
         const int k = threadIdx.x;
         float a = red[k][0], b = red[k][1], c = red[k][2], d = red[k][3];
         if (k < 2) {
@@ -727,13 +735,35 @@ __global__ __launch_bounds__(256) void k_roi_scan(Proj p, int sw, int sh, unsign
 
 // second pass of the synchronous path: every pixel whose stand-in is within the tolerance of one of the
 // four extrema; the host re-evaluates exactly those with mapForward and its own libm
-__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, const unsigned* keys, int* cand_xy, int cap, int* count) {
-    const float dmin = fkey_inv(keys[0]), qmin = fkey_inv(keys[1]), dmax = fkey_inv(keys[2]), qmax = fkey_inv(keys[3]);
+// The scan's grid in x, CAND_ROWS rows per block in y (finer than the scan's, so that the few blocks that do hold candidates are
+// short).  Every block first reduces blk (a few hundred float4, L2-resident) to the four global
+// extrema - no atomics on shared keys, which serialise at the memory side when thousands of blocks issue them - and then holds a
+// candidate exactly when one of its OWN extrema is within the tolerance of the global one (the stand-ins are recomputed here by the
+// same instructions), so all but a handful of blocks leave right away.
+__global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, int* cand_xy, int cap, int* count, int rows, const float4* blk, int scan_rows, int scan_gy) {
+    __shared__ float red[4][4];
+    float dmin = 3.402823466e+38f, qmin = 3.402823466e+38f, dmax = -3.402823466e+38f, qmax = -3.402823466e+38f;
+    const int nblk = gridDim.x * scan_gy;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        const float4 b = blk[i];
+        dmin = fminf(dmin, b.x); qmin = fminf(qmin, b.y); dmax = fmaxf(dmax, b.z); qmax = fmaxf(qmax, b.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = fminf(dmin, __shfl_xor(dmin, o)); qmin = fminf(qmin, __shfl_xor(qmin, o));
+        dmax = fmaxf(dmax, __shfl_xor(dmax, o)); qmax = fmaxf(qmax, __shfl_xor(qmax, o));
+    }
+    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; red[0][wv] = dmin; red[1][wv] = qmin; red[2][wv] = dmax; red[3][wv] = qmax; }
+    __syncthreads();
+    dmin = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3])); qmin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    dmax = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3])); qmax = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
     // tolerances that cover the few-ulp error of v_rcp / v_rsq and of the host's own atan2f many times over (computed here so that
-    // the host needs no look at the keys between the two kernels: one round trip per detectResultRoi)
+    // the host needs no look at the extrema between the two kernels: one round trip per detectResultRoi)
     const float tol_d = 7.62939453125e-06f;                                   // 2^-17 of a (-2, 2] range
     const float tol_q = 4e-6f * fmaxf(fabsf(qmin), fabsf(qmax)) + 1e-9f;
-    const int y0 = blockIdx.y * CAND_ROWS, y1 = min(y0 + CAND_ROWS, sh);
+    const float4 mine = blk[(blockIdx.y * rows / scan_rows) * gridDim.x + blockIdx.x];      // the scan block this (finer) block lies in
+    if (!(mine.x <= dmin + tol_d || mine.z >= dmax - tol_d || mine.y <= qmin + tol_q || mine.w >= qmax - tol_q)) return;
+    const int y0 = blockIdx.y * rows, y1 = min(y0 + rows, sh);
     for (int y = y0; y < y1; ++y)
         for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256) {
             float d, q;
@@ -841,6 +871,7 @@ struct isx_warper {
     hipEvent_t ev_warp = nullptr;   // recorded on the main stream after a planned warp: its scan starts behind it
     hipEvent_t ev_scan = nullptr;   // recorded on the side stream after the check: isx_warper_join waits on it
     DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
+    DevBuf scan_blk;         // the synchronous scan's per-block extrema (k_roi_scan -> k_roi_candidates)
     void* pin = nullptr;     // pinned host landing zone of detectResultRoi's {keys, count, first candidates}
     // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
     // queued scans behind the main stream's position AT THAT CALL (e.g. after the last warp of a step, so
@@ -922,7 +953,7 @@ int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
     unsigned* sk = (unsigned*)w->scan_side.p;
     for (const isx_warper::Pending& pd : w->pending) {
         dim3 sgrid(cdiv(pd.sw, 256), cdiv(pd.sh, ROI_ROWS));   // ~8 K waves at 4K: one full-occupancy round
-        ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, pd.proj, pd.sw, pd.sh, sk);
+        ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, pd.proj, pd.sw, pd.sh, sk, ROI_ROWS, (float4*)nullptr);
         RoiBounds rb;
         for (int k = 0; k < 4; ++k) {
             double lo, hi;
@@ -1033,15 +1064,18 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
     // previous consumer); the mismatch counter keys[5] is sticky
-    dim3 grid(cdiv(sw, 256), cdiv(sh, ROI_ROWS));
-    double px = (double)sw * sh;
-    ISX_LAUNCH("roi_scan", px * 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, keys);
+    dim3 grid(cdiv(sw, 256), cdiv(sh, SYNC_ROWS));
+    ISX_TRY(w->scan_blk.reserve((size_t)grid.x * grid.y * sizeof(float4)));
+    float4* blk = (float4*)w->scan_blk.p;
+    ISX_LAUNCH("roi_scan", 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, (unsigned*)nullptr, SYNC_ROWS, blk);
     // The scan ranked the pixels by the stand-ins (d, q).  Collect every pixel whose stand-in is within
     // a tolerance of one of the four extrema and evaluate mapForward on exactly those with the host's
     // libm: the result is what the reference code computes on this host.  Scan, candidate pass, the copy of
     // {count, first candidates} into pinned memory and the re-arming of the keys are enqueued back to back:
     // ONE stream synchronisation per detectResultRoi (the corner must reach the host, W:148-150,160).
-    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(cdiv(sw, 256), cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, keys, cand, CAND_CAP, count);
+    static_assert(SYNC_ROWS % CAND_ROWS == 0, "a candidate block lies inside one scan block");
+    ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(grid.x, cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, cand, CAND_CAP, count, CAND_ROWS,
+               (const float4*)blk, SYNC_ROWS, (int)grid.y);
     if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
     ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
     ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
