@@ -855,7 +855,7 @@ __device__ unsigned long long g_phase[1024][12];
 #define PT_FLUSH do { } while (0)
 #endif
 template <int M, int SK, bool FINE0, bool TOP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? 4 : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     using WT = typename WorkT<M>::t;
     // Tiles are taken G at a time: their coarse tiles (and, in the last round, that of out_k) are staged in ONE phase —
     // every global load of the round in flight together, the fine-level pixels included, one barrier pair per round
