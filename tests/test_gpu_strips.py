@@ -266,3 +266,21 @@ def test_world2_strips_of_one_panorama_assemble_it(gpu):
     ret = mp.Manager().dict()
     mp.spawn(_worker_strips, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_example_stitch_strips_three_ranks(gpu, tmp_path):
+    """examples/stitch_strips.py under torch.distributed.run: 3 ranks share the one GPU (gloo), rank 0 checks the assembled panorama
+    against the whole blend and writes it"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "pano.bmp")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "examples", "stitch_strips.py"), "--backend", "gloo", "--check",
+                        "--tiles", "6", "--width", "960", "--height", "540", "--focal", "750", "--out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "strips == whole blend: True" in r.stdout
+    import imagestitch_amd as I
+    pano = I.imread(out)
+    assert pano.shape[2] == 3 and pano.shape[1] > 3 * 128
