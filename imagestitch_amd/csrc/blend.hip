@@ -700,14 +700,17 @@ __device__ __forceinline__ void write_final(const OutMat& o, int x, int y, const
 
 // two horizontally adjacent result pixels (x even): CV_16SC3 = 12 contiguous bytes -> three dword
 // stores when the row is 4-byte aligned (OutMat::vec), mask = one 16-bit store
-template <int M, bool BOUNDED = false>
+// ALLIN: the caller has established for the whole wave (one ballot) that the vector path applies and both pixels are inside
+template <int M, bool BOUNDED = false, bool ALLIN = false>
 __device__ __forceinline__ void write_final_pair(const OutMat& o, int x, int y, const Px<M>& d0, const Px<M>& d1) {
-    if (!o.vec || o.img_f32 || x + 1 >= o.cols) {
-        write_final<M, BOUNDED>(o, x, y, d0);
-        write_final<M, BOUNDED>(o, x + 1, y, d1);
-        return;
+    if constexpr (!ALLIN) {
+        if (!o.vec || o.img_f32 || x + 1 >= o.cols) {
+            write_final<M, BOUNDED>(o, x, y, d0);
+            write_final<M, BOUNDED>(o, x + 1, y, d1);
+            return;
+        }
+        if (y >= o.rows) return;
     }
-    if (y >= o.rows) return;
     const bool on0 = d0.w > WEIGHT_EPS, on1 = d1.w > WEIGHT_EPS;
     unsigned* q = (unsigned*)(o.img + (__umul24((unsigned)y, (unsigned)o.img_step) + (unsigned)x * 6u));
     if constexpr (BOUNDED && M != M_I16) {
@@ -950,9 +953,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
             }
         }
         PT(t0 == 0 ? 1 : 5);    // coarse tiles issued
+        // Wave-level tier (FINE0, CV_8UC3 tiles): when EVERY lane of the wave owns pixels of the tile and both of its rows' windows lie
+        // inside the tile's buffer - true for all waves but those on a tile's rim - the wave takes a path without a single per-lane
+        // branch: the per-pixel form below spends as many scalar instructions on exec-mask bookkeeping (343 per wave against 547
+        // vector ones, profiles/round2_final_kernel_sq.txt) as the arithmetic is worth.
+        bool wfast[G];
+#pragma unroll
+        for (int s = 0; s < G; ++s) {
+            wfast[s] = false;
+            if constexpr (FINE0 && SK == SK_U8) {
+                if (touch[s]) {
+                    const Src0& q = ts.s0[t0 + s];
+                    const int lcx = lx0[s] + lane, lcy = ly0[s] + wv, xr = 2 * lcx - q.left;
+                    bool ok = mine[s] & (xr >= 0) & (xr + 1 < q.cols);
+                    unsigned io[2], mo[2];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int yr = 2 * lcy + dy - q.top;
+                        io[dy] = __umul24((unsigned)yr, (unsigned)q.img_step) + __umul24((unsigned)xr, 3u) + q.imis;
+                        mo[dy] = __umul24((unsigned)yr, (unsigned)q.mask_step) + (unsigned)xr + q.mmis;
+                        ok = ok & ((unsigned)yr < (unsigned)q.rows) & ((io[dy] & ~3u) + 12u <= q.iend) & ((mo[dy] & ~3u) + 8u <= q.mend);
+                    }
+                    wfast[s] = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+                    if (wfast[s]) {
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) {
+                            rw[s][dy].v = *(const U3*)(q.img_al + (io[dy] & ~3u));
+                            rw[s][dy].q = *(const U2*)(q.mask_al + (mo[dy] & ~3u));
+                            rw[s][dy].sh = (io[dy] & 3u) | ((mo[dy] & 3u) << 2);
+                            rw[s][dy].fast = true;
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < G; ++s)
-            if (mine[s]) {   // the thread's 2x2 fine pixels of this tile
+            if (!wfast[s] && mine[s]) {   // the thread's 2x2 fine pixels of this tile
                 const int t = t0 + s, lcx = lx0[s] + lane, lcy = ly0[s] + wv;
                 Src0 s0;
                 if constexpr (FINE0) {
@@ -986,12 +1023,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
         PT(t0 == 0 ? 3 : 7);    // memory + barrier wait
 #pragma unroll
         for (int s = 0; s < G; ++s) {
-            if (!mine[s]) continue;
             const int t = t0 + s;
+            if (wfast[s]) {          // every lane: both windows loaded
+                if constexpr (FINE0 && SK == SK_U8) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const RawPair& r = rw[s][dy];
+                        const unsigned lo = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh & 3u), hi = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh & 3u);
+                        const unsigned mk = __builtin_amdgcn_alignbyte(r.q.y, r.q.x, r.sh >> 2);
+                        const float inv255 = (float)(1. / 255.);
+                        const int a0 = lo & 255, a1 = (lo >> 8) & 255, a2 = (lo >> 16) & 255, b0 = lo >> 24, b1 = hi & 255, b2 = (hi >> 8) & 255;
+                        Px<M>& a = gg[s][dy][0];
+                        Px<M>& b = gg[s][dy][1];
+                        if constexpr (M == M_I16) { a.c0 = a0; a.c1 = a1; a.c2 = a2; b.c0 = b0; b.c1 = b1; b.c2 = b2; }
+                        else { a.c0 = (float)a0; a.c1 = (float)a1; a.c2 = (float)a2; b.c0 = (float)b0; b.c1 = (float)b1; b.c2 = (float)b2; }
+                        a.w = (float)(mk & 255) * inv255;
+                        b.w = (float)((mk >> 8) & 255) * inv255;
+                    }
+                }
+            } else {
+            if (!mine[s]) continue;
             if constexpr (FINE0) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
                     src0_pair_finish<M, SK>(ts.s0[t], 2 * (lx0[s] + lane), 2 * (ly0[s] + wv) + dy, rw[s][dy], gg[s][dy][0], gg[s][dy][1]);
+            }
             }
             if constexpr (PK) {
                 const UpPk u = pyr_up_2x2_pk<M>(ct[b0 + s], lane, wv, lx0[s] + lane, ccl[s]);
@@ -1039,6 +1095,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
     // fp16 levels of integer images), every weight a multiple of 2^-8 / 255 or zero, so a normalised numerator is zero or far above
     // 2^-103 and far below 2^31: the shared-reciprocal division (isx_device.hpp) and the clamp-first conversions are exact.
     constexpr bool BOUNDED = PK && FINE0 && (SK == SK_U8 || SK == SK_S16);
+    // wave-level tier of the stores: every (remaining) lane's 2 x 2 pixels inside the result and the mats fit the vector path
+    bool allin = false;
+    if constexpr (FINE0) allin = out.vec && !out.img_f32 && __builtin_amdgcn_ballot_w64(!((2 * cx + 1 < out.cols) & (2 * cy + 1 < out.rows))) == 0ull;
     if constexpr (PK) {
         const UpPk u = pyr_up_2x2_pk<M>(ct[NB - 1], lane, wv, cx, coarse_out.cols);
 #pragma unroll
@@ -1060,8 +1119,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
             Px<M> dd[2];
             dd[0].c0 = ra0.x; dd[0].c1 = ra0.y; dd[0].c2 = rc.x; dd[0].w = accW[dy].x;
             dd[1].c0 = ra1.x; dd[1].c1 = ra1.y; dd[1].c2 = rc.y; dd[1].w = accW[dy].y;
-            if constexpr (FINE0) write_final_pair<M, BOUNDED>(out, 2 * cx, fy, dd[0], dd[1]);
-            else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
+            if constexpr (FINE0) {
+                if (allin) write_final_pair<M, BOUNDED, true>(out, 2 * cx, fy, dd[0], dd[1]);
+                else write_final_pair<M, BOUNDED>(out, 2 * cx, fy, dd[0], dd[1]);
+            } else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
         }
     } else {
     Up4<M> u = pyr_up_2x2<M>(ct[NB - 1], lane, wv, cx, coarse_out.cols);
@@ -1089,8 +1150,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
             }
             dd[dx] = d;
         }
-        if constexpr (FINE0) write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
-        else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
+        if constexpr (FINE0) {
+            if (allin) write_final_pair<M, false, true>(out, 2 * cx, fy, dd[0], dd[1]);
+            else write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
+        } else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
     }
     }
     PT(10);                     // epilogue: normalise, pyrUp of out, convert, stores issued
