@@ -234,17 +234,41 @@ __device__ __forceinline__ RawPair src0_pair_issue(const Src0& s, int x, int y) 
     return r;
 }
 
+// two adjacent CV_8UC3 pixels + their mask bytes out of the loaded windows
+template <int M>
+__device__ __forceinline__ void raw_pair_decode(const RawPair& r, Px<M>& a, Px<M>& b) {
+    const unsigned lo = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh & 3u), hi = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh & 3u);
+    const unsigned mk = __builtin_amdgcn_alignbyte(r.q.y, r.q.x, r.sh >> 2);
+    const float inv255 = (float)(1. / 255.);
+    const int a0 = lo & 255, a1 = (lo >> 8) & 255, a2 = (lo >> 16) & 255, b0 = lo >> 24, b1 = hi & 255, b2 = (hi >> 8) & 255;
+    if constexpr (M == M_I16) { a.c0 = a0; a.c1 = a1; a.c2 = a2; b.c0 = b0; b.c1 = b1; b.c2 = b2; }
+    else { a.c0 = (float)a0; a.c1 = (float)a1; a.c2 = (float)a2; b.c0 = (float)b0; b.c1 = (float)b1; b.c2 = (float)b2; }
+    a.w = (float)(mk & 255) * inv255;
+    b.w = (float)((mk >> 8) & 255) * inv255;
+}
+
+// Wave-level test for the window path (one ballot): the pair (x, x + 1) of row y lies inside the tile and both windows inside its
+// buffers for EVERY active lane; the offsets come back for the loads.  `pre`: conditions the caller already has per lane.
+__device__ __forceinline__ bool wave_pair_fast(const Src0& s, int x, int y, bool pre, unsigned& io, unsigned& mo) {
+    const int yr = y - s.top, xr = x - s.left;
+    io = __umul24((unsigned)yr, (unsigned)s.img_step) + __umul24((unsigned)xr, 3u) + s.imis;
+    mo = __umul24((unsigned)yr, (unsigned)s.mask_step) + (unsigned)xr + s.mmis;
+    const bool ok = pre & ((unsigned)yr < (unsigned)s.rows) & (xr >= 0) & (xr + 1 < s.cols) & ((io & ~3u) + 12u <= s.iend) & ((mo & ~3u) + 8u <= s.mend);
+    return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
+__device__ __forceinline__ RawPair raw_pair_load(const Src0& s, unsigned io, unsigned mo) {
+    RawPair r;
+    r.v = *(const U3*)(s.img_al + (io & ~3u));
+    r.q = *(const U2*)(s.mask_al + (mo & ~3u));
+    r.sh = (io & 3u) | ((mo & 3u) << 2);
+    r.fast = true;
+    return r;
+}
+
 template <int M, int SK>
 __device__ __forceinline__ void src0_pair_finish(const Src0& s, int x, int y, const RawPair& r, Px<M>& a, Px<M>& b) {
     if (r.fast) {
-        const unsigned lo = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh & 3u), hi = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh & 3u);
-        const unsigned mk = __builtin_amdgcn_alignbyte(r.q.y, r.q.x, r.sh >> 2);
-        const float inv255 = (float)(1. / 255.);
-        const int a0 = lo & 255, a1 = (lo >> 8) & 255, a2 = (lo >> 16) & 255, b0 = lo >> 24, b1 = hi & 255, b2 = (hi >> 8) & 255;
-        if constexpr (M == M_I16) { a.c0 = a0; a.c1 = a1; a.c2 = a2; b.c0 = b0; b.c1 = b1; b.c2 = b2; }
-        else { a.c0 = (float)a0; a.c1 = (float)a1; a.c2 = (float)a2; b.c0 = (float)b0; b.c1 = (float)b1; b.c2 = (float)b2; }
-        a.w = (float)(mk & 255) * inv255;
-        b.w = (float)((mk >> 8) & 255) * inv255;
+        raw_pair_decode<M>(r, a, b);
     } else {
         a = load_src0<M, SK>(s, x, y);
         b = load_src0<M, SK>(s, x + 1, y);
@@ -964,26 +988,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
             if constexpr (FINE0 && SK == SK_U8) {
                 if (touch[s]) {
                     const Src0& q = ts.s0[t0 + s];
-                    const int lcx = lx0[s] + lane, lcy = ly0[s] + wv, xr = 2 * lcx - q.left;
-                    bool ok = mine[s] & (xr >= 0) & (xr + 1 < q.cols);
+                    const int lcx = lx0[s] + lane, lcy = ly0[s] + wv;
                     unsigned io[2], mo[2];
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        const int yr = 2 * lcy + dy - q.top;
-                        io[dy] = __umul24((unsigned)yr, (unsigned)q.img_step) + __umul24((unsigned)xr, 3u) + q.imis;
-                        mo[dy] = __umul24((unsigned)yr, (unsigned)q.mask_step) + (unsigned)xr + q.mmis;
-                        ok = ok & ((unsigned)yr < (unsigned)q.rows) & ((io[dy] & ~3u) + 12u <= q.iend) & ((mo[dy] & ~3u) + 8u <= q.mend);
-                    }
-                    wfast[s] = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-                    if (wfast[s]) {
-#pragma unroll
-                        for (int dy = 0; dy < 2; ++dy) {
-                            rw[s][dy].v = *(const U3*)(q.img_al + (io[dy] & ~3u));
-                            rw[s][dy].q = *(const U2*)(q.mask_al + (mo[dy] & ~3u));
-                            rw[s][dy].sh = (io[dy] & 3u) | ((mo[dy] & 3u) << 2);
-                            rw[s][dy].fast = true;
-                        }
-                    }
+                    const bool f0 = wave_pair_fast(q, 2 * lcx, 2 * lcy, mine[s], io[0], mo[0]), f1 = wave_pair_fast(q, 2 * lcx, 2 * lcy + 1, mine[s], io[1], mo[1]);
+                    wfast[s] = f0 & f1;
+                    if (wfast[s]) { rw[s][0] = raw_pair_load(q, io[0], mo[0]); rw[s][1] = raw_pair_load(q, io[1], mo[1]); }
                 }
             }
         }
@@ -1027,19 +1036,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
             if (wfast[s]) {          // every lane: both windows loaded
                 if constexpr (FINE0 && SK == SK_U8) {
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        const RawPair& r = rw[s][dy];
-                        const unsigned lo = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh & 3u), hi = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh & 3u);
-                        const unsigned mk = __builtin_amdgcn_alignbyte(r.q.y, r.q.x, r.sh >> 2);
-                        const float inv255 = (float)(1. / 255.);
-                        const int a0 = lo & 255, a1 = (lo >> 8) & 255, a2 = (lo >> 16) & 255, b0 = lo >> 24, b1 = hi & 255, b2 = (hi >> 8) & 255;
-                        Px<M>& a = gg[s][dy][0];
-                        Px<M>& b = gg[s][dy][1];
-                        if constexpr (M == M_I16) { a.c0 = a0; a.c1 = a1; a.c2 = a2; b.c0 = b0; b.c1 = b1; b.c2 = b2; }
-                        else { a.c0 = (float)a0; a.c1 = (float)a1; a.c2 = (float)a2; b.c0 = (float)b0; b.c1 = (float)b1; b.c2 = (float)b2; }
-                        a.w = (float)(mk & 255) * inv255;
-                        b.w = (float)((mk >> 8) & 255) * inv255;
-                    }
+                    for (int dy = 0; dy < 2; ++dy) raw_pair_decode<M>(rw[s][dy], gg[s][dy][0], gg[s][dy][1]);
                 }
             } else {
             if (!mine[s]) continue;
