@@ -676,6 +676,7 @@ struct OutMat {  // the caller's blend() outputs
     int vec;         // image rows 4-byte aligned and mask rows 2-byte aligned: pair stores allowed
     int bx0;         // column window (isx_blender_set_window): first block column of this launch, 0 without a window
     int grp, gx, gy; // grp > 0: a 1-D launch in the XCD-aware block order of isx_device.hpp (xcd_block) over gx x gy blocks
+    unsigned xmagic; // xcd_magic(grp, gx)
 };
 
 // saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
     __shared__ Px<M> ct[NB][UP_TY + 2][WAVE + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int bxi = blockIdx.x, byi = blockIdx.y;
-    if (out.grp > 0 && !xcd_block(blockIdx.x, out.grp, out.gx, out.gy, bxi, byi)) return;
+    if (out.grp > 0 && !xcd_block(blockIdx.x, out.grp, out.gx, out.gy, out.xmagic, bxi, byi)) return;
     const int cx0 = (bxi + out.bx0) * WAVE, cy0 = byi * UP_TY;
     PT_DECL;
     // float work types: the accumulators and every stencil operation on (b, g) / (r, -) register pairs (packed fp32, see pyr_up_2x2_pk)
@@ -1765,7 +1766,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         // 262 with 8 (algorithmic: 229); launch time 67.1 / 65.7 / 68.3 / 73.5 us - larger groups leave the XCDs uneven shares.
         constexpr int XCD_GRP = 2;
         if (k == 1 && (int)grid.y >= 8 * XCD_GRP) {
-            o.grp = XCD_GRP; o.gx = (int)grid.x; o.gy = (int)grid.y;
+            o.grp = XCD_GRP; o.gx = (int)grid.x; o.gy = (int)grid.y; o.xmagic = xcd_magic(XCD_GRP, o.gx);
             grid = dim3(xcd_grid_blocks(XCD_GRP, o.gx, o.gy), 1);
         }
         if (k == 1) {
@@ -2309,7 +2310,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
-    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0;
+    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0; o.xmagic = 0;
     if (windowed) {
         // the kernels keep addressing the mosaic's columns: the mats' origins move left by the window's first column (a multiple of
         // ISX_WINDOW_GRANULE, so every alignment is kept and a block of the last step starts exactly there), the right crop is the

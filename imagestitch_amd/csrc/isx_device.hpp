@@ -77,11 +77,13 @@ __device__ __forceinline__ f32x2 splat2(float v) { f32x2 r = {v, v}; return r; }
 // fabric itself.  Here the blocks of one XCD walk groups of `grp` block rows column by column (vertical and horizontal neighbours are
 // dispatched back to back on the same XCD and meet in its L2), and the groups are dealt to the XCDs round robin, which keeps their
 // shares of the image even.  Launch xcd_grid_blocks(grp, gx, gy) blocks; false = a padding block.
-__device__ __forceinline__ bool xcd_block(unsigned L, int grp, int gx, int gy, int& bx, int& by) {
+// per = grp * gx blocks per group, magic = 2^32 / per + 1 (xcd_magic on the host): j / per without a division sequence per wave
+__device__ __forceinline__ bool xcd_block(unsigned L, int grp, int gx, int gy, unsigned magic, int& bx, int& by) {
     const unsigned xcd = L & 7u, j = L >> 3, per = (unsigned)(grp * gx);
-    const unsigned g = j / per, r = j - g * per;
-    bx = (int)(r / (unsigned)grp);
-    by = (int)((g * 8u + xcd) * (unsigned)grp + (r - (unsigned)bx * (unsigned)grp));
+    const unsigned g = __umulhi(j, magic), r = j - g * per;          // exact while j * per < 2^32
+    const unsigned c = grp == 2 ? r >> 1 : r / (unsigned)grp;
+    bx = (int)c;
+    by = (int)((g * 8u + xcd) * (unsigned)grp + (r - c * (unsigned)grp));
     return by < gy;
 }
 

@@ -95,6 +95,7 @@ bool profiling_enabled();
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // blocks of a 1-D launch in the XCD-aware order of isx_device.hpp's xcd_block: gy rows in groups of grp, the groups dealt to 8 XCDs
+inline unsigned xcd_magic(int grp, int gx) { return 0xFFFFFFFFu / (unsigned)(grp * gx) + 1u; }
 inline unsigned xcd_grid_blocks(int grp, int gx, int gy) { return (unsigned)(8 * cdiv(cdiv(gy, grp), 8) * grp) * (unsigned)gx; }
 
 }  // namespace isx
