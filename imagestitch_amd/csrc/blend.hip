@@ -1761,11 +1761,12 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
         OutMat o = out;
         o.bx0 = bx_lo;
-        // last step: XCD-aware block order in groups of 2 block rows (see OutMat).  Measured on the 4K pair (tools/measure_traffic.py,
+        // last two steps (levels 0 and 1; the level-1 step runs at the fabric's rate: 48.5 -> 46.2 us for the four upper steps; no gain
+        // from level 2 up): XCD-aware block order in groups of 2 block rows (see OutMat).  Measured on the 4K pair (tools/measure_traffic.py,
         // profiles/round2_xcd_order.txt): fabric traffic per launch 383 MB in plain row-major order, 282 MB with groups of 2, 268 with 4,
         // 262 with 8 (algorithmic: 229); launch time 67.1 / 65.7 / 68.3 / 73.5 us - larger groups leave the XCDs uneven shares.
         constexpr int XCD_GRP = 2;
-        if (k == 1 && (int)grid.y >= 8 * XCD_GRP) {
+        if (k <= 2 && (int)grid.y >= 8 * XCD_GRP) {
             o.grp = XCD_GRP; o.gx = (int)grid.x; o.gy = (int)grid.y; o.xmagic = xcd_magic(XCD_GRP, o.gx);
             grid = dim3(xcd_grid_blocks(XCD_GRP, o.gx, o.gy), 1);
         }
