@@ -491,7 +491,7 @@ def main():
     if args.graph:
         for _ in range(args.steps):   # the dominant kernel's HIP-event timing comes from eager steps outside the timed region
             for p in pairs:
-                p.step()
+                p.step_sync() if args.sync_roi else p.step()
         ent_graph = _lib.profile_entries()
         lib.isx_profile_enable(0)
     # as timeit does: no Python garbage collection inside the timed region (a generation-2 pass over torch's and numpy's objects
@@ -521,7 +521,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             for p in pairs:
-                p.replay() if args.graph else p.step()
+                p.replay() if args.graph else (p.step_sync() if args.sync_roi else p.step())
         if args.graph:
             for p in pairs:
                 torch.cuda.current_stream().wait_stream(p.gstream)
@@ -613,7 +613,14 @@ def main():
             out["dropin"] = dropin_legs(args, K, Rs, host_imgs0, dev, {"f32": _lib.PREC_F32, "i16": _lib.PREC_I16})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, F, args.bands, prec, args.kind, NT, args.yaw)
-        print(json.dumps(out))
+        # RCCL writes a banner (ROCm version, host, library path) through C stdio, which a pipe would deliver AFTER this line at exit:
+        # push it out first, so that the JSON line is the last line of rank 0's output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
