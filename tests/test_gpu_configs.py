@@ -54,6 +54,55 @@ def test_config1_two_1080p_tiles_3_bands(gpu, oracle):
         ps.check_plan()
 
 
+def test_config3_sixteen_4k_pairs_eager_on_four_streams(gpu, oracle):
+    """BASELINE config 3 as bench.py runs it by default (--pairs 16: eager launches, the pairs spread over 4 streams so that one pair's
+    small pyramid levels run under another's large kernels): three steps of 16 concurrent pairs; every mosaic equals the same pair's
+    mosaic from a serial single-stream run, and one pair equals the oracle."""
+    import torch
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F, NP, NS = 3840, 2160, 3000.0, 16, 4
+    K, Rs = synth.camera_pair(W, H, F)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    check_pair = 5
+    host_imgs = [synth.make_tile(H, W, 320 + i) for i in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    inputs = []
+    for p in range(NP):
+        if p == check_pair:
+            inputs.append([torch.from_numpy(i).to(dev) for i in host_imgs])
+        else:
+            gen.manual_seed(synth.SEED0 + 50 + p)
+            inputs.append([torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generator=gen) for _ in range(2)])
+    serial = []
+    for p in range(NP):                                    # the expected mosaics: one stitcher, one stream, one pair after the other
+        ps = PairStitcher(inputs[p], K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "float32")
+        out, omask = ps.step()
+        serial.append((out.clone(), omask.clone()))
+        ps.check_plan()
+        del ps
+    torch.cuda.synchronize()
+    pairs = [PairStitcher(inputs[p], K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, streams[p % NS], "float32") for p in range(NP)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for ps in pairs:
+            ps.out.zero_(); ps.out_mask.zero_()
+        torch.cuda.synchronize()
+        for p, ps in enumerate(pairs):                     # 16 steps enqueued back to back over the 4 streams
+            with torch.cuda.stream(streams[p % NS]):
+                ps.step()
+        torch.cuda.synchronize()
+        for p, ps in enumerate(pairs):
+            assert torch.equal(ps.out, serial[p][0]) and torch.equal(ps.out_mask, serial[p][1]), "pair %d, step %d" % (p, rep)
+    for ps in pairs:
+        ps.check_plan()
+    _, _, _, _, od, om = _oracle_mosaic(oracle, oracle.CYL, F, K, Rs, host_imgs, 5, oracle.F32, True)
+    assert np.array_equal(pairs[check_pair].out_mask.cpu().numpy(), om)
+    assert np.array_equal(pairs[check_pair].out.cpu().numpy(), od)
+    del pairs, serial, inputs
+    torch.cuda.empty_cache()
+
+
 def test_config3_sixteen_4k_pairs_as_graphs(gpu, oracle):
     """BASELINE config 3: 16 independent 4K pairs resident on one GPU, each captured as its own hipGraph, replayed twice;
     every replayed mosaic equals the eager (launch by launch) run of the same pair, and one pair equals the oracle."""
