@@ -462,3 +462,46 @@ def test_pair_stitcher_cycles_agree(gpu, prec):
         outs.append((out.cpu().numpy().copy(), om.cpu().numpy().copy()))
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize("prec_name", ["i16", "f32", "f16acc32"])
+@pytest.mark.parametrize("off_img,off_mask,pad", [(1, 3, 5), (2, 1, 0), (3, 2, 7), (0, 0, 1)])
+def test_deferred_blend_of_misaligned_device_views(gpu, oracle, prec_name, off_img, off_mask, pad):
+    """CV_8UC3 tiles and masks that are views into larger device buffers: data pointers off by 1-3 bytes from a dword, row pitches
+    that are no multiple of 4.  The level-0 kernels read them through aligned 12-byte windows (and, in the last collapse step, a
+    wave-level test of those windows): every offset / pitch combination must give the oracle's mosaic."""
+    import torch
+    prec = {"i16": gpu.PREC_I16, "f32": gpu.PREC_F32, "f16acc32": gpu.PREC_F16ACC32}[prec_name]
+    oprec = {"i16": oracle.I16, "f32": oracle.F32, "f16acc32": oracle.F16ACC32}[prec_name]
+    rng = np.random.default_rng(1000 + off_img * 16 + off_mask * 4 + pad)
+    dev = torch.device("cuda:0")
+    sizes = [(301, 150), (277, 163)]
+    corners = [(-13, 4), (170, -6)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for w, h in sizes]
+    masks = [(rng.random((h, w)) > 0.1).astype(np.uint8) * 255 for w, h in sizes]
+
+    def view(a, off):
+        h, w = a.shape[:2]
+        row = w * (a.shape[2] if a.ndim == 3 else 1)
+        pitch = row + pad
+        buf = torch.zeros((off + h * pitch + 16,), dtype=torch.uint8, device=dev)
+        v = buf[off:off + h * pitch].view(h, pitch)[:, :row]
+        v.copy_(torch.from_numpy(a.reshape(h, row)).to(dev))
+        return v.view(h, w, 3) if a.ndim == 3 else v, buf
+
+    mb = gpu.MultiBandBlender(False, 4, prec)
+    mb.set_deferred_level0(True)
+    ob = oracle.MultiBand(4, oprec)
+    mb.prepare(corners, sizes); ob.prepare(corners, sizes)
+    keep = []
+    for im, m, c in zip(imgs, masks, corners):
+        vi, bi = view(im, off_img)
+        vm, bm = view(m, off_mask)
+        assert vi.data_ptr() % 4 == off_img % 4 or off_img == 0
+        keep += [vi, vm, bi, bm]
+        mb.feed_u8(vi, vm, c)
+        ob.feed(im.astype(np.int16), m, c)
+    out_f32 = prec_name != "i16"
+    d, dm = mb.blend(out_f32=out_f32)
+    od, om = ob.blend(out_f32)
+    assert np.array_equal(dm.cpu().numpy(), om) and np.array_equal(d.cpu().numpy(), od)
