@@ -68,6 +68,7 @@ _SIGS = {
     "isx_blender_set_mark_event": [C.c_void_p, C.c_void_p, C.c_int],
     "isx_blender_set_window": [C.c_void_p, C.c_int, C.c_int],
     "isx_warper_set_dst_columns": [C.c_void_p, C.c_int, C.c_int],
+    "isx_blend_pair_linear_release": [],
     "isx_blender_create": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "isx_blender_destroy": [C.c_void_p],
     "isx_blender_set_stream": [C.c_void_p, C.c_void_p],

@@ -47,37 +47,98 @@ __global__ __launch_bounds__(256) void k_lin_cost(LinGeom g, const unsigned char
     costV[(size_t)y * cw + x] = c;
 }
 
-// One wave.  The seam moves at most one column per row, so a 64-column window of the next SEAM_ROWS
-// rows is staged in LDS and lane 0 walks it; the window is re-centred every SEAM_ROWS rows.
+// Five waves.  The seam moves at most one column per row (B:268-307), and which way it moves from column x of row y depends on
+// costV[y + 1][x - 1 .. x + 1] alone.  So waves 1-4 (the producers) turn a window of SEAM_ROWS x 256 costs into a table of steps
+// (-1 / 0 / +1 per cell, every lane four columns of its rows, the reference's comparisons and tie order), and wave 0 (the walker)
+// only follows the table: one dependent LDS byte per row.  Chunks are double-buffered in LDS; the producer fetches a chunk's costs
+// two chunks before it is walked, centred where the seam stands then - by the time it is walked the seam has moved at most
+// 3 * SEAM_ROWS = 72 columns, well inside the 128 the window reaches to either side - so neither the memory latency nor the
+// comparisons are on the walker's path.  (First version: one wave, a 64-column window per 24 rows loaded and then walked with three
+// LDS reads and the comparisons per row: 483 us for the 2170 rows of a 4K pair.)
 constexpr int SEAM_ROWS = 24;
-__global__ __launch_bounds__(64) void k_lin_seam(LinGeom g, const float* costV, int* seam) {
-    __shared__ float win[SEAM_ROWS][64];
-    __shared__ int s_px;
-    const int cw = g.iBr + 2, lane = threadIdx.x;
-    if (lane == 0) { s_px = g.iBr / 2; seam[0] = g.iBr / 2; }
-    __syncthreads();
-    for (int py = 0; py < g.iHe - 1; py += SEAM_ROWS) {
-        int px = s_px;
-        int x0 = px - 32;
-        int nr = min(SEAM_ROWS, g.iHe - 1 - py);
+constexpr int SEAM_W = 256;
+static_assert(3 * SEAM_ROWS + 2 < SEAM_W / 2, "a window fetched three chunks ahead still holds the seam and its neighbours");
+
+__device__ __forceinline__ int seam_dir(float a, float b, float c) {     // B:283-300: left / stay / right from the three costs below
+    // if (a == b && a == c) stay; else if (a <= b && a <= c) left; else if (b <= a && b <= c) stay; else if (c <= a && c <= b) right
+    const bool all = (a == b) & (a == c), la = (a <= b) & (a <= c), lb = (b <= a) & (b <= c), lc = (c <= a) & (c <= b);
+    int d = lc ? 1 : 0;
+    d = lb ? 0 : d;
+    d = la ? -1 : d;
+    return all ? 0 : d;
+}
+
+constexpr int SEAM_PRODUCERS = 4;                        // producer waves: each fetches and tabulates every 4th row of a chunk
+constexpr int SEAM_PR = SEAM_ROWS / SEAM_PRODUCERS;      // rows of a chunk per producer wave
+static_assert(SEAM_ROWS % SEAM_PRODUCERS == 0, "rows of a chunk are dealt evenly to the producer waves");
+
+__global__ __launch_bounds__(64 * (1 + SEAM_PRODUCERS)) void k_lin_seam(LinGeom g, const float* costV, int* seam) {
+    __shared__ signed char dir[2][SEAM_ROWS][SEAM_W];
+    __shared__ int s_x0[2], s_px;
+    const int cw = g.iBr + 2, lane = threadIdx.x & 63, last = g.iHe - 1;     // rows 1 .. last are chosen by the walk
+    const bool producer = threadIdx.x >= 64;
+    const int pw = (int)(threadIdx.x >> 6) - 1;          // producer wave index (rows pw, pw + 4, ...)
+    int px = g.iBr / 2;
+    if (threadIdx.x == 0) seam[0] = px;
+    if (last < 1) return;
+    const int nchunks = (last + SEAM_ROWS - 1) / SEAM_ROWS;
+    float4 S0[SEAM_PR], S1[SEAM_PR];         // producer: its rows of two chunks in flight (even chunks in S0, odd ones in S1; registers)
+    int x0_0 = 0, x0_1 = 0;
+    auto fetch = [&](float4 (&S)[SEAM_PR], int& x0, int j, int centre) {   // chunk j = rows j * SEAM_ROWS + 1 ..., columns centre - 128 .. centre + 127
+        x0 = centre - SEAM_W / 2;
+        const int py = j * SEAM_ROWS;
+        const bool inside = x0 >= 0 && x0 + SEAM_W <= cw;                  // wave-uniform: no clamping needed
+#pragma unroll
+        for (int i = 0; i < SEAM_PR; ++i) {
+            const int r = pw + SEAM_PRODUCERS * i;
+            const float* q = costV + (size_t)min(py + 1 + r, last) * cw;
+            const int c = x0 + 4 * lane;
+            float4 v;
+            if (inside) { v.x = q[c]; v.y = q[c + 1]; v.z = q[c + 2]; v.w = q[c + 3]; }
+            else { v.x = q[min(max(c, 0), cw - 1)]; v.y = q[min(max(c + 1, 0), cw - 1)]; v.z = q[min(max(c + 2, 0), cw - 1)]; v.w = q[min(max(c + 3, 0), cw - 1)]; }
+            S[i] = v;
+        }
+    };
+    auto publish = [&](const float4 (&S)[SEAM_PR], int x0, int b) {       // the step table of a chunk into LDS buffer b
+#pragma unroll
+        for (int i = 0; i < SEAM_PR; ++i) {
+            const int r = pw + SEAM_PRODUCERS * i;
+            const float4 v = S[i];
+            const float left = __shfl_up(v.w, 1), right = __shfl_down(v.x, 1);     // the window's outermost columns are never reached
+            const int d0 = seam_dir(left, v.x, v.y), d1 = seam_dir(v.x, v.y, v.z), d2 = seam_dir(v.y, v.z, v.w), d3 = seam_dir(v.z, v.w, right);
+            *(unsigned*)&dir[b][r][4 * lane] = (unsigned)(d0 & 255) | ((unsigned)(d1 & 255) << 8) | ((unsigned)(d2 & 255) << 16) | ((unsigned)(d3 & 255) << 24);
+        }
+        if (lane == 0 && pw == 0) s_x0[b] = x0;
+    };
+    auto walk = [&](int j) {                    // wave 0, lane 0: follow the table of chunk j
+        const int b = j & 1, x0 = s_x0[b], py = j * SEAM_ROWS, nr = min(SEAM_ROWS, last - py);
         for (int r = 0; r < nr; ++r) {
-            int xx = min(max(x0 + lane, 0), cw - 1);
-            win[r][lane] = costV[(size_t)(py + 1 + r) * cw + xx];
+            px = min(max(px + (int)dir[b][r][px - x0], 0), cw - 1);          // xl = max(px - 1, 0), xr = min(px + 1, cw - 1)
+            seam[py + 1 + r] = px;
         }
+        s_px = px;
+    };
+    if (producer) {
+        fetch(S0, x0_0, 0, px);
+        if (nchunks > 1) fetch(S1, x0_1, 1, px);
+        publish(S0, x0_0, 0);
+        if (nchunks > 2) fetch(S0, x0_0, 2, px);          // S0 is free again
+    }
+    __syncthreads();
+    for (int j = 0; j < nchunks; j += 2) {
+        // even chunk j (LDS buffer 0) is walked while the table of chunk j + 1 (S1 -> buffer 1) is written
+        if (!producer) { if (lane == 0) walk(j); }
+        else if (j + 1 < nchunks) publish(S1, x0_1, 1);
         __syncthreads();
-        if (lane == 0) {
-            for (int r = 0; r < nr; ++r) {
-                int xl = max(px - 1, 0), xr = min(px + 1, cw - 1);   // clamp (out of bounds in the reference)
-                float a = win[r][xl - x0], b = win[r][px - x0], c = win[r][xr - x0];
-                if (a == b && a == c) { }
-                else if (a <= b && a <= c) px = xl;
-                else if (b <= a && b <= c) { }
-                else if (c <= a && c <= b) px = xr;
-                seam[py + 1 + r] = px;
-            }
-            s_px = px;
-        }
+        px = s_px;
+        if (producer && j + 3 < nchunks) fetch(S1, x0_1, j + 3, px);
+        if (j + 1 >= nchunks) break;
+        // odd chunk j + 1 (buffer 1) is walked while the table of chunk j + 2 (S0 -> buffer 0) is written
+        if (!producer) { if (lane == 0) walk(j + 1); }
+        else if (j + 2 < nchunks) publish(S0, x0_0, 0);
         __syncthreads();
+        px = s_px;
+        if (producer && j + 4 < nchunks) fetch(S0, x0_0, j + 4, px);
     }
 }
 
@@ -171,7 +232,24 @@ void geom_sizes(int rows1, int cols1, int rows2, int cols2, int tl1x, int tl1y, 
 
 }  // namespace
 
+namespace {
+struct LinScratch { DevBuf buf; int device = -1; };
+LinScratch& lin_scratch() {
+    static thread_local LinScratch* s = new LinScratch();   // never destroyed at thread exit (the HIP runtime may be gone by then)
+    return *s;
+}
+}  // namespace
+
 extern "C" {
+
+int isx_blend_pair_linear_release(void) {
+    clear_error();
+    LinScratch& ls = lin_scratch();
+    if (ls.device >= 0) (void)hipSetDevice(ls.device);
+    ls.buf.release();
+    ls.device = -1;
+    return ISX_OK;
+}
 
 int isx_blend_pair_linear_size(int rows1, int cols1, int rows2, int cols2, int tl1_x, int tl1_y, int tl2_x, int tl2_y,
                                int* pano_rows, int* pano_cols) {
@@ -212,7 +290,11 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2, int tl
     ISX_TRY(sp.use_out(pano, st, "blend_pair_linear: pano"));
     g.step1 = s1.d.step; g.step2 = s2.d.step; g.pstep = sp.d.step;
     const int cw = g.iBr + 2, mw = g.width + 2;
-    DevBuf scratch;
+    // work buffers (cost map, seam, the two weight maps: 38 MB for a 4K pair) persist per host thread and device, grow-only: a
+    // hipMalloc / hipFree pair per call cost 0.24 ms of a 0.55 ms call (isx_blend_pair_linear_release returns them)
+    LinScratch& ls = lin_scratch();
+    if (ls.device != device) { ls.buf.release(); ls.device = device; }
+    DevBuf& scratch = ls.buf;
     size_t cost_b = ((size_t)g.iHe * cw * 4 + 255) & ~(size_t)255, seam_b = ((size_t)g.iHe * 4 + 255) & ~(size_t)255,
            m_b = ((size_t)g.height * mw * 4 + 255) & ~(size_t)255;
     ISX_TRY(scratch.reserve(cost_b + seam_b + 2 * m_b));
@@ -223,13 +305,13 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2, int tl
     const unsigned char* i1 = (const unsigned char*)s1.d.data;
     const unsigned char* i2 = (const unsigned char*)s2.d.data;
     ISX_LAUNCH("lin_cost", 0.0, st, k_lin_cost, dim3(cdiv(cw, 256), g.iHe), dim3(256), 0, g, i1, i2, costV);
-    ISX_LAUNCH("lin_seam", 0.0, st, k_lin_seam, dim3(1), dim3(64), 0, g, costV, seam);
+    ISX_LAUNCH("lin_seam", 0.0, st, k_lin_seam, dim3(1), dim3(64 * (1 + SEAM_PRODUCERS)), 0, g, costV, seam);
     ISX_LAUNCH("lin_classify", 0.0, st, k_lin_classify, dim3(cdiv(mw, 256), g.height), dim3(256), 0, g, i1, i2, m1, m2);
     ISX_LAUNCH("lin_rows", 0.0, st, k_lin_rows, dim3(g.height), dim3(64), 0, g, seam, m1, m2);
     ISX_LAUNCH("lin_compose", 0.0, st, k_lin_compose, dim3(cdiv(g.panoBr, 256), g.panoHe), dim3(256), 0, g, i1, i2, m1, m2, (unsigned char*)sp.d.data);
     if (seam_x) ISX_HIP(hipMemcpyAsync(seam_x, seam, (size_t)g.iHe * 4, hipMemcpyDeviceToHost, st));
     ISX_TRY(sp.finish_out(st));
-    ISX_HIP(hipStreamSynchronize(st));   // scratch is freed on return
+    ISX_HIP(hipStreamSynchronize(st));   // the seam and a host pano are complete when the call returns (cv::Mat semantics)
     return ISX_OK;
 }
 

@@ -315,6 +315,9 @@ int isx_blend_pair_linear_size(int rows1, int cols1, int rows2, int cols2,
 int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2,
                           int tl1_x, int tl1_y, int tl2_x, int tl2_y,
                           isx_mat* pano, int* seam_x, int device, void* hip_stream);
+/* isx_blend_pair_linear keeps its work buffers (cost map, seam, weight maps: 38 MB for a 4K pair) per calling thread between
+ * calls; this returns them. */
+int isx_blend_pair_linear_release(void);
 
 /* ---- assembling a batch of mosaics across the GPUs of a node (no counterpart in the reference; BASELINE config 4) ---------------- */
 /* One process per GPU.  The independent pairs of a batch are partitioned across the ranks (no collective while blending); each rank
