@@ -282,3 +282,50 @@ def test_buildmaps_reproduces_the_references_xmap_ymap_bitmaps_on_the_gpu(gpu, o
     oxm, oym = oracle.build_maps(oracle.CYL, float(D["scale"]), kr, roi)
     assert xm.tobytes() == oxm.tobytes() and ym.tobytes() == oym.tobytes()
     assert check_maps_against_the_reference_bitmaps(xm, ym) == 14
+
+
+@pytest.mark.parametrize("kind", ["cylindrical", "spherical"])
+@pytest.mark.parametrize("out16,dense", [(False, False), (False, True), (True, False), (True, True)])
+def test_warp_dst_columns(gpu, kind, out16, dense):
+    """isx_warper_set_dst_columns: the fused warp computes only the 64-column blocks that hold the requested columns and leaves the
+    rest of the mats alone - CV_8UC3 / CV_16SC3 outputs, pitched (dword stores) and dense (per-pixel stores) destinations, both
+    projectors, host-synchronous and planned form; inside the range the result is the full warp's."""
+    import torch
+    W, H, F = 500, 300, 380.0
+    K, Rs = synth.camera_pair(W, H, F, yaw=0.3)
+    img = torch.from_numpy(synth.make_tile(H, W, 3, noise_only=True)).cuda()
+    wp = (gpu.CylindricalWarper if kind == "cylindrical" else gpu.SphericalWarper)().create(F)
+    corner, full, fmask = wp.warp_with_mask(img, K, Rs[0], out16=out16)
+    h, w = full.shape[:2]
+    roi = wp.warpRoi((W, H), K, Rs[0])
+    dt = torch.int16 if out16 else torch.uint8
+    es = 2 if out16 else 1
+
+    def fresh():
+        if dense:
+            return torch.full((h, w, 3), 77, dtype=dt, device="cuda"), torch.full((h, w), 9, dtype=torch.uint8, device="cuda")
+        pitch = (w * 3 * es + 63) // 64 * 64
+        di = torch.full((h * pitch // es,), 77, dtype=dt, device="cuda").as_strided((h, w, 3), (pitch // es, 3, 1))
+        mp = (w + 63) // 64 * 64
+        dm = torch.full((h * mp,), 9, dtype=torch.uint8, device="cuda").as_strided((h, w), (mp, 1))
+        return di, dm
+
+    for c0, c1 in ((0, 1), (70, 200), (64, 128), (w - 5, w), (130, w + 40), (0, w)):
+        for planned in ((False, True) if kind == "cylindrical" else (False,)):
+            di, dm = fresh()
+            wp.set_dst_columns(c0, c1)
+            if planned:
+                wp.warp_with_mask_planned(img, K, Rs[0], roi, di, dm)
+            else:
+                assert wp.warp_with_mask(img, K, Rs[0], out16=out16, dst_img=di, dst_mask=dm)[0] == corner
+            wp.set_dst_columns(0, 0)
+            torch.cuda.synchronize()
+            lo, hi = c0 // 64 * 64, min(c1, w)             # computed: the blocks from the one that holds c0 up to the range's end
+            assert torch.equal(di[:, lo:hi], full[:, lo:hi]) and torch.equal(dm[:, lo:hi], fmask[:, lo:hi]), (c0, c1, planned)
+            assert (di[:, :lo] == 77).all() and (dm[:, :lo] == 9).all()
+            assert (di[:, hi:] == 77).all() and (dm[:, hi:] == 9).all(), (c0, c1, planned)
+    if kind == "cylindrical":
+        assert wp.plan_status() == 0
+    di, dm = fresh()                                         # (0, 0): the whole tile again
+    wp.warp_with_mask(img, K, Rs[0], out16=out16, dst_img=di, dst_mask=dm)
+    assert torch.equal(di, full) and torch.equal(dm, fmask)
