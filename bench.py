@@ -231,6 +231,26 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: check that the node has N GPUs, then become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>`
+    (one process per GPU over RCCL, the same command the driver issues)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()            # hipGetDeviceCount
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s) (hipGetDeviceCount); one process per GPU needs %d. "
+                         "Nothing was launched." % (n, have, n))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +307,8 @@ def main():
     from imagestitch_amd import _lib, synth
     from imagestitch_amd.pipeline import PairStitcher
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)      # does not return: this process becomes torch.distributed.run with --gpus ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.pairs is None:
         args.pairs = 1 if world == 1 else 4
@@ -294,8 +316,14 @@ def main():
         args.streams = 1 if args.pairs == 1 else min(args.pairs, 4)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch %d ranks (python -m torch.distributed.run --nproc-per-node %d ...), "
+                         "or run `python bench.py --gpus %d` without WORLD_SIZE set and it starts them itself" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but hipGetDeviceCount reports %d device(s): one process per GPU needs %d GPUs on this node"
+                         % (local, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
