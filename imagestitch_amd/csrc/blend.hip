@@ -1158,6 +1158,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
     PT_FLUSH;
 }
 
+#include "collapse_roll.inc"
+
 // ------------------------------------------------------------------------------------------------
 // N2  FeatherBlender (W:278-281,302,313; OpenCV 3.4.2 blenders.cpp createWeightMap / feed / blend)
 //   weight = min(distanceTransform(mask, DIST_L1, 3) * sharpness, 1)
@@ -1657,6 +1659,45 @@ int flush_deferred(isx_blender* b) {
     return ISX_OK;
 }
 
+// The last collapse step as the rolling kernel (collapse_roll.inc) when its limits hold: coarse columns [cx_lo, cx_hi) of level 1 in
+// strips of RL_CW columns x R rows, one wave each, dealt to the XCDs in groups of two strip rows (xcd_block).  *done = false: the
+// caller launches k_collapse_gather instead.  ISX_ROLL=0 forces that (A/B runs); ISX_ROLL_R picks the strip height.
+template <int M, int SK, int R>
+int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& coarse, OutMat o, int cx_lo, int cx_hi, double bytes, bool* done) {
+    const int nsx = cdiv(cx_hi - cx_lo, RL_CW), nsy = cdiv(coarse.rows, R), nby = cdiv(nsy, ROLL_WAVES);
+    if (nsx <= 0 || nsy <= 0) return ISX_OK;
+    for (int sy = 0; sy < nsy; ++sy)          // no strip may be reached by more than ROLL_MAXT tiles
+        for (int sx = 0; sx < nsx; ++sx) {
+            const int x0 = 2 * (cx_lo + sx * RL_CW), y0 = 2 * sy * R;
+            int cnt = 0;
+            for (int t = 0; t < ts.n; ++t)
+                cnt += !((x0 >= ts.x_tl[t] + ts.w[t]) | (x0 + 2 * RL_CW <= ts.x_tl[t]) | (y0 >= ts.y_tl[t] + ts.h[t]) | (y0 + 2 * R <= ts.y_tl[t]));
+            if (cnt > ROLL_MAXT) return ISX_OK;
+        }
+    const int grp = 2;      // (xcd_magic needs grp * nsx >= 2)
+    o.bx0 = 0; o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx);
+    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll<M, SK, R>), dim3(xcd_grid_blocks(grp, nsx, nby)), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
+    *done = true;
+    return ISX_OK;
+}
+template <int M, int SK>
+int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, const LevelBuf& coarse, const OutMat& o, int cx_lo, int cx_hi, double bytes, bool* done) {
+    static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
+    static const int rsel = [] { const char* e = getenv("ISX_ROLL_R"); return e ? atoi(e) : 1; }();
+    *done = false;
+    if constexpr (SK == SK_U8) {
+        if (!mode || coarse.cols < 2 || (unsigned long long)coarse.rows * coarse.cols * 16ull >= (1ull << 32)) return ISX_OK;
+        for (int t = 0; t < ts.n; ++t)
+            if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].iend == 0u ||      // iend != 0: CV_8UC3 below 2 GiB, 32-bit offsets
+                (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return ISX_OK;
+        if constexpr (M == M_F32) {
+            if (rsel == 2) return launch_collapse_roll_r<M, SK, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        }
+        return launch_collapse_roll_r<M, SK, 1>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+    }
+    return ISX_OK;
+}
+
 // blend() of a fully deferred cycle: Gaussian chains of all tiles, top gather, gathering collapse chain
 template <int M, int SK>
 int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
@@ -1772,6 +1813,11 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         }
         if (k == 1) {
             bytes = bytes * frac + (double)out.rows * (need_hi[0] - need_lo[0]) * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));   // result + mask
+            if (k != L) {
+                bool done = false;
+                ISX_TRY((launch_collapse_roll<M, SK>(b, st, ts, d[1], out, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, &done)));
+                if (done) continue;
+            }
             if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
             else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, false>), grid, dim3(256), 0, ts, d[1], d[0], o);
         } else {

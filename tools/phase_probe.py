@@ -32,6 +32,14 @@ torch.cuda.synchronize()
 lib.isx_debug_phase(buf, 0)
 v = list(buf)
 waves = v[11]
+if os.environ.get("ISX_ROLL", "1") != "0":
+    names = ["block order, tile selection", "slot descriptors, lane offsets", "loads issued", "all loads waited for (timing build only)",
+             "tiles: row / column filters, decode, accumulate", "out_1: filters, normalise, convert, stores issued"]
+    tot = sum(v[:11])
+    print("k_collapse_roll<%s, U8> on a 4K pair:" % (sys.argv[1] if len(sys.argv) > 1 else "f32"), "%.0f waves per launch, wave lifetime %.0f s_memtime ticks" % (waves / n, tot / waves))
+    for k in range(6):
+        print("  %-58s %8.1f ticks/wave  %5.1f %%" % (names[k], v[k] / waves, 100.0 * v[k] / tot))
+    sys.exit(0)
 names = ["round 0: tile descriptors (scalar loads)", "round 0: coarse tiles issued (LDS-DMA)", "round 0: fine pixels issued", "round 0: memory + barrier wait",
          "round 1: tile descriptors", "round 1: coarse tiles + out issued", "round 1: fine pixels issued", "round 1: memory + barrier wait",
          "round 0: decode + pyrUp + accumulate", "round 1: decode + pyrUp + accumulate", "epilogue: normalise, pyrUp(out), convert, stores issued"]
