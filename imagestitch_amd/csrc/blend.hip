@@ -677,6 +677,7 @@ struct OutMat {  // the caller's blend() outputs
     int bx0;         // column window (isx_blender_set_window): first block column of this launch, 0 without a window
     int grp, gx, gy; // grp > 0: a 1-D launch in the XCD-aware block order of isx_device.hpp (xcd_block) over gx x gy blocks
     unsigned xmagic; // xcd_magic(grp, gx)
+    int band;        // > 0: xcd_band_block's mapping, block rows per XCD band
 };
 
 // saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
@@ -1674,9 +1675,13 @@ int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& co
                 cnt += !((x0 >= ts.x_tl[t] + ts.w[t]) | (x0 + 2 * RL_CW <= ts.x_tl[t]) | (y0 >= ts.y_tl[t] + ts.h[t]) | (y0 + 2 * R <= ts.y_tl[t]));
             if (cnt > ROLL_MAXT) return ISX_OK;
         }
-    const int grp = 2;      // (xcd_magic needs grp * nsx >= 2)
+    static const int band_mode = [] { const char* e = getenv("ISX_ROLL_BAND"); return e ? atoi(e) : 1; }();
+    static const int grp_sel = [] { const char* e = getenv("ISX_ROLL_GRP"); return e ? atoi(e) : 2; }();
+    const int grp = std::max(grp_sel, nsx == 1 ? 2 : 1);      // (xcd_magic needs grp * nsx >= 2)
     o.bx0 = 0; o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx);
-    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll<M, SK, R>), dim3(xcd_grid_blocks(grp, nsx, nby)), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
+    o.band = band_mode ? cdiv(nby, 8) : 0;
+    const unsigned nblk = o.band ? xcd_band_blocks(grp, nsx, nby) : xcd_grid_blocks(grp, nsx, nby);
+    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll<M, SK, R>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
     *done = true;
     return ISX_OK;
 }
@@ -2357,7 +2362,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
-    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0; o.xmagic = 0;
+    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0; o.xmagic = 0; o.band = 0;
     if (windowed) {
         // the kernels keep addressing the mosaic's columns: the mats' origins move left by the window's first column (a multiple of
         // ISX_WINDOW_GRANULE, so every alignment is kept and a block of the last step starts exactly there), the right crop is the

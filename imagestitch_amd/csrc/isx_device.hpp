@@ -87,6 +87,20 @@ __device__ __forceinline__ bool xcd_block(unsigned L, int grp, int gx, int gy, u
     return by < gy;
 }
 
+// The same walk with every XCD owning ONE contiguous band of `band` block rows (band = ceil(gy / 8)) instead of every 8th group: the
+// groups an XCD works on one after the other are vertically adjacent, so the halo rows two groups share are still in that XCD's L2
+// when the second group reads them (a group's working set is a fraction of the 4 MB).  Right when the work per block row is even
+// from top to bottom (a pair's overlap is a vertical stripe).  Launch xcd_band_blocks(grp, gx, gy) blocks.
+__device__ __forceinline__ bool xcd_band_block(unsigned L, int grp, int gx, int gy, int band, unsigned magic, int& bx, int& by) {
+    const unsigned xcd = L & 7u, j = L >> 3, per = (unsigned)(grp * gx);
+    const unsigned g = __umulhi(j, magic), r = j - g * per;
+    const unsigned c = grp == 2 ? r >> 1 : r / (unsigned)grp;
+    const unsigned rb = g * (unsigned)grp + (r - c * (unsigned)grp);      // block row inside the band
+    bx = (int)c;
+    by = (int)(xcd * (unsigned)band + rb);
+    return (rb < (unsigned)band) & (by < gy);
+}
+
 // IEEE division a / z by the hardware's own recurrence, written out so that several numerators share one reciprocal and two of them
 // ride in one packed FMA:  r1 = r0 + r0 (1 - z r0);  q0 = a r1;  q1 = q0 + r1 (a - z q0);  q = q1 + r1 (a - z q1)   with r0 = v_rcp_f32(z).
 // This is what v_div_scale / v_rcp / v_fma x 5 / v_div_fmas / v_div_fixup compute whenever v_div_scale does not rescale: z and

@@ -98,4 +98,6 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline unsigned xcd_magic(int grp, int gx) { return 0xFFFFFFFFu / (unsigned)(grp * gx) + 1u; }
 inline unsigned xcd_grid_blocks(int grp, int gx, int gy) { return (unsigned)(8 * cdiv(cdiv(gy, grp), 8) * grp) * (unsigned)gx; }
 
+inline unsigned xcd_band_blocks(int grp, int gx, int gy) { return (unsigned)(8 * cdiv(cdiv(gy, 8), grp) * grp) * (unsigned)gx; }
+
 }  // namespace isx

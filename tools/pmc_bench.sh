@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 n=0
 for grp in "$@"; do
   n=$((n+1)); P=/tmp/pmc_bench_$n; rm -rf $P
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $P -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dropin --no-live-traffic $BENCH_ARGS > /tmp/pmc_bench_$n.log 2>&1
+  timeout ${PASS_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $P -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dropin --no-live-traffic $BENCH_ARGS > /tmp/pmc_bench_$n.log 2>&1
   python - "$P" "${KFILTER:-k_}" >> $out <<'PY'
 import csv, glob, collections, re, sys
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
