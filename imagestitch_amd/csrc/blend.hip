@@ -1663,42 +1663,60 @@ int flush_deferred(isx_blender* b) {
 // The last collapse step as the rolling kernel (collapse_roll.inc) when its limits hold: coarse columns [cx_lo, cx_hi) of level 1 in
 // strips of RL_CW columns x R rows, one wave each, dealt to the XCDs in groups of two strip rows (xcd_block).  *done = false: the
 // caller launches k_collapse_gather instead.  ISX_ROLL=0 forces that (A/B runs); ISX_ROLL_R picks the strip height.
-template <int M, int SK, int R>
+// most tiles that reach any one strip of RL_CW x R coarse pixels: every tile covers a rectangle of strip indices; the deepest overlap of
+// those rectangles is found on the grid of their corners (at most 2 n x 2 n cells)
+inline int roll_max_tiles(const TileSet& ts, const LevelBuf& coarse, int cx_lo, int cx_hi, int R) {
+    const int nsx = cdiv(cx_hi - cx_lo, RL_CW), nsy = cdiv(coarse.rows, R);
+    int x0[DEF_MAX], x1[DEF_MAX], y0[DEF_MAX], y1[DEF_MAX], m = 0;
+    for (int t = 0; t < ts.n; ++t) {
+        // strip sx covers fine columns [2 (cx_lo + sx RL_CW), + 2 RL_CW); it is reached when that interval meets [x_tl, x_tl + w)
+        const int fx0 = ts.x_tl[t] - 2 * cx_lo, fx1 = fx0 + ts.w[t], fy0 = ts.y_tl[t], fy1 = fy0 + ts.h[t];
+        if (fx1 <= 0 || fy1 <= 0) continue;
+        const int a = fx0 > 0 ? fx0 / (2 * RL_CW) : 0, b = std::min(nsx - 1, (fx1 - 1) / (2 * RL_CW));
+        const int c = fy0 > 0 ? fy0 / (2 * R) : 0, d = std::min(nsy - 1, (fy1 - 1) / (2 * R));
+        if (a > b || c > d) continue;
+        x0[m] = a; x1[m] = b; y0[m] = c; y1[m] = d; ++m;
+    }
+    int most = 0;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {         // deepest point lies at (a left edge, a top edge)
+            const int px = x0[i], py = y0[j];
+            int cnt = 0;
+            for (int t = 0; t < m; ++t) cnt += (x0[t] <= px) & (px <= x1[t]) & (y0[t] <= py) & (py <= y1[t]);
+            most = std::max(most, cnt);
+        }
+    return most;
+}
+template <int M, int SK, int R, int MAXT>
 int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& coarse, OutMat o, int cx_lo, int cx_hi, double bytes, bool* done) {
     const int nsx = cdiv(cx_hi - cx_lo, RL_CW), nsy = cdiv(coarse.rows, R), nby = cdiv(nsy, ROLL_WAVES);
     if (nsx <= 0 || nsy <= 0) return ISX_OK;
-    for (int sy = 0; sy < nsy; ++sy)          // no strip may be reached by more than ROLL_MAXT tiles
-        for (int sx = 0; sx < nsx; ++sx) {
-            const int x0 = 2 * (cx_lo + sx * RL_CW), y0 = 2 * sy * R;
-            int cnt = 0;
-            for (int t = 0; t < ts.n; ++t)
-                cnt += !((x0 >= ts.x_tl[t] + ts.w[t]) | (x0 + 2 * RL_CW <= ts.x_tl[t]) | (y0 >= ts.y_tl[t] + ts.h[t]) | (y0 + 2 * R <= ts.y_tl[t]));
-            if (cnt > ROLL_MAXT) return ISX_OK;
-        }
     static const int band_mode = [] { const char* e = getenv("ISX_ROLL_BAND"); return e ? atoi(e) : 1; }();
     static const int grp_sel = [] { const char* e = getenv("ISX_ROLL_GRP"); return e ? atoi(e) : 2; }();
     const int grp = std::max(grp_sel, nsx == 1 ? 2 : 1);      // (xcd_magic needs grp * nsx >= 2)
     o.bx0 = 0; o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx);
     o.band = band_mode ? cdiv(nby, 8) : 0;
     const unsigned nblk = o.band ? xcd_band_blocks(grp, nsx, nby) : xcd_grid_blocks(grp, nsx, nby);
-    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll<M, SK, R>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
+    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll<M, SK, R, MAXT>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
     *done = true;
     return ISX_OK;
 }
 template <int M, int SK>
 int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, const LevelBuf& coarse, const OutMat& o, int cx_lo, int cx_hi, double bytes, bool* done) {
     static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
-    static const int rsel = [] { const char* e = getenv("ISX_ROLL_R"); return e ? atoi(e) : 1; }();
+    static const int rsel = [] { const char* e = getenv("ISX_ROLL_R"); return e ? atoi(e) : 2; }();      // rows per wave (tuning runs only)
     *done = false;
     if constexpr (SK == SK_U8) {
         if (!mode || coarse.cols < 2 || (unsigned long long)coarse.rows * coarse.cols * 16ull >= (1ull << 32)) return ISX_OK;
         for (int t = 0; t < ts.n; ++t)
-            if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].iend == 0u ||      // iend != 0: CV_8UC3 below 2 GiB, 32-bit offsets
+            if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].rows < 2 || ts.s0[t].iend == 0u ||      // iend != 0: CV_8UC3 below 2 GiB, 32-bit offsets
                 (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return ISX_OK;
-        if constexpr (M == M_F32) {
-            if (rsel == 2) return launch_collapse_roll_r<M, SK, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
-        }
-        return launch_collapse_roll_r<M, SK, 1>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        // two rows per wave while at most two tiles reach a strip (a pair, a row of tiles with narrow overlaps); one row and a third slot
+        // for panoramas whose tiles overlap their second neighbours (BASELINE config 5); k_collapse_gather beyond that
+        if (rsel != 1 && roll_max_tiles(ts, coarse, cx_lo, cx_hi, 2) <= 2) return launch_collapse_roll_r<M, SK, 2, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        const int most = roll_max_tiles(ts, coarse, cx_lo, cx_hi, 1);
+        if (most <= 2) return launch_collapse_roll_r<M, SK, 1, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        if (most <= 3) return launch_collapse_roll_r<M, SK, 1, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
     }
     return ISX_OK;
 }
