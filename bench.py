@@ -30,10 +30,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def measured_traffic(kernel, args, live=True):
+    measured_traffic.all_kernels = None
     """HBM (fabric) bytes per launch of `kernel` from rocprofv3's PMC counters, (2 x FETCH_SIZE + WRITE_SIZE) KiB with FETCH and WRITE in
     separate passes (tools/measure_traffic.py; the factor 2 is calibrated for the kernels' access shapes, profiles/round2_fetch_calib.txt).
     live: collected NOW, by two short child runs of this command under `rocprofv3 --kernel-trace --pmc X` (about 30 s); when rocprofv3 is
-    missing or a pass fails, the committed measurement of the same command (profiles/round2_traffic.json) is returned instead.
+    missing or a pass fails, the committed measurement of the same command (profiles/round3_traffic.json) is returned instead.
     Returns (bytes or None, source)."""
     import shutil
     import subprocess
@@ -48,16 +49,17 @@ def measured_traffic(kernel, args, live=True):
                                env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300)
                 d = json.load(open(out))
             k = d["kernels"][kernel]
+            measured_traffic.all_kernels = {n: v["traffic_bytes"] for n, v in d["kernels"].items()}
             return k["traffic_bytes"], ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate child passes of this "
                                         "command (tools/measure_traffic.py), (2 x %.0f + %.0f) KiB per launch" % (k["FETCH_SIZE_KiB"], k["WRITE_SIZE_KiB"]))
         except Exception:
             pass
     try:
-        path = os.path.join(ROOT, "profiles", "round2_traffic.json")
+        path = os.path.join(ROOT, "profiles", "round3_traffic.json")
         d = json.load(open(path))
         if d.get("bench_args", []) != [] or args.precision != "f32" or args.bands != 5 or args.tiles != 2 or args.width != 3840 or args.kind != "cylindrical":
             return None, "no PMC measurement of this command"
-        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round2_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
+        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round3_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
                                                       "rocprofv3 was not usable in this run)")
     except Exception:
         return None, "no PMC measurement of this command"
@@ -284,8 +286,10 @@ def main():
                     help="one GPU, no gather: run what rank R of W would run under --shard strips (its share of the compute, measurable here)")
     ap.add_argument("--gather", default="chunk", choices=["chunk", "single"],
                     help="N > 1: all-gather the rank's block pair by pair behind each blend (default), or as ONE collective per step")
-    ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx"],
-                    help="N > 1: torch.distributed (RCCL) or the library's own RCCL communicator (isx_gather_*)")
+    ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx", "p2p"],
+                    help="N > 1: torch.distributed (RCCL), the library's own RCCL communicator (isx_gather_*), or the direct schedule "
+                         "(isx_gather_p2p_*: every chunk copied straight into every rank's buffer, one stream per destination - tells RCCL's "
+                         "schedule from the links)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cycle", default="deferred", choices=["deferred", "copy", "eager"],
@@ -394,6 +398,7 @@ def main():
     # the transfer is the lever.  --gather single: ONE all-gather per step, overlapped with the next step only.
     # --gather-backend torch: torch.distributed (RCCL); isx: the library's own communicator (isx_gather_*, for C++ pipelines).
     send, gather_buf, comm, ev_pair, ev_gather, chunks, isx_g = None, None, None, None, None, None, None
+    p2p = False
     if use_dist:
         shapes = [tuple(p.out.shape) for p in pairs]
         # rows of the send block padded to 4 bytes (at most 3 bytes per row more on the wire): the last collapse step then
@@ -417,6 +422,10 @@ def main():
             views.append(vs)
         if args.gather_backend == "isx":
             isx_g = mosaic.IsxGather(local)
+        elif args.gather_backend == "p2p":
+            isx_g = mosaic.IsxGather(local, collective=False)
+            gather_buf = isx_g.p2p_setup(n_out)          # the library's own hipMalloc, exported to the peers through HIP IPC
+            p2p = True
     if args.graph:
         if use_dist:
             for p, v in zip(pairs, views[0]):
@@ -428,7 +437,9 @@ def main():
     def post_chunk(b, i):
         """all-gather of pair i's mosaic (chunk i of send[b]) on the communication stream, behind ev_pair[b][i]"""
         off, n = chunks[i]
-        if isx_g is not None:
+        if p2p:
+            isx_g.p2p_chunk(send[b], off, n, ev_pair[b][i])
+        elif isx_g is not None:
             isx_g.chunk(send[b], off, n, gather_buf, ev_pair[b][i])
         else:
             comm.wait_event(ev_pair[b][i])
@@ -436,7 +447,9 @@ def main():
                 mosaic.gather_chunk(send[b], off, n, gather_buf)
 
     def post_block(b):
-        if isx_g is not None:
+        if p2p:
+            isx_g.p2p_chunk(send[b], 0, n_out, ev_pair[b][-1])
+        elif isx_g is not None:
             isx_g.chunk(send[b], 0, n_out, gather_buf, ev_pair[b][-1])
         else:
             comm.wait_event(ev_pair[b][-1])
@@ -445,7 +458,9 @@ def main():
 
     def gathers_done(b):
         """record `send[b] has been read by its gathers` for the step that reuses it"""
-        if isx_g is not None:
+        if p2p:
+            isx_g.p2p_wait(comm)
+        elif isx_g is not None:
             isx_g.wait(comm)
         ev_gather[b].record(comm)
 
@@ -506,6 +521,7 @@ def main():
         p.step_sync()
     torch.cuda.synchronize()
     ent = _lib.profile_entries()
+    ent_step = {k: dict(v) for k, v in ent.items()}      # the serialised step: every launch of every pair, bracketed
     per_kernel = {k: {"ms": round(v["ms"], 4), "launches": v["launches"], "alg_MB": round(v["alg_bytes"] / 1e6, 2)} for k, v in ent.items()}
     # dominant kernel = the heaviest single launch of the step (largest average launch duration)
     dominant = max(ent.items(), key=lambda kv: kv[1]["ms"] / max(kv[1]["launches"], 1))[0] if ent else None
@@ -557,7 +573,10 @@ def main():
         dt_c = time.perf_counter() - t1
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            if isx_g is not None:
+            if p2p:
+                isx_g.p2p_chunk(send[0], 0, n_out)
+                isx_g.p2p_wait()
+            elif isx_g is not None:
                 isx_g.all(send[0], gather_buf)
             else:
                 mosaic.gather_mosaics(send[0], gather_buf)
@@ -587,6 +606,21 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5),
                     "alg_bytes_per_launch": int(bytes_per_launch), "launches": e["launches"], "bracketed_every": SAMPLE}
         pair_ms = dt / args.steps / args.pairs * 1e3
+        # the whole step against HBM: the kernels' own algorithmic bytes (every input read once, every output written once) and, when
+        # the PMC passes ran, the fabric bytes they actually moved, both over the measured step time
+        step_alg = sum(v["alg_bytes"] for v in ent_step.values()) / max(len(pairs), 1)
+        step_hbm = {"alg_bytes_per_pair": int(step_alg), "frac_alg": round(step_alg / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic_bytes_per_pair": None, "frac_traffic": None}
+        allk = getattr(measured_traffic, "all_kernels", None)
+        if allk:
+            tr = 0.0
+            for name, v in ent_step.items():
+                per = allk.get(name) or allk.get("k_" + name)
+                if per is None and name == "warp_img_mask":
+                    per = allk.get("warp_img_mask")
+                if per is not None:
+                    tr += per * v["launches"] / max(len(pairs), 1)
+            step_hbm["traffic_bytes_per_pair"] = int(tr)
+            step_hbm["frac_traffic"] = round(tr / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out = {
             "metric": "Mpix/s warp+5-band-blend @4K pair", "value": round(mpix_step * args.steps / dt, 1), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -601,16 +635,22 @@ def main():
                     "tiles_this_rank": pairs[0].active} if strips else {}),
                 "pairs_per_gpu": args.pairs, "streams": len(pstreams), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
-            "pipeline_roofline": {"alg_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
-                                  "achieved_GBs": round(bm["total"] / (pair_ms * 1e-3) / 1e9, 1), "frac": round(bm["total"] / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
+            # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them
+            "model_rate": {"model_bytes_per_pair": int(bm["total"]), "warp": int(bm["warp"]), "feed": int(bm["feed"]), "blend": int(bm["blend"]),
+                           "model_bytes_per_step_time_GBs": round(bm["total"] / (pair_ms * 1e-3) / 1e9, 1),
+                           "note": "SURVEY's work model divided by the measured step time; not a bandwidth (see step_hbm for bytes actually moved)"},
             "roofline": roof,
+            "step_hbm": step_hbm,
             "kernels_ms_one_step": per_kernel,
         }
         if split:
             dt_c, dt_g, nsend = split
-            out["multi_gpu"] = {"without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),
+            out["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),
                                 "gather_alone_ms": round(dt_g / args.steps * 1e3, 4), "send_bytes_per_rank": nsend,
-                                "gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1),
+                                # bytes every rank RECEIVES from its peers / gather time; with one rank nothing crosses a link: the local copy's rate instead
+                                **({"gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1)} if world > 1 else
+                                   {"local_copy_GBs": round(nsend / (dt_g / args.steps) / 1e9, 1)}),
                                 "gather": args.gather, "gather_backend": args.gather_backend,
                                 "note": "value = steps with the gathers overlapped with the blends that follow them; the two legs here are timed after "
                                         "it, each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}

@@ -105,6 +105,11 @@ _SIGS = {
     "isx_gather_chunk_ptr": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)],
     "isx_gather_wait": [C.c_void_p, C.c_void_p],
     "isx_gather_synchronize": [C.c_void_p],
+    "isx_gather_p2p_alloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p],
+    "isx_gather_p2p_open": [C.c_void_p, C.c_char_p],
+    "isx_gather_p2p_chunk": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p],
+    "isx_gather_p2p_wait": [C.c_void_p, C.c_void_p],
+    "isx_gather_p2p_synchronize": [C.c_void_p],
     "isx_selftest_division": [C.c_int, C.c_int, C.c_ulonglong, _IP],
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],

@@ -182,7 +182,9 @@ class IsxGather:
     """The same collective through the C-ABI (isx_gather_*: an RCCL communicator owned by the library, for pipelines without
     torch).  The 128-byte rendezvous id travels over whatever the caller has; here: torch.distributed's object broadcast."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, collective=True):
+        """collective=False: no RCCL communicator (only the direct schedule p2p_* is available; any torch.distributed backend will do
+        for the handle exchange)."""
         import ctypes as C
         import torch.distributed as dist
         from . import _lib
@@ -190,6 +192,10 @@ class IsxGather:
         self._check = _lib.check
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         ident = [None]
+        if not collective:
+            self._h = C.c_void_p()
+            self._check(self._lib.isx_gather_create(self.world, self.rank, None, int(device), C.byref(self._h)))
+            return
         if self.rank == 0:
             buf = C.create_string_buffer(128)
             self._check(self._lib.isx_gather_unique_id(buf))
@@ -226,6 +232,44 @@ class IsxGather:
 
     def synchronize(self):
         self._check(self._lib.isx_gather_synchronize(self._h))
+
+    # ---- the direct schedule (isx_gather_p2p_*): every chunk copied straight into every rank's receive buffer over its own link ----
+    def p2p_setup(self, block_bytes, group=None):
+        """Allocates this rank's receive buffer (world x block_bytes, the library's own hipMalloc: an IPC handle names a whole
+        allocation), exchanges the 64-byte HIP IPC handles and maps every peer's buffer.  Returns the buffer as a torch uint8 tensor
+        (a view of the library's memory: it lives as long as this object)."""
+        import torch
+        import torch.distributed as dist
+        C = self._C
+        n = self.world * int(block_bytes)
+        ptr, handle = C.c_void_p(), C.create_string_buffer(64)
+        self._check(self._lib.isx_gather_p2p_alloc(self._h, n, C.byref(ptr), handle))
+        handles = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(handles, handle.raw, group=group)
+        else:
+            handles[0] = handle.raw
+        self._check(self._lib.isx_gather_p2p_open(self._h, b"".join(handles)))
+
+        class _Mem:      # __cuda_array_interface__ holder: torch wraps the pointer without copying
+            pass
+        m = _Mem()
+        m.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr.value), False), "version": 2}
+        self._p2p_keep = m
+        self.p2p_buf = torch.as_tensor(m, device=torch.device("cuda", torch.cuda.current_device()))
+        return self.p2p_buf
+
+    def p2p_chunk(self, send, offset, count, ready_event=None):
+        ev = self._C.c_void_p(ready_event.cuda_event) if ready_event is not None else None
+        self._check(self._lib.isx_gather_p2p_chunk(self._h, self._C.c_void_p(send.data_ptr()), send.numel() * send.element_size(), offset, count, ev))
+
+    def p2p_wait(self, stream=None):
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self._check(self._lib.isx_gather_p2p_wait(self._h, self._C.c_void_p(st.cuda_stream)))
+
+    def p2p_synchronize(self):
+        self._check(self._lib.isx_gather_p2p_synchronize(self._h))
 
 
 def unpack_blocks(gathered_row, shapes):

@@ -325,7 +325,8 @@ int isx_blend_pair_linear_release(void);
  * The library loads librccl.so.1 at the first of these calls (dlopen; inside a torch process that is torch's own copy).
  *   isx_gather_unique_id : rank 0 creates the 128-byte rendezvous id and hands it to the other ranks by any means it has (a file,
  *                          a socket, MPI_Bcast, torch.distributed.broadcast_object_list).
- *   isx_gather_create    : collective over all ranks; `device` is this rank's GPU.
+ *   isx_gather_create    : collective over all ranks; `device` is this rank's GPU.  id == NULL: no RCCL communicator is created (no
+ *                          collective call needed) and only the direct schedule below is available.
  *   isx_gather_all       : ONE all-gather of `bytes` bytes from `send` into recv[rank * bytes ...) on `hip_stream`.
  *   isx_gather_chunk     : the same block gathered chunk by chunk (a chunk = one pair's mosaic, [offset, offset + bytes) of the send
  *                          block): enqueued on the handle's own communication stream behind `ready_event` (a hipEvent_t the caller
@@ -346,6 +347,21 @@ int isx_gather_chunk(isx_gather* g, const void* send_base, size_t block_bytes, s
 int isx_gather_chunk_ptr(const isx_gather* g, void* recv_base, size_t offset, size_t bytes, int rank, void** ptr);
 int isx_gather_wait(isx_gather* g, void* hip_stream);
 int isx_gather_synchronize(isx_gather* g);
+/* The direct schedule beside the collective (xGMI is point to point: a rank's block crosses each of its world - 1 links once whatever
+ * the schedule; here the rank issues the world - 1 device-to-device copies itself, one stream per destination, instead of leaving rings
+ * and channels to RCCL - bench.py --gather-backend p2p against torch / isx tells the schedule from the links):
+ *   isx_gather_p2p_alloc : this rank's receive buffer (world x block bytes, its own hipMalloc) and its 64-byte HIP IPC handle, which
+ *                          travels to the other ranks by whatever the caller has (as the unique id does);
+ *   isx_gather_p2p_open  : maps every rank's buffer (handles: world x 64 bytes, in rank order), creates the per-destination streams;
+ *   isx_gather_p2p_chunk : bytes [offset, offset + bytes) of the send block copied into every rank's buffer (this rank's own
+ *                          included) behind `ready_event`, same layout as isx_gather_chunk (isx_gather_chunk_ptr applies);
+ *   isx_gather_p2p_wait  : makes `hip_stream` wait for this rank's copies enqueued so far (its send block may then be rewritten);
+ *                          arrival on the destination ranks is the callers' to establish, as after any one-sided put.                 */
+int isx_gather_p2p_alloc(isx_gather* g, size_t bytes, void** ptr, unsigned char handle[64]);
+int isx_gather_p2p_open(isx_gather* g, const unsigned char* handles);
+int isx_gather_p2p_chunk(isx_gather* g, const void* send_base, size_t block_bytes, size_t offset, size_t bytes, void* ready_event);
+int isx_gather_p2p_wait(isx_gather* g, void* hip_stream);
+int isx_gather_p2p_synchronize(isx_gather* g);
 
 /* ---- self-test --------------------------------------------------------------------------------- */
 /* The fused warp kernel divides x / z and y / z with one shared reciprocal and the hardware division's own recurrence

@@ -230,7 +230,9 @@ def test_full_size_4k_pair(gpu, oracle):
     imgs = [synth.make_tile(H, W, i) for i in range(2)]
     dev = torch.device("cuda:0")
     for prec in (gpu.PREC_I16, gpu.PREC_F32):
-        ps = PairStitcher([torch.from_numpy(i).to(dev) for i in imgs], K, Rs, F, "cylindrical", 5, prec, 0, None, "int16")
+        # the fp32 blender writes (and is compared as) CV_32FC3: after saturate_cast<short> a sub-LSB difference could not show
+        f32 = prec == gpu.PREC_F32
+        ps = PairStitcher([torch.from_numpy(i).to(dev) for i in imgs], K, Rs, F, "cylindrical", 5, prec, 0, None, "float32" if f32 else "int16")
         out, omask = ps.step()
         out, omask = out.cpu().numpy(), omask.cpu().numpy()
         if prec == gpu.PREC_I16:
@@ -247,8 +249,9 @@ def test_full_size_4k_pair(gpu, oracle):
         ob.prepare(ps.corners, ps.sizes)
         for i in range(2):
             ob.feed(o_warp[i].astype(np.int16), seam[i], ps.corners[i])
-        od, om = ob.blend(False)
+        od, om = ob.blend(f32)
         assert np.array_equal(omask, om)
+        assert out.dtype == od.dtype == (np.float32 if f32 else np.int16)
         assert np.array_equal(out, od), "4K blend differs (precision %d)" % prec
         # properties
         union = np.zeros_like(omask)

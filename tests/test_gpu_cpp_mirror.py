@@ -21,7 +21,8 @@ def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path, demo):
     inc = ["-I", os.path.join(ROOT, "include")]
     if demo == "cv_adapter_demo":
         inc = ["-I", os.path.join(ROOT, "tests", "cpp", "opencv_stub")] + inc
-    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall"] + inc + [os.path.join(ROOT, "tests", "cpp", demo + ".cpp"),
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-Wextra", "-Wsuggest-override", "-Woverloaded-virtual", "-Werror=suggest-override",
+                           "-Werror=overloaded-virtual"] + inc + [os.path.join(ROOT, "tests", "cpp", demo + ".cpp"),
                            "-o", exe, "-L", lib_dir, "-limagestitch_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     W, H, F = 420, 260, 330.0
     imgs = [synth.make_tile(H, W, 40 + i) for i in range(2)]

@@ -102,6 +102,18 @@ def _worker_rccl_world1(rank, world, port, ret):
     send = torch.randint(0, 256, (3 * 1000 + 8,), dtype=torch.uint8, device=dev, generator=g)
     chunks = [(0, 1000), (1000, 1000), (2000, 1008)]
     ok = True
+    # the direct schedule (isx_gather_p2p_*) at world 1: the rank's own buffer is its only destination
+    ig = mosaic.IsxGather(0, collective=False)
+    out = ig.p2p_setup(send.numel())
+    out.zero_()
+    ev = torch.cuda.Event(); ev.record()
+    for off, n in chunks:
+        ig.p2p_chunk(send, off, n, ev)
+    ig.p2p_wait()
+    torch.cuda.synchronize()
+    for off, n in chunks:
+        ok = ok and torch.equal(mosaic.chunk_view(out, world, off, n, rank), send[off:off + n])
+    del out, ig
     for backend in ("torch", "isx"):
         ig = mosaic.IsxGather(0) if backend == "isx" else None
         out = torch.zeros((world * send.numel(),), dtype=torch.uint8, device=dev)
@@ -137,4 +149,152 @@ def test_rccl_gather_whole_block_and_chunks_world1(gpu):
     import torch.multiprocessing as mp
     ret = mp.Manager().dict()
     mp.spawn(_worker_rccl_world1, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret.get(0), dict(ret)
+
+
+def _worker_p2p_world2(rank, world, port, ret):
+    """Two processes on cuda:0 push their blocks into each other's receive buffers through HIP IPC (no RCCL: it refuses two ranks on
+    one device; gloo carries the 64-byte handles and the barriers)."""
+    import torch
+    import torch.distributed as dist
+    from imagestitch_amd import mosaic
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+    chunks = [(0, 4096), (4096, 70000), (74096, 1000)]
+    n = sum(c[1] for c in chunks)
+    send = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g)
+    ig = mosaic.IsxGather(0, collective=False)
+    buf = ig.p2p_setup(n)
+    buf.zero_()
+    torch.cuda.synchronize(); dist.barrier()              # nobody writes into a buffer that is still being cleared
+    ev = torch.cuda.Event(); ev.record()
+    for off, c in chunks:
+        ig.p2p_chunk(send, off, c, ev)
+    ig.p2p_synchronize()                                   # this rank's puts have landed ...
+    dist.barrier()                                         # ... and so have everybody's
+    torch.cuda.synchronize()
+    ok = True
+    for r in range(world):
+        gr = torch.Generator(device=dev); gr.manual_seed(100 + r)
+        expect = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=gr)
+        for off, c in chunks:
+            ok = ok and torch.equal(mosaic.chunk_view(buf, world, off, c, r), expect[off:off + c])
+    ret[rank] = bool(ok)
+    dist.barrier()
+    del buf, ig
+    dist.destroy_process_group()
+
+
+def test_p2p_direct_gather_world2_on_one_gpu(gpu):
+    import torch.multiprocessing as mp
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_p2p_world2, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _worker_config4_rank_step(rank, world, port, ret):
+    """BASELINE config 4's per-rank step at full size: 4 pairs of 4K tiles on 4 streams, each blend writing its CV_8UC3 mosaic straight
+    into the pitched send block, the block gathered pair by pair behind each blend through RCCL (torch.distributed and the library's own
+    communicator) and through the direct schedule; the gathered block equals the serial runs pair by pair and the oracle for pair 0."""
+    import torch
+    import torch.distributed as dist
+    import imagestitch_amd as I
+    from imagestitch_amd import mosaic, synth
+    from imagestitch_amd.pipeline import PairStitcher
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    W4, H4, F4, NP = 3840, 2160, 3000.0, 4
+    K, Rs = synth.camera_pair(W4, H4, F4)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NP)]
+    host_imgs = [[synth.make_tile(H4, W4, 40 * p + i) for i in range(2)] for p in range(NP)]
+    serial = []
+    for p in range(NP):                                     # the reference: every pair alone, on the default stream
+        ps = PairStitcher([torch.from_numpy(i).to(dev) for i in host_imgs[p]], K, Rs, F4, "cylindrical", 5, I.PREC_F32, 0, None, "uint8")
+        out, _ = ps.step()
+        serial.append(out.cpu().numpy().copy())
+        del ps
+    pairs = [PairStitcher([torch.from_numpy(i).to(dev) for i in host_imgs[p]], K, Rs, F4, "cylindrical", 5, I.PREC_F32, 0, streams[p], "uint8")
+             for p in range(NP)]
+    shapes = [tuple(p.out.shape) for p in pairs]
+    pitches = [(sh[1] * sh[2] + 3) // 4 * 4 for sh in shapes]
+    sizes = [sh[0] * pt for sh, pt in zip(shapes, pitches)]
+    n_out = sum(sizes)
+    send = torch.empty((n_out,), dtype=torch.uint8, device=dev)
+    chunks, off = [], 0
+    for p, (sh, pt, n) in enumerate(zip(shapes, pitches, sizes)):
+        pairs[p].out = send[off:off + n].as_strided(sh, (pt, sh[2], 1))
+        chunks.append((off, n)); off += n
+    ok = True
+    for backend in ("torch", "isx", "p2p"):
+        ig = None
+        if backend == "isx":
+            ig = mosaic.IsxGather(0)
+            gbuf = torch.zeros((world * n_out,), dtype=torch.uint8, device=dev)
+        elif backend == "p2p":
+            ig = mosaic.IsxGather(0, collective=False)
+            gbuf = ig.p2p_setup(n_out); gbuf.zero_()
+        else:
+            gbuf = torch.zeros((world * n_out,), dtype=torch.uint8, device=dev)
+        send.fill_(7)
+        torch.cuda.synchronize()
+        comm = torch.cuda.Stream(device=dev)
+        evs = [torch.cuda.Event() for _ in range(NP)]
+        for step in range(2):                               # the second step replays the planned one
+            for p in range(NP):
+                with torch.cuda.stream(streams[p]):
+                    pairs[p].step()
+                evs[p].record(streams[p])
+                o, n = chunks[p]
+                if backend == "p2p":
+                    ig.p2p_chunk(send, o, n, evs[p])
+                elif backend == "isx":
+                    ig.chunk(send, o, n, gbuf, evs[p])
+                else:
+                    comm.wait_event(evs[p])
+                    with torch.cuda.stream(comm):
+                        mosaic.gather_chunk(send, o, n, gbuf)
+            if backend == "p2p":
+                ig.p2p_wait(comm)
+            elif backend == "isx":
+                ig.wait(comm)
+            comm.synchronize()
+            for p in range(NP):
+                streams[p].wait_stream(comm)              # the next step overwrites the send block
+        torch.cuda.synchronize()
+        for p in range(NP):
+            pairs[p].check_plan()
+            o, n = chunks[p]
+            got = mosaic.chunk_view(gbuf, world, o, n, rank).as_strided(shapes[p], (pitches[p], shapes[p][2], 1)).cpu().numpy()
+            ok = ok and np.array_equal(got, serial[p])
+        del gbuf, ig
+    # pair 0 against the oracle (fp32 blend converted to CV_8U: blend + convertTo, W:315)
+    from oracle import capi as O
+    corners, warped, wmasks = [], [], []
+    for im, R in zip(host_imgs[0], Rs):
+        c, wi, _ = O.warp_u8(O.CYL, F4, K, R, im, O.LINEAR, O.BORDER_REFLECT)
+        _, wm, _ = O.warp_u8(O.CYL, F4, K, R, np.full((H4, W4), 255, np.uint8), O.NEAREST, O.BORDER_CONSTANT)
+        corners.append(c); warped.append(wi); wmasks.append(wm)
+    seam = synth.seam_masks(corners, wmasks)
+    mb = O.MultiBand(5, O.F32)
+    mb.prepare(corners, [(m.shape[1], m.shape[0]) for m in wmasks])
+    for wi, sm, c in zip(warped, seam, corners):
+        mb.feed(wi.astype(np.int16), sm, c)
+    of32, om = mb.blend(True)
+    o8 = np.clip(np.rint(of32), 0, 255).astype(np.uint8)     # saturate_cast<uchar>(cvRound(v)): round half to even
+    ok = ok and np.array_equal(serial[0], o8)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_per_rank_step_at_4k_with_chunked_gathers(gpu):
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_config4_rank_step, args=(1, _free_port(), ret), nprocs=1, join=True)
     assert ret.get(0), dict(ret)

@@ -36,6 +36,8 @@ ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_warp_
 
 
 def launch_name(kname, full):
+    if kname == "k_collapse_roll":       # round 3: the last collapse step without LDS
+        return "collapse_gather_final"
     if kname == "k_collapse_gather":
         return "collapse_gather_final" if re.search(r"k_collapse_gather<\d+, -?\d+, true", full) else "collapse_gather"
     if kname in ("k_pyr_down", "k_pyr_down_multi"):
