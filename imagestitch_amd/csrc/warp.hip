@@ -426,10 +426,8 @@ struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; };
 // one pixel of the fixed-point bilinear from its two 12-byte windows: window pixel 0 weighs wA, pixel 1 weighs wB (wA + wB = 32),
 // the upper row gy, the lower fy (gy + fy = 32): (sum of the BilinearTab_i products + 2^14) >> 15 == (S + 512) >> 10 with the
 // separable exact S (see k_warp_img_mask).  Returns b | g << 8 | r << 16.
-__device__ __forceinline__ unsigned sample_windows(const U3& v0, const U3& v1, unsigned o0, unsigned o1, unsigned wA, unsigned wB, unsigned gy, unsigned fy) {
-    const unsigned s0 = o0 & 3u, s1 = o1 & 3u;
-    const unsigned l0 = __builtin_amdgcn_alignbyte(v0.y, v0.x, s0), h0 = __builtin_amdgcn_alignbyte(v0.z, v0.y, s0);   // b0 g0 r0 b1 | g1 r1 . .
-    const unsigned l1 = __builtin_amdgcn_alignbyte(v1.y, v1.x, s1), h1 = __builtin_amdgcn_alignbyte(v1.z, v1.y, s1);
+// the same from the taps' own bytes: l = b0 g0 r0 b1, h = g1 r1 . . of the upper (0) and lower (1) row
+__device__ __forceinline__ unsigned sample_taps(unsigned l0, unsigned h0, unsigned l1, unsigned h1, unsigned wA, unsigned wB, unsigned gy, unsigned fy) {
     const unsigned wb = wA | (wB << 24), wgl = wA << 8, wgh = wB, wrl = wA << 16, wrh = wB << 8;
     const unsigned t0b = __builtin_amdgcn_udot4(l0, wb, 0u, false), t1b = __builtin_amdgcn_udot4(l1, wb, 0u, false);
     const unsigned t0g = __builtin_amdgcn_udot4(h0, wgh, __builtin_amdgcn_udot4(l0, wgl, 0u, false), false);
@@ -441,6 +439,12 @@ __device__ __forceinline__ unsigned sample_windows(const U3& v0, const U3& v1, u
     const unsigned c2 = mad24(t0r, gy, mad24(t1r, fy, 512u)) >> 10;
     return c0 | (c1 << 8) | (c2 << 16);
 }
+__device__ __forceinline__ unsigned sample_windows(const U3& v0, const U3& v1, unsigned o0, unsigned o1, unsigned wA, unsigned wB, unsigned gy, unsigned fy) {
+    const unsigned s0 = o0 & 3u, s1 = o1 & 3u;
+    const unsigned l0 = __builtin_amdgcn_alignbyte(v0.y, v0.x, s0), h0 = __builtin_amdgcn_alignbyte(v0.z, v0.y, s0);   // b0 g0 r0 b1 | g1 r1 . .
+    const unsigned l1 = __builtin_amdgcn_alignbyte(v1.y, v1.x, s1), h1 = __builtin_amdgcn_alignbyte(v1.z, v1.y, s1);
+    return sample_taps(l0, h0, l1, h1, wA, wB, gy, fy);
+}
 
 // cv::borderInterpolate(p, n, BORDER_REFLECT) for p in [-n, 2n - 1] (at most one reflection): p < 0 -> -p - 1 = ~p, p >= n -> 2n - 1 - p
 __device__ __forceinline__ int reflect_once(int p, int n2m1) {
@@ -448,8 +452,19 @@ __device__ __forceinline__ int reflect_once(int p, int n2m1) {
     return min(q, n2m1 - q);
 }
 
+// ablation study of the tile warp (tools/ab_libs.sh builds, profiles/round3_warp_ablation.txt): bit 0 no stores, bit 1 every window from
+// one cache-resident source row, bit 2 no transform (coordinates = a shift), bit 3 non-temporal stores; WARP_WAVES waves per workgroup
+#ifndef WARP_ABL
+#define WARP_ABL 0
+#endif
+#ifndef WARP_WAVES
+#define WARP_WAVES 4
+#endif
+#ifndef WARP_WPE
+#define WARP_WPE 7
+#endif
 template <int KIND, bool OUT16, bool VEC>
-__global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
+__global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu(WARP_WPE))) void k_warp_tile(WarpTileArgs a) {
     const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
     // A wave is 64 pixels wide and 4 rows tall (16 lanes x 4 pixels per row), a block 64 x 16: the band of border pixels along the
     // left and right edge of the warped tile is a few dozen pixels wide, so with 256 x 1 waves every row's first and last wave crossed
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     // where waves cross the image border (tier 2 below, the occasional generic pixel) and live several times longer than interior
     // waves - dispatched first they overlap with the rest of the launch, dispatched last they were its tail.
     const int by = (blockIdx.y & 1) ? (int)gridDim.y - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1);
-    const int dy = by * 16 + wv * 4 + (lane >> 4);
+    const int dy = by * (4 * WARP_WAVES) + wv * 4 + (lane >> 4);
     if (dy >= d.h || dx0 >= d.w) return;
     const bool whole = VEC && dx0 + 4 <= d.w;       // four real columns and dword-aligned rows: vector stores
     // ---- mapBackward (W:46-63): the transform of the thread's four columns in this row -------------------------------
@@ -499,6 +514,10 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         const f32x2 ax = div_by_refined(X[h], Z[h], r1), ay = div_by_refined(Y[h], Z[h], r1);
         tx[2 * h] = ax.x; tx[2 * h + 1] = ax.y; ty[2 * h] = ay.x; ty[2 * h + 1] = ay.y;
     }
+    if (WARP_ABL & 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tx[k] = (float)(32 * (dx0 + k) + 7); ty[k] = (float)(32 * dy + 5); Z[k >> 1] = splat2(1.f); }
+    }
     // z of the four pixels inside the division's guarded range?  (A NaN slips through min / max and is caught below: its quotient
     // is NaN, which no clamp leaves unchanged.)  Otherwise - z <= 0 (W:61) included - the generic code path does the thread's row.
     const float zmin = fminf(fminf(Z[0].x, Z[0].y), fminf(Z[1].x, Z[1].y)), zmax = fmaxf(fmaxf(Z[0].x, Z[0].y), fmaxf(Z[1].x, Z[1].y));
@@ -523,6 +542,8 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
     }
     unsigned m4 = 0xffffffffu;              // tier-1 pixels: cvRound(x) in [0, cols), cvRound(y) in [0, rows) -> mask 255 (W:213-214, W:232)
     if (__builtin_amdgcn_ballot_w64(!all1) == 0ull) {      // wave-uniform: every pixel of the wave is a tier-1 pixel
+        // (Byte-misaligned global_load_dwordx2 at the taps themselves - no window, no v_alignbyte - was tried in round 3: right bytes, but
+        // this gather then takes 62 us per pair of tiles instead of 45; the regular 6-byte stride of the collapse step does not mind.)
         unsigned o0[4], fxy[4];
         U3 v0[4], v1[4];
 #pragma unroll
@@ -530,6 +551,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             const unsigned bx = __float_as_uint(cxs[k] + RNE_MAGIC), by = __float_as_uint(cys[k] + RNE_MAGIC);
             fxy[k] = (bx & 31u) | ((by & 31u) << 8);
             o0[k] = mad24(__builtin_amdgcn_ubfe(by, 5, 18), step, mad24(__builtin_amdgcn_ubfe(bx, 5, 18), 3u, addr_c));
+            if (WARP_ABL & 2) o0[k] = mad24(__builtin_amdgcn_ubfe(bx, 5, 18), 3u, mis + 12u) - 0x60000u;      // row 0: cache-resident
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {       // all eight loads in flight together
@@ -553,6 +575,8 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         // bytes (end4: the end rounded up to a dword - the dword holding the last valid byte is readable as a whole) and the taps sit up
         // to six bytes into it: the window's dwords are then rotated by one before the usual byte alignment.
         const unsigned end4 = ((unsigned)(rows - 1) * step + (unsigned)cols * 3u + mis + 3u) & ~3u;
+        const bool big_enough = (cols >= 2) & (rows >= 3) & (end4 >= 12u);
+        const unsigned last_win = end4 >= 12u ? end4 - 12u : 0u;
         unsigned al0[4], al1[4], wab[4];      // aligned window starts
         unsigned shifts = 0;                  // byte offset of the taps inside their windows (0 .. 6), three bits per window
 #pragma unroll
@@ -561,7 +585,8 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             const int isx = (int)(__float_as_uint(cx + RNE_MAGIC) - 0x4B400000u), isy = (int)(__float_as_uint(cy + RNE_MAGIC) - 0x4B400000u);
             const int sx = isx >> 5, sy = isy >> 5, fx = isx & 31, fy = isy & 31;
             // one reflection at most: sx, sx + 1 in [-cols, 2 cols - 1], same for the rows
-            const bool ok = (cx == tx[k]) & (cy == ty[k]) & ((unsigned)(sx + cols) < (unsigned)(3 * cols - 1)) & ((unsigned)(sy + rows) < (unsigned)(3 * rows - 1));
+            // (sources too small for a window - a single column, fewer than 3 rows, fewer than 12 bytes - take the generic path and issue no window load)
+            const bool ok = big_enough & (cx == tx[k]) & (cy == ty[k]) & ((unsigned)(sx + cols) < (unsigned)(3 * cols - 1)) & ((unsigned)(sy + rows) < (unsigned)(3 * rows - 1));
             const int c0 = reflect_once(sx, 2 * cols - 1), c1 = reflect_once(sx + 1, 2 * cols - 1);
             const int r0 = reflect_once(sy, 2 * rows - 1), r1 = reflect_once(sy + 1, 2 * rows - 1);
             const int cb = min(min(c0, c1), cols - 2);                               // window = pixels cb, cb + 1
@@ -569,7 +594,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             if (!ok) generic = true;
             const unsigned cb3 = ok ? (unsigned)cb * 3u + mis : mis;
             const unsigned q0 = ok ? __umul24((unsigned)r0, step) + cb3 : mis, q1 = ok ? __umul24((unsigned)r1, step) + cb3 : mis;   // the taps' byte offsets
-            const unsigned a0 = min(q0 & ~3u, end4 - 12u), a1 = min(q1 & ~3u, end4 - 12u);
+            const unsigned a0 = min(q0 & ~3u, last_win), a1 = min(q1 & ~3u, last_win);
             al0[k] = a0; al1[k] = a1;
             shifts |= ((q0 - a0) << (6 * k)) | ((q1 - a1) << (6 * k + 3));
             wab[k] = wA | ((unsigned)fy << 8);
@@ -594,6 +619,7 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
         }
     }
     // ---- stores ------------------------------------------------------------------------------------------------------------
+    if ((WARP_ABL & 1) && d.w > -3) { if (px[0] + px[1] + px[2] + px[3] + m4 == 0x12345u) d.mask[0] = 1; return; }
     if (whole) {
         if constexpr (OUT16) {
             unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 6u));
@@ -606,11 +632,14 @@ __global__ __launch_bounds__(256) void k_warp_tile(WarpTileArgs a) {
             }
         } else {
             unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 3u));
-            q[0] = px[0] | (px[1] << 24);                                   // b0 g0 r0 b1
-            q[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);        // g1 r1 b2 g2
-            q[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);        // r2 b3 g3 r3
+            const unsigned q0 = px[0] | (px[1] << 24);                                   // b0 g0 r0 b1
+            const unsigned q1 = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);        // g1 r1 b2 g2
+            const unsigned q2 = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);        // r2 b3 g3 r3
+            if (WARP_ABL & 8) { __builtin_nontemporal_store(q0, q); __builtin_nontemporal_store(q1, q + 1); __builtin_nontemporal_store(q2, q + 2); }
+            else { q[0] = q0; q[1] = q1; q[2] = q2; }
         }
-        *(unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
+        if (WARP_ABL & 8) __builtin_nontemporal_store(m4, (unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)));
+        else *(unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
     } else {    // the partial group at the right edge, or destination rows that are not dword aligned: per-pixel stores
 #pragma unroll 1
         for (int k = 0; k < 4 && dx0 + k < d.w; ++k) {
@@ -1228,9 +1257,9 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             bx0 = std::min(w->col0, dw - 1) / 64; wcrop = std::min(w->col1, dw);
             bytes *= (double)(cdiv(wcrop, 64) - bx0) / cdiv(dw, 64);
         }
-        const dim3 gridt(cdiv(wcrop, 64) - bx0, cdiv(dh, 16));
+        const dim3 gridt(cdiv(wcrop, 64) - bx0, cdiv(dh, 4 * WARP_WAVES));
         const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0}};
-#define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(256), 0, wta)
+#define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(64 * WARP_WAVES), 0, wta)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
         if (!src_mask) {
             if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_TILE_K(true, true); else ISX_WARP_TILE_K(true, false); }
