@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--focal", type=float, default=3000.0)
     ap.add_argument("--yaw", type=float, default=0.36, help="the pair's cameras are rotated by -/+ yaw about the vertical axis")
     ap.add_argument("--kind", default="cylindrical", choices=["cylindrical", "spherical"],
-                    help="spherical (BASELINE config 5) implies --sync-roi: its ROI is a host-side border scan, there is no planned variant")
+                    help="spherical = BASELINE config 5's projector (its ROI: a border scan on the device + pole tests; planned and synchronous forms as for the cylinder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not collect roofline.traffic now (two child runs under rocprofv3 --pmc, ~30 s); report the committed measurement")
@@ -342,8 +342,6 @@ def main():
     W, H, F = args.width, args.height, args.focal
     NT = args.tiles
     K, Rs = synth.camera_ring(W, H, F, NT, 2.0 * args.yaw)   # NT = 2: synth.camera_pair(W, H, F, yaw)
-    if args.kind == "spherical":
-        args.sync_roi = True
     gen = torch.Generator(device=dev)
     pairs = []
     # --shard strips: this rank's column window of the panorama, from the rig alone (every rank derives the same strips)

@@ -804,6 +804,70 @@ __global__ __launch_bounds__(256) void k_roi_candidates(Proj p, int sw, int sh, 
         }
 }
 
+// ---- spherical projector: detectResultRoiByBorder on the device ---------------------------------------------------------------------
+// OpenCV's SphericalWarper finds its ROI from the source's BORDER pixels only (plus two pole tests, which are plain arithmetic on
+// K and R and stay on the host): 2 (W + H) mapForwards.  Round 2 evaluated them on the host (0.33 ms for an 8K tile, memoised) and had no
+// planned form.  Here one workgroup ranks the border pixels by monotone stand-ins as the cylinder's scan does -
+//   u = scale * atan2f(x_, z_)                   ~ the diamond angle d of (x_, z_)
+//   v = scale * (pi - acosf(w)), w = y_ / |r|    ~ w itself (v increases with w; NaN -> 0 as `w == w ? w : 0`)
+// - and either hands the pixels within a tolerance of the four extrema to the host (synchronous form: exact mapForward with the host's
+// libm on a handful of points, one round trip) or folds the extrema into the four keys that k_roi_check_rearm compares with the planned
+// ROI's stand-in intervals (planned form: no host round trip, capturable).
+__device__ __forceinline__ void forward_proxy_sph(const Proj& p, float x, float y, float& d, float& q) {
+    const float x_ = p.r_kinv[0] * x + p.r_kinv[1] * y + p.r_kinv[2];
+    const float y_ = p.r_kinv[3] * x + p.r_kinv[4] * y + p.r_kinv[5];
+    const float z_ = p.r_kinv[6] * x + p.r_kinv[7] * y + p.r_kinv[8];
+    const float ax = fabsf(x_), az = fabsf(z_);
+    const float t = ax * __builtin_amdgcn_rcpf(ax + az);
+    d = copysignf(z_ >= 0.f ? t : 2.f - t, x_);
+    const float w = y_ * __builtin_amdgcn_rsqf(x_ * x_ + y_ * y_ + z_ * z_);
+    q = (w == w) ? w : 0.f;
+}
+__device__ __forceinline__ void border_point(int i, int sw, int sh, int& x, int& y) {      // i in [0, 2 sw + 2 sh): top, bottom, left, right
+    if (i < sw) { x = i; y = 0; }
+    else if (i < 2 * sw) { x = i - sw; y = sh - 1; }
+    else if (i < 2 * sw + sh) { x = 0; y = i - 2 * sw; }
+    else { x = sw - 1; y = i - 2 * sw - sh; }
+}
+// keys != nullptr: planned form (atomics on the four keys, one block: no contention).  cand != nullptr: synchronous form.
+__global__ __launch_bounds__(1024) void k_roi_border_sph(Proj p, int sw, int sh, unsigned* keys, int* cand_xy, int cap, int* count) {
+    __shared__ float red[4][16];
+    const int n = 2 * sw + 2 * sh;
+    float dmin = 3.402823466e+38f, qmin = 3.402823466e+38f, dmax = -3.402823466e+38f, qmax = -3.402823466e+38f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        int x, y; float d, q;
+        border_point(i, sw, sh, x, y);
+        forward_proxy_sph(p, (float)x, (float)y, d, q);
+        dmin = (d < dmin) ? d : dmin; qmin = (q < qmin) ? q : qmin; dmax = (dmax < d) ? d : dmax; qmax = (qmax < q) ? q : qmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = fminf(dmin, __shfl_xor(dmin, o)); qmin = fminf(qmin, __shfl_xor(qmin, o));
+        dmax = fmaxf(dmax, __shfl_xor(dmax, o)); qmax = fmaxf(qmax, __shfl_xor(qmax, o));
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = dmin; red[1][wv] = qmin; red[2][wv] = dmax; red[3][wv] = qmax; }
+    __syncthreads();
+    dmin = red[0][0]; qmin = red[1][0]; dmax = red[2][0]; qmax = red[3][0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { dmin = fminf(dmin, red[0][k]); qmin = fminf(qmin, red[1][k]); dmax = fmaxf(dmax, red[2][k]); qmax = fmaxf(qmax, red[3][k]); }
+    if (keys != nullptr && threadIdx.x == 0) {
+        atomicMin(&keys[0], fkey(dmin)); atomicMin(&keys[1], fkey(qmin)); atomicMax(&keys[2], fkey(dmax)); atomicMax(&keys[3], fkey(qmax));
+    }
+    if (cand_xy == nullptr) return;
+    const float tol_d = 7.62939453125e-06f;                                   // as k_roi_candidates
+    const float tol_q = 4e-6f * fmaxf(fabsf(qmin), fabsf(qmax)) + 1e-9f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        int x, y; float d, q;
+        border_point(i, sw, sh, x, y);
+        forward_proxy_sph(p, (float)x, (float)y, d, q);
+        if (d <= dmin + tol_d || d >= dmax - tol_d || q <= qmin + tol_q || q >= qmax - tol_q) {
+            const int j = atomicAdd(count, 1);
+            if (j < cap) { cand_xy[2 * j] = x; cand_xy[2 * j + 1] = y; }
+        }
+    }
+}
+
 // sync-free path: the scanned extrema must lie inside the stand-in intervals of the planned ROI
 // (lo/hi: min d, min q, max d, max q; margins already applied by the host)
 struct RoiBounds { float lo[4], hi[4]; };
@@ -877,6 +941,28 @@ double proxy_d_of_u(double u, double scale) {
     return th < 0.0 ? -dd : dd;
 }
 double proxy_q_of_v(double v, double scale) { return v / scale; }
+// spherical: v = scale (pi - acos w)  =>  w = cos(pi - v / scale) = -cos(v / scale), increasing on [0, pi scale]
+double proxy_w_of_v(double v, double scale) {
+    const double pi = 3.14159265358979323846;
+    const double a = std::max(0.0, std::min(pi, v / scale));
+    return -std::cos(a);
+}
+
+// SphericalWarper::detectResultRoi's pole tests (OpenCV warpers.cpp): is the projection's north (v = pi scale) / south (v = 0) pole
+// inside the source image?  Plain arithmetic on K and R^T, no transcendental: always on the host.
+void sph_poles(const float k[9], const float rinv[9], int sw, int sh, bool* north, bool* south) {
+    *north = *south = false;
+    float x = rinv[1], y = rinv[4], z = rinv[7];
+    if (y > 0.f) {
+        float x_ = (k[0] * x + k[1] * y) / z + k[2], y_ = k[4] * y / z + k[5];
+        if (x_ > 0.f && x_ < sw && y_ > 0.f && y_ < sh) *north = true;
+    }
+    x = rinv[1]; y = -rinv[4]; z = rinv[7];
+    if (y > 0.f) {
+        float x_ = (k[0] * x + k[1] * y) / z + k[2], y_ = k[4] * y / z + k[5];
+        if (x_ > 0.f && x_ < sw && y_ > 0.f && y_ < sh) *south = true;
+    }
+}
 
 // static_cast<int>(extremum) == bound  <=>  extremum in (bound - 1, bound] / [bound, bound + 1) / (-1, 1)
 void trunc_interval(int bound, double& lo, double& hi) {
@@ -905,7 +991,7 @@ struct isx_warper {
     // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
     // queued scans behind the main stream's position AT THAT CALL (e.g. after the last warp of a step, so
     // that they run under the memory-bound pyramid kernels instead of under the next tile's warp)
-    struct Pending { Proj proj; int sw, sh; int planned[4]; };
+    struct Pending { Proj proj; int sw, sh; int planned[4]; float k[9], rinv[9]; };
     std::vector<Pending> pending;
     bool defer_verify = false;
     MatStage st_src, st_mask, st_dst, st_dmask, st_x, st_y;
@@ -981,15 +1067,32 @@ int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
     }
     unsigned* sk = (unsigned*)w->scan_side.p;
     for (const isx_warper::Pending& pd : w->pending) {
-        dim3 sgrid(cdiv(pd.sw, 256), cdiv(pd.sh, ROI_ROWS));   // ~8 K waves at 4K: one full-occupancy round
-        ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, pd.proj, pd.sw, pd.sh, sk, ROI_ROWS, (float4*)nullptr);
+        const bool sph = pd.proj.kind == ISX_WARP_SPHERICAL;
+        bool north = false, south = false;
+        if (sph) {
+            ISX_LAUNCH("roi_border_sph", 0.0, w->side, k_roi_border_sph, dim3(1), dim3(1024), 0, pd.proj, pd.sw, pd.sh, sk, (int*)nullptr, 0, (int*)nullptr);
+            sph_poles(pd.k, pd.rinv, pd.sw, pd.sh, &north, &south);
+        } else {
+            dim3 sgrid(cdiv(pd.sw, 256), cdiv(pd.sh, ROI_ROWS));   // ~8 K waves at 4K: one full-occupancy round
+            ISX_LAUNCH("roi_scan", 0.0, w->side, k_roi_scan, sgrid, dim3(256), 0, pd.proj, pd.sw, pd.sh, sk, ROI_ROWS, (float4*)nullptr);
+        }
         RoiBounds rb;
         for (int k = 0; k < 4; ++k) {
             double lo, hi;
             trunc_interval(pd.planned[k], lo, hi);
             const bool is_u = (k == 0 || k == 2);
-            double plo = is_u ? proxy_d_of_u(lo, pd.proj.scale) : proxy_q_of_v(lo, pd.proj.scale);
-            double phi = is_u ? proxy_d_of_u(hi, pd.proj.scale) : proxy_q_of_v(hi, pd.proj.scale);
+            double plo = is_u ? proxy_d_of_u(lo, pd.proj.scale) : (sph ? proxy_w_of_v(lo, pd.proj.scale) : proxy_q_of_v(lo, pd.proj.scale));
+            double phi = is_u ? proxy_d_of_u(hi, pd.proj.scale) : (sph ? proxy_w_of_v(hi, pd.proj.scale) : proxy_q_of_v(hi, pd.proj.scale));
+            if (sph) {
+                // a pole inside the image replaces the border's extremum by its own value (min / max with 0 or pi scale): where the planned
+                // bound IS the pole's, the border's extremum only has to lie on the border's side of it
+                const double pv = 3.14159265358979323846 * pd.proj.scale;
+                const double pole[2][4] = {{0.0, pv, 0.0, pv}, {0.0, 0.0, 0.0, 0.0}};
+                for (int q = 0; q < 2; ++q)
+                    if ((q == 0 ? north : south) && f2i_host((float)pole[q][k]) == pd.planned[k]) {
+                        if (k < 2) phi = is_u ? 2.0 : 1.0; else plo = is_u ? -2.0 : -1.0;
+                    }
+            }
             // margin: the stand-ins carry a few ulp of error; an extremum this close to an integer boundary is
             // not flagged (the check is a guard against a stale plan, not a proof)
             const double m = 4e-6 * std::max(1.0, std::max(std::fabs(plo), std::fabs(phi)));
@@ -1023,7 +1126,7 @@ int roi_stream_of(isx_warper* w, hipStream_t* out) {
 
 int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync_free, const int* planned) {
     hipStream_t st = w->stream;
-    if (w->kind != ISX_WARP_SPHERICAL && !sync_free) ISX_TRY(roi_stream_of(w, &st));
+    if (!sync_free) ISX_TRY(roi_stream_of(w, &st));
     size_t need = 64 + (size_t)CAND_CAP * 8;
     if (!w->scan.p) {   // keys armed once here; every consumer re-arms them (k_warp_img_mask / k_roi_rearm)
         ISX_TRY(w->scan.reserve(need));
@@ -1033,38 +1136,41 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     unsigned* keys = (unsigned*)w->scan.p;
     int* count = (int*)(keys + 4);
     int* cand = (int*)((char*)w->scan.p + 64);
-    if (w->kind == ISX_WARP_SPHERICAL) {
-        ISX_CHECK_ARG(!sync_free, ISX_ERR_UNSUPPORTED, "planned warp: spherical ROI is computed on the host; use isx_warper_warp_with_mask");
+    if (w->kind == ISX_WARP_SPHERICAL && !sync_free) {
         for (const auto& e : w->sph_memo)
             if (e.sw == sw && e.sh == sh && memcmp(&e.proj, &w->proj, sizeof(Proj)) == 0 && memcmp(e.k, w->k, sizeof(e.k)) == 0 && memcmp(e.rinv, w->rinv, sizeof(e.rinv)) == 0) {
                 std::copy(e.roi, e.roi + 4, roi);
                 if (mm) std::copy(e.mm, e.mm + 4, mm);
                 return ISX_OK;
             }
+        // detectResultRoiByBorder: the border pixels ranked on the device, the candidates for the four extrema evaluated here with the
+        // host's libm (exactly the values the host-only scan of round 2 took its minima / maxima over), then OpenCV's two pole tests
+        ISX_TRY(roi_stream_of(w, &st));
+        ISX_LAUNCH("roi_border_sph", 0.0, st, k_roi_border_sph, dim3(1), dim3(1024), 0, w->proj, sw, sh, (unsigned*)nullptr, cand, CAND_CAP, count);
+        if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
+        ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
+        ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
+        ISX_HIP(hipStreamSynchronize(st));
+        const int n = ((const int*)w->pin)[4];
+        ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
+        ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the border of the %d x %d source (bad K / R / scale?)", sw, sh);
+        w->host_cand.resize((size_t)n * 2);
+        std::memcpy(w->host_cand.data(), (const char*)w->pin + 64, (size_t)std::min(n, CAND_FIRST) * 8);
+        if (n > CAND_FIRST)
+            ISX_HIP(hipMemcpy(w->host_cand.data() + 2 * (size_t)CAND_FIRST, cand + 2 * (size_t)CAND_FIRST, (size_t)(n - CAND_FIRST) * 8, hipMemcpyDeviceToHost));
         float tl_u = std::numeric_limits<float>::max(), tl_v = tl_u, br_u = -tl_u, br_v = -tl_u, u, v;
-        auto upd = [&](float x, float y) {
-            map_forward_host(w->proj, x, y, u, v);
+        for (int i = 0; i < n; ++i) {
+            map_forward_host(w->proj, (float)w->host_cand[2 * i], (float)w->host_cand[2 * i + 1], u, v);
             tl_u = (std::min)(tl_u, u); tl_v = (std::min)(tl_v, v); br_u = (std::max)(br_u, u); br_v = (std::max)(br_v, v);
-        };
-        for (int i = 0; i < sw; ++i) { upd((float)i, 0.f); upd((float)i, (float)(sh - 1)); }
-        for (int i = 0; i < sh; ++i) { upd(0.f, (float)i); upd((float)(sw - 1), (float)i); }
+        }
         tl_u = (float)f2i_host(tl_u); tl_v = (float)f2i_host(tl_v); br_u = (float)f2i_host(br_u); br_v = (float)f2i_host(br_v);
-        const float* k = w->k; const float* rinv = w->rinv;
-        float x = rinv[1], y = rinv[4], z = rinv[7];
-        if (y > 0.f) {
-            float x_ = (k[0] * x + k[1] * y) / z + k[2], y_ = k[4] * y / z + k[5];
-            if (x_ > 0.f && x_ < sw && y_ > 0.f && y_ < sh) {
-                float pv = (float)(3.1415926535897932384626433832795 * w->scale);
-                tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, pv); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, pv);
-            }
+        bool north, south;
+        sph_poles(w->k, w->rinv, sw, sh, &north, &south);
+        if (north) {
+            const float pv = (float)(3.1415926535897932384626433832795 * w->scale);
+            tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, pv); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, pv);
         }
-        x = rinv[1]; y = -rinv[4]; z = rinv[7];
-        if (y > 0.f) {
-            float x_ = (k[0] * x + k[1] * y) / z + k[2], y_ = k[4] * y / z + k[5];
-            if (x_ > 0.f && x_ < sw && y_ > 0.f && y_ < sh) {
-                tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, 0.f); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, 0.f);
-            }
-        }
+        if (south) { tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, 0.f); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, 0.f); }
         if (mm) { mm[0] = tl_u; mm[1] = tl_v; mm[2] = br_u; mm[3] = br_v; }
         roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
         if (w->sph_memo.size() >= 32) w->sph_memo.erase(w->sph_memo.begin());
@@ -1087,6 +1193,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         isx_warper::Pending pd;
         pd.proj = w->proj; pd.sw = sw; pd.sh = sh;
         std::copy(planned, planned + 4, pd.planned);
+        std::copy(w->k, w->k + 9, pd.k); std::copy(w->rinv, w->rinv + 9, pd.rinv);
         w->pending.push_back(pd);
         if (!w->defer_verify) return flush_verify(w);
         return ISX_OK;
@@ -1198,8 +1305,6 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(set_camera(w, K, R));
     int roi[4];
-    ISX_CHECK_ARG(!(planned && verify_plan && w->kind == ISX_WARP_SPHERICAL), ISX_ERR_UNSUPPORTED,
-                  "planned warp: the spherical ROI is computed on the host; use isx_warper_warp_with_mask");
     if (planned) std::copy(planned, planned + 4, roi);   // the verifying scan is enqueued behind the warp kernel (below)
     else ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, false, nullptr));
     ISX_TRY(check_roi_sane(roi));

@@ -220,3 +220,64 @@ def test_config5_ring_of_8_tiles_full_8k_properties(gpu):
         assert int(vals.min()) >= v - 1 and int(vals.max()) <= v + 1, (c, int(vals.min()), int(vals.max()))
     del ms, imgs
     torch.cuda.empty_cache()
+
+
+def test_config5_planned_step_and_graph_equal_the_synchronous_step(gpu, oracle):
+    """The spherical projector on the sync-free path (round 3: its ROI is a border scan on the device): the planned step (ROI verified on
+    the device, no host round trip), its hipGraph replay and the synchronous step (every corner returned to the host) produce the same
+    mosaic, which is the oracle's; a plan that does not fit the cameras raises the sticky mismatch flag."""
+    import torch
+    from imagestitch_amd import IsxError
+    from imagestitch_amd.pipeline import MosaicStitcher
+    W, H, F, N = 960, 540, 750.0, 4
+    K, Rs = synth.camera_ring(W, H, F, N, 0.55)
+    imgs = [synth.make_tile(H, W, 700 + i) for i in range(N)]
+    corners, warped, wmasks, seam, od, om = _oracle_mosaic(oracle, oracle.SPH, F, K, Rs, imgs, 5, oracle.F32, False)
+    dev = torch.device("cuda:0")
+    d_imgs = [torch.from_numpy(i).to(dev) for i in imgs]
+    ms = MosaicStitcher(d_imgs, K, Rs, F, "spherical", 5, gpu.PREC_F32, 0, None, "int16")
+    assert ms.corners == corners
+    out_sync = ms.step_sync()[0].clone()
+    assert np.array_equal(out_sync.cpu().numpy(), od)
+    out_planned = ms.step()[0].clone()
+    ms.check_plan()                                     # the device-side check agreed with the plan
+    assert torch.equal(out_planned, out_sync)
+    ms.capture()
+    ms.out.zero_()
+    out_graph = ms.replay()[0]
+    torch.cuda.synchronize()
+    ms.check_plan()
+    assert torch.equal(out_graph, out_sync)
+    # a stale plan: the same ROIs with cameras that look elsewhere
+    K2, Rs2 = synth.camera_ring(W, H, F, N, 0.40)
+    stale = MosaicStitcher(d_imgs, K, Rs, F, "spherical", 5, gpu.PREC_F32, 0, None, "int16")
+    stale.Rs = Rs2
+    stale.step()
+    with pytest.raises(IsxError):
+        stale.check_plan()
+    del ms, stale
+
+
+def test_spherical_roi_device_border_scan_equals_host_scan(gpu, oracle):
+    """detectResultRoi of the spherical projector (device border scan + host refinement + pole tests) against the oracle's host-only scan:
+    random cameras incl. ones that look at a pole (pitch near +-90 degrees), several source sizes."""
+    import imagestitch_amd as I
+    rng = np.random.RandomState(5)
+    wp = I.SphericalWarper(0)
+    n_pole = 0
+    for trial in range(60):
+        W, H = int(rng.randint(40, 900)), int(rng.randint(40, 700))
+        f = float(rng.uniform(0.4, 2.0) * max(W, H))
+        K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float32)
+        pitch = rng.uniform(-1.7, 1.7) if trial % 3 == 0 else rng.uniform(-0.4, 0.4)
+        yaw, roll = rng.uniform(-3.0, 3.0), rng.uniform(-0.3, 0.3)
+        cx, sx, cy, sy, cz, sz = np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw), np.cos(roll), np.sin(roll)
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        R = (Ry @ Rx @ Rz).astype(np.float32)
+        scale = float(rng.uniform(0.5, 1.5) * f)
+        w = wp.create(scale)
+        got = w.warpRoi((W, H), K, R)
+        exp, _ = oracle.detect_roi(oracle.SPH, scale, K, R, W, H)
+        assert tuple(int(v) for v in got) == tuple(int(v) for v in exp), (trial, W, H, f, pitch, yaw, roll, got, exp)
+        n_pole += abs(pitch) > 1.2
+    assert n_pole >= 5

@@ -12,7 +12,7 @@ cp $O/${TAG}_traffic.json profiles/${TAG}_traffic.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 2>/dev/null | line > $O/${TAG}_bench_n1.json
 # 2. the same command under the kernel tracer
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin 2>/dev/null | line > $O/${TAG}_bench_under_rocprof.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin 2>/dev/null | line > $O/${TAG}_bench_under_rocprof.json
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats.csv
 # 3. per-kernel VALU utilisation / occupancy
 bash tools/pmc_kernels.sh 1 $TAG/pmc_f32 > $O/${TAG}_pmc_f32.txt 2>&1

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 PREC=${1:-1}; TAG=${2:-pmc}
 P=gpurun_out/$TAG; rm -rf $P; mkdir -p $P
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $P/run -- python tools/pipeline_probe.py $PREC 5 > $P/log.txt 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $P/run -- python tools/pipeline_probe.py $PREC 5 > $P/log.txt 2>&1
 python - "$P" <<'PY'
 import csv, glob, collections, re, sys
 P=sys.argv[1]
