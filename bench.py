@@ -278,6 +278,9 @@ def main():
                     help="HIP streams the pairs of a step are spread over (default: 1 for one pair, min(pairs, 4) otherwise): independent pairs on "
                          "separate streams overlap - one pair's launch-latency-bound small pyramid levels run under another pair's large kernels "
                          "(measured: 0.252 -> 0.220 ms per 4K pair with 2-4 streams; one hipGraph per pair does not overlap)")
+    ap.add_argument("--batch", action="store_true",
+                    help="blend the pairs of a step in ONE chain of launches (isx_blender_blend_batch: every pyramid level of up to 6 mosaics per "
+                         "launch) on one stream, instead of pair by pair spread over --streams")
     ap.add_argument("--shard", default="pairs", choices=["pairs", "strips"],
                     help="N > 1: pairs = every rank blends its own independent pairs (BASELINE config 4); strips = ONE panorama of --tiles tiles "
                          "per step, cut into N column strips: rank r warps and feeds only the tiles near its strip, blends the strip "
@@ -316,6 +319,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.pairs is None:
         args.pairs = 1 if world == 1 else 4
+    if args.batch and args.streams is None:
+        args.streams = 1
     if args.streams is None:
         args.streams = 1 if args.pairs == 1 else min(args.pairs, 4)
     rank = int(os.environ.get("RANK", "0"))
@@ -472,6 +477,22 @@ def main():
                 p.out = v
         if args.graph:
             b = 0                                  # the graphs run on their own streams and always write send[0]
+        if args.batch and not args.graph and not args.sync_roi:
+            for g, ps in enumerate(pstreams):           # one batched chain per stream: the pairs created on that stream
+                group = pairs[g::len(pstreams)]
+                if ps is not None and use_dist:
+                    ps.wait_event(ev_gather[b])
+                with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                    PairStitcher.step_batch(group)
+            if use_dist:
+                for i in range(len(pairs)):
+                    ev_pair[b][i].record(pstreams[i % len(pstreams)] if pstreams[0] is not None else main)
+                    if args.gather == "chunk":
+                        post_chunk(b, i)
+                if args.gather == "single":
+                    post_block(b)
+                gathers_done(b)
+            return
         for i, p in enumerate(pairs):
             ps = pstreams[i % len(pstreams)]
             if ps is not None and use_dist and not args.graph:
@@ -631,7 +652,7 @@ def main():
                 "tiles_per_mosaic": NT,
                 **({"shard": "strips", "strip": "%d/%d" % (strip_rank, strip_world), "window": list(window), "panorama_cols": fw_all,
                     "tiles_this_rank": pairs[0].active} if strips else {}),
-                "pairs_per_gpu": args.pairs, "streams": len(pstreams), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "pairs_per_gpu": args.pairs, "streams": len(pstreams), "batched_blend": bool(args.batch), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
             # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them

@@ -93,6 +93,7 @@ _SIGS = {
     "isx_blender_feed_u8": [C.c_void_p, _MP, _MP, C.c_int, C.c_int],
     "isx_blender_result_size": [C.c_void_p, _IP, _IP],
     "isx_blender_blend": [C.c_void_p, _MP, _MP],
+    "isx_blender_blend_batch": [C.POINTER(C.c_void_p), C.c_int, _MP, _MP],
     "isx_blender_debug_level": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _IP, _IP],
     "isx_blend_pair_linear_size": [C.c_int] * 8 + [_IP, _IP],
     "isx_blend_pair_linear": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, _MP, _IP, C.c_int, C.c_void_p],

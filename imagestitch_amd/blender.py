@@ -144,6 +144,27 @@ class MultiBandBlender:
         return dst, dst_mask
 
 
+def blend_batch(blenders, dsts, dst_masks):
+    """isx_blender_blend_batch: blend() of several prepared + fed blenders in one chain of launches (deferred multi-band cycles of one
+    rig share every launch; the rest are blended one by one).  dsts / dst_masks: one output per blender.  Returns (dsts, dst_masks)."""
+    n = len(blenders)
+    lib = blenders[0]._lib
+    hs = (C.c_void_p * n)(*[b._h for b in blenders])
+    mat_t = type(as_mat(dsts[0]))
+    md = (mat_t * n)(*[as_mat(d) for d in dsts])
+    mm = (mat_t * n)(*[as_mat(m) for m in dst_masks])
+    try:
+        check(lib.isx_blender_blend_batch(hs, n, md, mm))
+    finally:
+        for b in blenders:
+            for img, mask in b._fed:
+                for t in (img, mask):
+                    if _is_tensor(t) and t.is_cuda and b._stream_obj is not None and hasattr(t, "record_stream"):
+                        t.record_stream(b._stream_obj)
+            b._fed = []
+    return dsts, dst_masks
+
+
 class FeatherBlender(MultiBandBlender):
     """cv::detail::FeatherBlender as every reference demo runs it (W:278-281,302,313):
     blender = Blender.createDefault(Blender.FEATHER, False); blender.setSharpness(0.1)."""

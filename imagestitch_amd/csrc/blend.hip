@@ -848,9 +848,9 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
 // top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t})) at level-L pixel (x, y); the tile rectangles of
 // ts are those of level L - sh (the first collapse step passes its fine level, sh = 1).
 template <int M>
-__device__ __forceinline__ Px<M> top_px(const TileSet& ts, int x, int y, int sh) {
+__device__ __forceinline__ Px<M> top_px(const TileSet& ts, int tb, int te, int x, int y, int sh) {
     Px<M> d; d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f;
-    for (int t = 0; t < ts.n; ++t) {
+    for (int t = tb; t < te; ++t) {
         const int lx = x - (ts.x_tl[t] >> sh), ly = y - (ts.y_tl[t] >> sh);
         if ((unsigned)lx < (unsigned)ts.coarse[t].cols && (unsigned)ly < (unsigned)ts.coarse[t].rows) {
             Px<M> g = load_px<M, false>(ts.coarse[t], lx, ly);
@@ -883,8 +883,10 @@ __device__ unsigned long long g_phase[1024][12];
 #define PT(k) do { } while (0)
 #define PT_FLUSH do { } while (0)
 #endif
-template <int M, int SK, bool FINE0, bool TOP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+// The tiles [tb, te) of ts are those of ONE mosaic (all of them in a single blend; one mosaic's share in a batched launch, see
+// BatchOut): the body of a collapse step for the block (blockIdx.x, blockIdx.y) of that mosaic.
+template <int M, int SK, bool FINE0, bool TOP>
+__device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const int tb, const int te, const LevelBuf& coarse_out, const LevelBuf& fine_out, const OutMat& out) {
     using WT = typename WorkT<M>::t;
     // Tiles are taken G at a time: their coarse tiles (and, in the last round, that of out_k) are staged in ONE phase —
     // every global load of the round in flight together, the fine-level pixels included, one barrier pair per round
@@ -918,8 +920,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
         for (int j = 0; j < 2; ++j) { acc[i][j][0] = 0; acc[i][j][1] = 0; acc[i][j][2] = 0; accw[i][j] = 0.f; accA[i][j] = splat2(0.f); accC[i] = splat2(0.f); accW[i] = splat2(0.f); }
     constexpr int NCT = (UP_TY + 2) * (WAVE + 2);
     int rnd = 0;                                           // rounds executed so far
-    for (int t0 = 0; t0 < max(ts.n, 1); t0 += G) {
-        const bool with_out = t0 + G >= ts.n;
+    for (int t0 = tb; t0 < max(te, tb + 1); t0 += G) {
+        const bool with_out = t0 + G >= te;
         bool touch[G], mine[G];
         int lx0[G], ly0[G], ccl[G], crw[G];
         const void* cimg[G];
@@ -932,20 +934,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
         // decoded (level 0: decoded after the barrier, so that the round waits for memory once).
 #pragma unroll
         for (int s = 0; s < G; ++s) {
-            const int t = min(t0 + s, ts.n - 1);
+            const int t = min(t0 + s, te - 1);
             touch[s] = false; mine[s] = false; lx0[s] = 0; ly0[s] = 0; ccl[s] = 1; crw[s] = 1; cimg[s] = nullptr;
-            if (ts.n > 0) {
+            if (te > tb) {
                 // block-uniform: does the block's fine region touch the tile's rectangle?
                 const int tx = ts.x_tl[t], ty = ts.y_tl[t], tw = ts.w[t], th = ts.h[t], ccols = ts.coarse[t].cols, crows = ts.coarse[t].rows;
                 cimg[s] = ts.coarse[t].img; ccl[s] = ccols; crw[s] = crows;
                 asm volatile("" ::"s"(tx), "s"(ty), "s"(tw), "s"(th), "s"(ccols), "s"(crows), "s"(cimg[s]));   // one batch of s_loads, one wait
-                touch[s] = (t0 + s < ts.n) & !((2 * cx0 >= tx + tw) | (2 * cx0 + 2 * WAVE <= tx) | (2 * cy0 >= ty + th) | (2 * cy0 + 2 * UP_TY <= ty));
+                touch[s] = (t0 + s < te) & !((2 * cx0 >= tx + tw) | (2 * cx0 + 2 * WAVE <= tx) | (2 * cy0 >= ty + th) | (2 * cy0 + 2 * UP_TY <= ty));
                 lx0[s] = cx0 - (tx >> 1); ly0[s] = cy0 - (ty >> 1);      // block origin in the tile's coarse coordinates
                 const int lcx = lx0[s] + lane, lcy = ly0[s] + wv;
                 mine[s] = touch[s] & ((unsigned)lcx < (unsigned)ccols) & ((unsigned)lcy < (unsigned)crows);
             }
         }
-        PT(t0 == 0 ? 0 : 4);    // descriptors
+        PT(t0 == tb ? 0 : 4);    // descriptors
         // A round none of whose tiles reaches this block is skipped altogether (block-uniform: no staging, no barrier) unless it is the
         // one that stages out_k - with two tiles side by side that is the first round of every block right of the overlap.
         {
@@ -973,12 +975,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
                 if (with_out) {
                     const int gx = min(max(cx0 - 1 + rx, 0), coarse_out.cols - 1), gy = up_row_map<M>(cy0 - 1 + ry, coarse_out.rows);
                     if constexpr (DMA_O) glds16((const float4*)coarse_out.img + (__umul24((unsigned)gy, (unsigned)coarse_out.cols) + (unsigned)gx), &ct[NB - 1][0][0] + (i - lane));
-                    else if constexpr (TOP) sv[G][it] = top_px<M>(ts, gx, gy, 1);
+                    else if constexpr (TOP) sv[G][it] = top_px<M>(ts, tb, te, gx, gy, 1);
                     else sv[G][it] = load_px_rgb<M, OUT_DST>(coarse_out, gx, gy);
                 }
             }
         }
-        PT(t0 == 0 ? 1 : 5);    // coarse tiles issued
+        PT(t0 == tb ? 1 : 5);    // coarse tiles issued
         // Wave-level tier (FINE0, CV_8UC3 tiles): when EVERY lane of the wave owns pixels of the tile and both of its rows' windows lie
         // inside the tile's buffer - true for all waves but those on a tile's rim - the wave takes a path without a single per-lane
         // branch: the per-pixel form below spends as many scalar instructions on exec-mask bookkeeping (343 per wave against 547
@@ -1029,9 +1031,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
                 }
             }
         }
-        PT(t0 == 0 ? 2 : 6);    // fine pixels issued
+        PT(t0 == tb ? 2 : 6);    // fine pixels issued
         __syncthreads();
-        PT(t0 == 0 ? 3 : 7);    // memory + barrier wait
+        PT(t0 == tb ? 3 : 7);    // memory + barrier wait
 #pragma unroll
         for (int s = 0; s < G; ++s) {
             const int t = t0 + s;
@@ -1086,7 +1088,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
                     accw[dy][dx] = accw[dy][dx] + g.w;
                 }
         }
-        PT(t0 == 0 ? 8 : 9);    // decode + pyrUp + accumulate
+        PT(t0 == tb ? 8 : 9);    // decode + pyrUp + accumulate
     }
     const int cx = cx0 + lane, cy = cy0 + wv;
     if (cx >= coarse_out.cols || cy >= coarse_out.rows) { PT_FLUSH; return; }
@@ -1157,6 +1159,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
     }
     PT(10);                     // epilogue: normalise, pyrUp of out, convert, stores issued
     PT_FLUSH;
+}
+
+
+// One mosaic per launch: its tiles are all of ts.
+template <int M, int SK, bool FINE0, bool TOP = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+    collapse_gather_body<M, SK, FINE0, TOP>(ts, 0, ts.n, coarse_out, fine_out, out);
+}
+
+// Several mosaics per launch (isx_blender_blend_batch: independent pairs of one rig - BASELINE configs 3 and 4 - share every launch of
+// the chain, so that its launch-latency-bound small levels run at P times the waves): blockIdx.z is the mosaic, ts holds the tiles of
+// all of them grouped by mosaic (first[m] .. first[m + 1]), every mosaic has its own collapsed levels and result mats.
+constexpr int BATCH_MAX = 6;        // kernel arguments: TileSet (3.2 KB) + 6 x 128 bytes stay below the 4 KB limit
+struct BatchOut {
+    int first[BATCH_MAX + 1];
+    LevelBuf coarse_out[BATCH_MAX], fine_out[BATCH_MAX];
+    OutMat out[BATCH_MAX];
+};
+static_assert(sizeof(TileSet) + sizeof(BatchOut) <= 4096, "a batched collapse step's arguments exceed the kernel-argument limit");
+template <int M, int SK, bool FINE0, bool TOP = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather_batch(TileSet ts, BatchOut bo) {
+    const int m = blockIdx.z;
+    collapse_gather_body<M, SK, FINE0, TOP>(ts, bo.first[m], bo.first[m + 1], bo.coarse_out[m], bo.fine_out[m], bo.out[m]);
 }
 
 #include "collapse_roll.inc"
@@ -1892,6 +1917,155 @@ int run_blend(isx_blender* b, const OutMat& out) {
     return ISX_OK;
 }
 
+// blend() of nb fully deferred cycles in ONE chain of launches (isx_blender_blend_batch): the Gaussian chains of all tiles of all
+// mosaics level by level, then the collapse chain with the mosaic as grid.z.  The caller has checked that the blenders agree in
+// precision, band count, tile type, device and stream, hold no window, and that their tiles fit one TileSet.
+template <int M, int SK>
+int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
+    isx_blender* b0 = bs[0];
+    hipStream_t st = b0->stream;
+    const int L = b0->num_bands, prec = M;
+    LevelBuf* d[BATCH_MAX];
+    LevelBuf od[BATCH_MAX][MAX_LEVELS];
+    int first[BATCH_MAX + 1], nt = 0;
+    for (int m = 0; m < nb; ++m) {
+        isx_blender* b = bs[m];
+        d[m] = b->dst;
+        if (M == M_I16) {      // the collapsed levels as 16-byte register records (see run_blend_deferred_t)
+            size_t total = 0;
+            layout_levels(od[m], L, d[m][0].rows, d[m][0].cols, prec, false, nullptr, &total);
+            const size_t skip = ((size_t)d[m][0].rows * d[m][0].cols * g_px_bytes(prec) + 255) & ~(size_t)255;
+            ISX_TRY(b->out_arena.reserve(total - skip + 256));
+            layout_levels(od[m], L, d[m][0].rows, d[m][0].cols, prec, false, (char*)b->out_arena.p - skip, &total);
+            od[m][0].img = nullptr;
+            d[m] = od[m];
+        }
+        first[m] = nt;
+        nt += (int)b->tiles.size();
+        ISX_TRY(join_side_streams(b));
+    }
+    first[nb] = nt;
+    auto base = [&](int k_fine) {
+        TileSet ts;
+        memset(&ts, 0, sizeof(ts));
+        ts.n = nt;
+        int t = 0;
+        for (int m = 0; m < nb; ++m)
+            for (const isx_blender::TileRec& r : bs[m]->tiles) {
+                ts.s0[t] = r.s0;
+                ts.x_tl[t] = r.x_tl >> k_fine; ts.y_tl[t] = r.y_tl >> k_fine;
+                ts.w[t] = r.g[k_fine].cols; ts.h[t] = r.g[k_fine].rows;
+                ts.bx_lo[t] = 0; ts.bx_hi[t] = 1 << 30;
+                ++t;
+            }
+        return ts;
+    };
+    auto tile_rec = [&](int t) -> const isx_blender::TileRec& {
+        int m = 0;
+        while (t >= first[m + 1]) ++m;
+        return bs[m]->tiles[(size_t)(t - first[m])];
+    };
+    const double gin0 = src_px_bytes(SK) + 1.0;
+    // 1. Gaussian chains: one launch per level for every tile of every mosaic
+    for (int k = 0; k < L; ++k) {
+        TileSet ts = base(k);
+        int maxc = 0, maxr = 0;
+        double bytes = 0.0;
+        for (int t = 0; t < nt; ++t) {
+            const isx_blender::TileRec& r = tile_rec(t);
+            ts.fine[t] = r.g[k]; ts.coarse[t] = r.g[k + 1];
+            maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
+            bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
+        }
+        dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), nt);
+        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
+        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+        for (int m = 0; m < nb; ++m)
+            if (k == bs[m]->mark_level && bs[m]->mark_event) ISX_HIP(hipEventRecord(bs[m]->mark_event, st));
+    }
+    // 2. collapse chain, the mosaic as grid.z
+    for (int k = L; k >= 1; --k) {
+        TileSet ts = base(k - 1);
+        BatchOut bo;
+        memset(&bo, 0, sizeof(bo));
+        std::copy(first, first + nb + 1, bo.first);
+        double bytes = 0.0;
+        int gx = 0, gy = 0;
+        for (int t = 0; t < nt; ++t) {
+            const isx_blender::TileRec& r = tile_rec(t);
+            ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
+            if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;
+            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec)) + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);
+        }
+        for (int m = 0; m < nb; ++m) {
+            bo.coarse_out[m] = d[m][k]; bo.fine_out[m] = d[m][k - 1]; bo.out[m] = outs[m];
+            bo.out[m].bx0 = 0; bo.out[m].grp = 0; bo.out[m].band = 0;
+            if (k != L) bytes += (double)d[m][k].rows * d[m][k].cols * alg_d_rgb(prec);
+            if (k == 1) bytes += (double)outs[m].rows * outs[m].cols * (outs[m].img_f32 == 1 ? 13.0 : (outs[m].img_f32 == 2 ? 4.0 : 7.0));
+            else bytes += (double)d[m][k - 1].rows * d[m][k - 1].cols * alg_d_rgb(prec);
+            gx = std::max(gx, cdiv(d[m][k].cols, WAVE)); gy = std::max(gy, cdiv(d[m][k].rows, UP_TY));
+        }
+        if (k == 1 && k != L) {      // the last step: the rolling kernel when every mosaic qualifies (launch_collapse_roll's conditions)
+            static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
+            bool ok = mode != 0 && SK == SK_U8;
+            unsigned nblk = 0;
+            for (int m = 0; m < nb && ok; ++m) {
+                const LevelBuf& c = d[m][1];
+                ok = c.cols >= 2 && (unsigned long long)c.rows * c.cols * 16ull < (1ull << 32);
+                TileSet one;
+                memset(&one, 0, sizeof(one));
+                one.n = first[m + 1] - first[m];
+                for (int t = 0; t < one.n && ok; ++t) {
+                    const int g = first[m] + t;
+                    one.x_tl[t] = ts.x_tl[g]; one.y_tl[t] = ts.y_tl[g]; one.w[t] = ts.w[g]; one.h[t] = ts.h[g];
+                    ok = ts.coarse[g].cols >= 2 && ts.s0[g].cols >= 2 && ts.s0[g].rows >= 2 && ts.s0[g].iend != 0u &&
+                         (unsigned long long)ts.coarse[g].rows * ts.coarse[g].cols * 16ull < (1ull << 32);
+                }
+                ok = ok && roll_max_tiles(one, c, 0, c.cols, 2) <= 2;
+                if (ok) {
+                    const int nsx = cdiv(c.cols, RL_CW), nby = cdiv(cdiv(c.rows, 2), ROLL_WAVES), grp = std::max(2, nsx == 1 ? 2 : 1);
+                    OutMat& o = bo.out[m];
+                    o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx); o.band = cdiv(nby, 8);
+                    nblk = std::max(nblk, xcd_band_blocks(grp, nsx, nby));
+                }
+            }
+            if constexpr (SK == SK_U8) {
+                if (ok) {
+                    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll_batch<M, SK, 2, 2>), dim3(nblk, 1, nb), dim3(64 * ROLL_WAVES), 0, ts, bo, 0);
+                    continue;
+                }
+            }
+            for (int m = 0; m < nb; ++m) { bo.out[m].grp = 0; bo.out[m].band = 0; }
+        }
+        dim3 grid(gx, gy, nb);
+        if (k <= 2 && gy >= 16) {     // the XCD-aware block order of the single path (groups of 2 block rows), every mosaic with its own extent
+            unsigned nblk = 0;
+            for (int m = 0; m < nb; ++m) {
+                OutMat& o = bo.out[m];
+                o.grp = 2; o.gx = cdiv(d[m][k].cols, WAVE); o.gy = cdiv(d[m][k].rows, UP_TY); o.xmagic = xcd_magic(2, o.gx);
+                nblk = std::max(nblk, xcd_grid_blocks(2, o.gx, o.gy));
+            }
+            grid = dim3(nblk, 1, nb);
+        }
+        if (k == 1) {
+            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather_batch<M, SK, true, true>), grid, dim3(256), 0, ts, bo);
+            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather_batch<M, SK, true, false>), grid, dim3(256), 0, ts, bo);
+        } else {
+            if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather_batch<M, SK_U8, false, true>), grid, dim3(256), 0, ts, bo);
+            else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather_batch<M, SK_U8, false, false>), grid, dim3(256), 0, ts, bo);
+        }
+    }
+    return ISX_OK;
+}
+template <int M>
+int run_blend_batch(isx_blender** bs, int nb, const OutMat* outs) {
+    switch (bs[0]->tiles[0].sk) {
+        case SK_U8: return run_blend_batch_t<M, SK_U8>(bs, nb, outs);
+        case SK_S16: return run_blend_batch_t<M, SK_S16>(bs, nb, outs);
+        default: return run_blend_batch_t<M, SK_F32>(bs, nb, outs);
+    }
+}
+
 int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     ISX_CHECK_ARG(width > 0 && height > 0, ISX_ERR_INVALID, "prepare: empty destination ROI %d x %d", width, height);
     ISX_HIP(hipSetDevice(b->device));
@@ -2346,8 +2520,8 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
     return ISX_OK;
 }
 
-int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
-    clear_error();
+// the checks, staging and OutMat of Blender::blend for one blender (shared by isx_blender_blend and isx_blender_blend_batch)
+static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* po) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "blend: null blender");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "blend: prepare() has not been called (or blend() already released the pyramids)");
     ISX_TRY(check_mat(dst, "blend: dst"));
@@ -2376,7 +2550,7 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
         ISX_TRY(b->st_outmask.use_out(dst_mask, b->stream, "blend: dst_mask"));
         ISX_CHECK_ARG(b->st_outmask.d.step < (1u << 24), ISX_ERR_UNSUPPORTED, "blend: dst_mask row pitch %zu exceeds 16 MiB", b->st_outmask.d.step);
     }
-    OutMat o;
+    OutMat& o = *po;
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
@@ -2391,6 +2565,24 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
         o.cols = std::min(b->win_x1, b->fw);
     }
     o.vec = ((uintptr_t)o.img % 4 == 0) && (o.img_step % 4 == 0) && (!o.mask || (((uintptr_t)o.mask % 2 == 0) && (o.mask_step % 2 == 0)));
+    return ISX_OK;
+}
+// the copies back to host mats and the release of the pyramids (dst_pyr_laplace_.clear(); dst_band_weights_.clear())
+static int blend_end(isx_blender* b, isx_mat* dst_mask) {
+    ISX_TRY(b->st_out.finish_out(b->stream));
+    if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
+    b->tiles.clear();
+    b->ftiles.clear();
+    b->level0_pending = false;
+    b->prepared = false;   // dst_pyr_laplace_.clear(); dst_band_weights_.clear()
+    return ISX_OK;
+}
+
+int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
+    clear_error();
+    OutMat o;
+    ISX_TRY(blend_begin(b, dst, dst_mask, &o));
+    const bool windowed = b->win_x1 > b->win_x0;
     int rc = ISX_OK;
     if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend
         dim3 grid(cdiv(b->dst[0].cols, 64), cdiv(b->dst[0].rows, 4));
@@ -2421,12 +2613,48 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
         }
     }
     ISX_TRY(rc);
-    ISX_TRY(b->st_out.finish_out(b->stream));
-    if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
-    b->tiles.clear();
-    b->ftiles.clear();
-    b->level0_pending = false;
-    b->prepared = false;   // dst_pyr_laplace_.clear(); dst_band_weights_.clear()
+    return blend_end(b, dst_mask);
+}
+
+int isx_blender_blend_batch(isx_blender** bs, int n, isx_mat* dsts, isx_mat* dst_masks) {
+    clear_error();
+    ISX_CHECK_ARG(bs != nullptr && dsts != nullptr && n >= 1, ISX_ERR_INVALID, "blend_batch: bad argument");
+    for (int i = 0; i < n; ++i) ISX_CHECK_ARG(bs[i] != nullptr, ISX_ERR_INVALID, "blend_batch: null blender %d", i);
+    // Groups of blenders that can share a chain of launches: the deferred multi-band cycle with every tile still recorded, no window, the
+    // same precision / bands / tile type / device / stream, at most BATCH_MAX mosaics and DEF_MAX tiles.  Anything else is blended alone.
+    int i = 0;
+    while (i < n) {
+        isx_blender* b0 = bs[i];
+        auto batchable = [&](const isx_blender* b) {
+            return b->type == ISX_BLEND_MULTI_BAND && b->prepared && b->level0_pending && !b->tiles.empty() && b->win_x1 <= b->win_x0 &&
+                   b->prec == b0->prec && b->num_bands == b0->num_bands && b->num_bands >= 1 && b->tiles[0].sk == b0->tiles[0].sk &&
+                   b->device == b0->device && b->stream == b0->stream;
+        };
+        int j = i, tiles = 0;
+        if (batchable(b0))
+            while (j < n && j - i < BATCH_MAX && batchable(bs[j]) && tiles + (int)bs[j]->tiles.size() <= DEF_MAX) {
+                bool dup = false;
+                for (int q = i; q < j; ++q) dup = dup || bs[q] == bs[j];
+                if (dup) break;
+                tiles += (int)bs[j]->tiles.size(); ++j;
+            }
+        if (j - i < 2) {
+            ISX_TRY(isx_blender_blend(bs[i], &dsts[i], dst_masks ? &dst_masks[i] : nullptr));
+            ++i;
+            continue;
+        }
+        OutMat outs[BATCH_MAX];
+        for (int q = i; q < j; ++q) ISX_TRY(blend_begin(bs[q], &dsts[q], dst_masks ? &dst_masks[q] : nullptr, &outs[q - i]));
+        int rc;
+        switch (b0->prec) {
+            case M_I16: rc = run_blend_batch<M_I16>(bs + i, j - i, outs); break;
+            case M_F32: rc = run_blend_batch<M_F32>(bs + i, j - i, outs); break;
+            default: rc = run_blend_batch<M_F16>(bs + i, j - i, outs); break;
+        }
+        ISX_TRY(rc);
+        for (int q = i; q < j; ++q) ISX_TRY(blend_end(bs[q], dst_masks ? &dst_masks[q] : nullptr));
+        i = j;
+    }
     return ISX_OK;
 }
 

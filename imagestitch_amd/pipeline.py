@@ -167,6 +167,33 @@ class PairStitcher:
             self.warper.verify_after(self.mark)   # blend() recorded the mark behind its level-`verify_at` pyrDown
         return self.out, self.out_mask
 
+    def step_until_blend(self):
+        """The planned step up to (not including) blend(): warps, prepare, feeds - for step_batch."""
+        for i in self.active:
+            if self.tile_cols is not None:
+                self.warper.set_dst_columns(*self.tile_cols[i])
+            self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+        if self.tile_cols is not None:
+            self.warper.set_dst_columns(0, 0)
+        if self.mark is None:
+            self.warper.verify()
+        self.blender.prepare(self.corners, self.sizes)
+        for i in self.active:
+            self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+
+    @staticmethod
+    def step_batch(stitchers):
+        """The planned step of several independent mosaics with ONE chain of blend launches (isx_blender_blend_batch): every
+        stitcher's warps and feeds as in step(), then one batched blend.  The stitchers share a stream."""
+        from .blender import blend_batch
+        for s in stitchers:
+            s.step_until_blend()
+        blend_batch([s.blender for s in stitchers], [s.out for s in stitchers], [s.out_mask for s in stitchers])
+        for s in stitchers:
+            if s.mark is not None and not s.interleave:
+                s.warper.verify_after(s.mark)
+        return [(s.out, s.out_mask) for s in stitchers]
+
     def capture(self):
         """Capture the planned step into a hipGraph (one launch per step instead of ~17 API calls):
         everything the step enqueues is stream work on resident buffers — no allocation, no host copy,

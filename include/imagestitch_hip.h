@@ -248,6 +248,13 @@ int isx_blender_result_size(isx_blender* b, int* width, int* height);
  * result.convertTo(CV_8U), what imwrite (W:315) does to the panorama); dst_mask: CV_8UC1.  Releases the pyramids:
  * prepare must be called again before the next feed (as in OpenCV).                           */
 int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask);
+/* blend() of n blenders at once - the per-image loop of the reference's main() (W:223-233, 285-302, 313) run for a BATCH of independent
+ * mosaics (BASELINE configs 3 and 4: 16 / 4 pairs per step).  Blenders that are in the deferred cycle (isx_blender_set_deferred_level0)
+ * with the same precision, band count, tile type, device and stream share ONE chain of launches, up to 6 mosaics / 20 tiles per chain:
+ * every level's Gaussian chain and collapse step is one launch for all of them (the mosaic is the grid's z), so the levels that
+ * are launch-latency-bound for one pair run at P times the waves.  Every mosaic is bit for bit what isx_blender_blend gives; blenders
+ * that do not qualify are blended one by one.  dsts / dst_masks: n mats (dst_masks may be NULL).                                   */
+int isx_blender_blend_batch(isx_blender** bs, int n, isx_mat* dsts, isx_mat* dst_masks);
 
 /* introspection for parity tests: copy destination pyramid level `level` (after feeds, before
  * blend) to host buffers.  lap: rows*cols*3 of int16 (I16) or float (F32/F16ACC32); weight:

@@ -281,3 +281,57 @@ def test_spherical_roi_device_border_scan_equals_host_scan(gpu, oracle):
         assert tuple(int(v) for v in got) == tuple(int(v) for v in exp), (trial, W, H, f, pitch, yaw, roll, got, exp)
         n_pole += abs(pitch) > 1.2
     assert n_pole >= 5
+
+
+@pytest.mark.parametrize("prec_name", ["f32", "i16", "f16acc32"])
+def test_batched_blend_equals_the_serial_blends(gpu, prec_name):
+    """isx_blender_blend_batch (round 3: ONE chain of launches for several mosaics, the mosaic as grid.z): 8 pairs with different images
+    and three different rigs (mosaics of different sizes share a launch) - every mosaic and mask equal to the pair's own serial step;
+    8 pairs = a chain of 6 and a chain of 2."""
+    import torch
+    from imagestitch_amd.pipeline import PairStitcher
+    prec = {"i16": gpu.PREC_I16, "f32": gpu.PREC_F32, "f16acc32": gpu.PREC_F16ACC32}[prec_name]
+    W, H, F, NP = 1280, 720, 1000.0, 8
+    dev = torch.device("cuda:0")
+    pairs, serial = [], []
+    for p in range(NP):
+        K, Rs = synth.camera_pair(W, H, F, yaw=(0.30, 0.36, 0.25)[p % 3])
+        imgs = [torch.from_numpy(synth.make_tile(H, W, 1300 + 2 * p + i)).to(dev) for i in range(2)]
+        ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, prec, 0, None, "int16")
+        out, mask = ps.step()
+        serial.append((out.clone(), mask.clone()))
+        pairs.append(ps)
+    assert len({tuple(s[0].shape) for s in serial}) == 3            # three mosaic sizes in the batch
+    for rep in range(2):
+        for ps in pairs:
+            ps.out.fill_(-3); ps.out_mask.fill_(9)
+        res = PairStitcher.step_batch(pairs)
+        torch.cuda.synchronize()
+        for p, ps in enumerate(pairs):
+            ps.check_plan()
+            assert torch.equal(res[p][1], serial[p][1]), (prec_name, rep, p)
+            assert torch.equal(res[p][0], serial[p][0]), (prec_name, rep, p)
+
+
+def test_batched_blend_falls_back_for_blenders_that_do_not_qualify(gpu):
+    """a batch that mixes a deferred multi-band blender, an eager one and a windowed one: all blended, each as alone"""
+    import torch
+    import imagestitch_amd as I
+    from imagestitch_amd.blender import blend_batch
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F = 960, 540, 750.0
+    dev = torch.device("cuda:0")
+    K, Rs = synth.camera_pair(W, H, F)
+    imgs = [torch.from_numpy(synth.make_tile(H, W, 1500 + i)).to(dev) for i in range(2)]
+    ref = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, I.PREC_F32, 0, None, "int16")
+    exp, exp_mask = [t.clone() for t in ref.step()]
+    a = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, I.PREC_F32, 0, None, "int16")
+    b = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, I.PREC_F32, 0, None, "int16", deferred=False)      # eager cycle
+    c = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, I.PREC_I16, 0, None, "int16")                      # another precision
+    for s in (a, b, c):
+        s.step_until_blend()
+    blend_batch([a.blender, b.blender, c.blender], [a.out, b.out, c.out], [a.out_mask, b.out_mask, c.out_mask])
+    torch.cuda.synchronize()
+    assert torch.equal(a.out, exp) and torch.equal(b.out, exp) and torch.equal(a.out_mask, exp_mask) and torch.equal(b.out_mask, exp_mask)
+    ci = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, I.PREC_I16, 0, None, "int16")
+    assert torch.equal(c.out, ci.step()[0])
