@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const in
                     const Px<M> g = gg[s][dy][dx];
                     if constexpr (M == M_I16 && FINE0 && SK == SK_U8) {
                         // CV_8UC3 tiles: g in [0, 255], pyrUp of their Gaussian level in [0, 255], w in [0, 1] - cv::subtract cannot saturate,
-                        // static_cast<short>(lap * w) is a plain truncation of a value within +-255, and the sum over at most 8 tiles cannot
+                        // static_cast<short>(lap * w) is a plain truncation of a value within +-255, and the sum over at most DEF_MAX = 20 tiles (+-5100) cannot
                         // wrap a short: the three guards of the general form below never act and are not issued
                         acc[dy][dx][0] = acc[dy][dx][0] + (int)((float)(g.c0 - u.v[dy][dx][0]) * g.w);
                         acc[dy][dx][1] = acc[dy][dx][1] + (int)((float)(g.c1 - u.v[dy][dx][1]) * g.w);
@@ -1136,8 +1136,8 @@ __device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const in
             Px<M> d;
             d.c0 = acc[dy][dx][0]; d.c1 = acc[dy][dx][1]; d.c2 = acc[dy][dx][2]; d.w = accw[dy][dx];
             if constexpr (M == M_I16 && FINE0 && SK == SK_U8) {
-                // normalizeUsingWeightMap on integers within +-2040 over a denominator in [1e-5, 8 + 1e-5]: the three divisions share one
-                // reciprocal (isx_device.hpp: the hardware's own recurrence; the numerators are integers, the quotients below 2^28) and
+                // normalizeUsingWeightMap on integers within +-5100 (DEF_MAX = 20 tiles) over a denominator in [1e-5, 20 + 1e-5]: the three divisions share one
+                // reciprocal (isx_device.hpp: the hardware's own recurrence; the numerators are integers, the quotients below 2^30) and
                 // static_cast<short> is truncation + the low 16 bits
                 const float den = d.w + WEIGHT_EPS;
                 const f32x2 z = splat2(den), r1 = refine_rcp(z, splat2(__builtin_amdgcn_rcpf(den)));
@@ -2533,6 +2533,9 @@ static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* 
         ISX_CHECK_ARG(b->type == ISX_BLEND_FEATHER ? !b->ftiles.empty() : b->level0_pending, ISX_ERR_UNSUPPORTED,
                       "blend: a column window needs the deferred cycle (isx_blender_set_deferred_level0) with every tile still recorded");
         ISX_CHECK_ARG(b->win_x0 < b->fw, ISX_ERR_SIZE, "blend: the window starts at column %d, the result is %d wide", b->win_x0, b->fw);
+        // a last strip padded to its peers' width keeps the columns past the mosaic's edge as they are: device mats only (a host mat
+        // is copied back as a whole from its staging buffer)
+        ISX_CHECK_ARG(dst->device >= 0 && (!dst_mask || dst_mask->device >= 0), ISX_ERR_UNSUPPORTED, "blend: a column window needs device mats");
     }
     ISX_CHECK_ARG(dst->rows == b->fh && dst->cols == out_cols, ISX_ERR_SIZE, "blend: dst is %dx%d, result%s is %dx%d", dst->cols, dst->rows,
                   windowed ? " window" : "", out_cols, b->fh);

@@ -74,7 +74,9 @@ static_assert(SEAM_ROWS % SEAM_PRODUCERS == 0, "rows of a chunk are dealt evenly
 
 __global__ __launch_bounds__(64 * (1 + SEAM_PRODUCERS)) void k_lin_seam(LinGeom g, const float* costV, int* seam) {
     __shared__ signed char dir[2][SEAM_ROWS][SEAM_W];
-    __shared__ int s_x0[2], s_px;
+    // s_px[j & 1]: the column the walker reached at the end of chunk j.  Two slots: the walker goes straight on into chunk j + 1 and writes
+    // the other slot while slower waves may still be reading this one (a single slot was a formal race: ADVICE r2)
+    __shared__ int s_x0[2], s_px[2];
     const int cw = g.iBr + 2, lane = threadIdx.x & 63, last = g.iHe - 1;     // rows 1 .. last are chosen by the walk
     const bool producer = threadIdx.x >= 64;
     const int pw = (int)(threadIdx.x >> 6) - 1;          // producer wave index (rows pw, pw + 4, ...)
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(64 * (1 + SEAM_PRODUCERS)) void k_lin_seam(LinGeom 
             px = min(max(px + (int)dir[b][r][px - x0], 0), cw - 1);          // xl = max(px - 1, 0), xr = min(px + 1, cw - 1)
             seam[py + 1 + r] = px;
         }
-        s_px = px;
+        s_px[b] = px;
     };
     if (producer) {
         fetch(S0, x0_0, 0, px);
@@ -130,14 +132,14 @@ __global__ __launch_bounds__(64 * (1 + SEAM_PRODUCERS)) void k_lin_seam(LinGeom 
         if (!producer) { if (lane == 0) walk(j); }
         else if (j + 1 < nchunks) publish(S1, x0_1, 1);
         __syncthreads();
-        px = s_px;
+        px = s_px[0];
         if (producer && j + 3 < nchunks) fetch(S1, x0_1, j + 3, px);
         if (j + 1 >= nchunks) break;
         // odd chunk j + 1 (buffer 1) is walked while the table of chunk j + 2 (S0 -> buffer 0) is written
         if (!producer) { if (lane == 0) walk(j + 1); }
         else if (j + 2 < nchunks) publish(S0, x0_0, 0);
         __syncthreads();
-        px = s_px;
+        px = s_px[1];
         if (producer && j + 4 < nchunks) fetch(S0, x0_0, j + 4, px);
     }
 }
@@ -245,8 +247,7 @@ extern "C" {
 int isx_blend_pair_linear_release(void) {
     clear_error();
     LinScratch& ls = lin_scratch();
-    if (ls.device >= 0) (void)hipSetDevice(ls.device);
-    ls.buf.release();
+    ls.buf.release();      // (hipFree needs no current device: the caller's is left as it is)
     ls.device = -1;
     return ISX_OK;
 }

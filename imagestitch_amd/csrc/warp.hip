@@ -1379,6 +1379,10 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         // kernel's right crop is the range's end, its left end the block boundary at or below col0
         int bx0 = 0, wcrop = dw;
         if (w->col1 > w->col0 && !src_mask) {
+            // columns outside the range keep their contents: true for device mats, which are written in place; a host mat would be
+            // overwritten as a whole by the copy back from its staging buffer
+            ISX_CHECK_ARG(dst->device >= 0 && dst_mask->device >= 0, ISX_ERR_UNSUPPORTED,
+                          "warp_with_mask: isx_warper_set_dst_columns needs device mats (a host mat is copied back as a whole)");
             bx0 = std::min(w->col0, dw - 1) / 64; wcrop = std::min(w->col1, dw);
             bytes *= (double)(cdiv(wcrop, 64) - bx0) / cdiv(dw, 64);
         }

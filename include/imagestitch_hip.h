@@ -167,8 +167,9 @@ int isx_warper_join(isx_warper* w);
  * (memory-bound) pyramid kernels that follow.  join / plan_status flush the queue themselves.            */
 int isx_warper_set_deferred_verify(isx_warper* w, int on);
 /* Column range of the warped tile (nothing in the reference; the companion of isx_blender_set_window): the isx_warper_warp_with_mask*
- * calls that follow (without a source mask) compute only the columns [col0, col1) of dst_img / dst_mask - rounded outwards to blocks
- * of 64 - and leave the rest of the mats as it is.  For a rank that needs part of a neighbour's tile to blend its strip of a
+ * calls that follow (without a source mask) compute only the columns [col0, col1) of dst_img / dst_mask - the left end rounded down to a
+ * block of 64, the right end exactly col1 - and leave the rest of the mats as it is.  Device mats only (a host mat is copied back as a
+ * whole from its staging buffer: ISX_ERR_UNSUPPORTED); the same holds for the mats of a windowed blend.  For a rank that needs part of a neighbour's tile to blend its strip of a
  * panorama (imagestitch_amd/mosaic.py: tile_columns_for_window gives the range).  (0, 0) = the whole tile again.              */
 int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1);
 int isx_warper_verify(isx_warper* w);
