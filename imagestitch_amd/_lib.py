@@ -86,6 +86,8 @@ _SIGS = {
     "isx_bmp_read": [C.c_char_p, _MP],
     "isx_bmp_write": [C.c_char_p, _MP],
     "isx_jpeg_write": [C.c_char_p, _MP, C.c_int],
+    "isx_jpeg_size": [C.c_char_p, _IP, _IP],
+    "isx_jpeg_read": [C.c_char_p, _MP],
     "isx_blender_set_overlap": [C.c_void_p, C.c_int],
     "isx_blender_prepare": [C.c_void_p, C.c_int, _IP, _IP],
     "isx_blender_prepare_roi": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],

@@ -13,7 +13,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function ${ISX_EXTRA_FLAGS:-}"
 mkdir -p build
 pids=()
-for f in isx_core.cpp imgio.cpp seamfind.cpp gather.cpp warp.hip blend.hip prep.hip linear_blend.hip seam.hip; do
+for f in isx_core.cpp imgio.cpp jpegdec.cpp seamfind.cpp gather.cpp warp.hip blend.hip prep.hip linear_blend.hip seam.hip; do
     [ -f "$f" ] || continue
     o=build/${f%.*}.o
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ isx_internal.hpp -nt "$o" ] || [ isx_device.hpp -nt "$o" ] || [ collapse_roll.inc -nt "$o" ] || [ ../../include/imagestitch_hip.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
