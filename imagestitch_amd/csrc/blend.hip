@@ -2223,10 +2223,12 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     ISX_TRY(check_mat(mask, "feed: mask"));
     if (u8_entry) ISX_CHECK_ARG(img->type == ISX_8UC3, ISX_ERR_TYPE, "feed_u8: img must be CV_8UC3, got %s", type_name(img->type));
     else {
-        ISX_CHECK_ARG(img->type != ISX_8UC3, ISX_ERR_UNSUPPORTED,
-                      "feed: CV_8UC3 input selects OpenCV's 8-bit pyramid, which the reference never uses; convert to CV_16SC3 (W:294) or call isx_blender_feed_u8");
-        ISX_CHECK_ARG(img->type == ISX_16SC3 || (img->type == ISX_32FC3 && b->prec != ISX_PREC_I16), ISX_ERR_TYPE,
-                      "feed: img must be CV_16SC3%s, got %s", b->prec != ISX_PREC_I16 ? " or CV_32FC3" : "", type_name(img->type));
+        // CV_8UC3 selects createLaplacePyr's 8-bit branch in OpenCV 3.4.2 (blenders.cpp): pyrDown / pyrUp on CV_8U levels, subtract(...,
+        // CV_16S), the top level converted to CV_16S.  With the same work type (int), the same casts ((v + 128) >> 8, (v + 32) >> 6) and every
+        // intermediate inside [0, 255] (kernel weights sum to 256 / 64 over bytes), saturate_cast<uchar> never acts and that branch produces
+        // exactly the CV_16S branch's numbers for the converted image: it is the fused-conversion path of isx_blender_feed_u8.
+        ISX_CHECK_ARG(img->type == ISX_8UC3 || img->type == ISX_16SC3 || (img->type == ISX_32FC3 && b->prec != ISX_PREC_I16), ISX_ERR_TYPE,
+                      "feed: img must be CV_16SC3 or CV_8UC3%s, got %s", b->prec != ISX_PREC_I16 ? " or CV_32FC3" : "", type_name(img->type));
     }
     ISX_CHECK_ARG(mask->type == ISX_8UC1, ISX_ERR_TYPE, "feed: mask must be CV_8U, got %s", type_name(mask->type));
     ISX_CHECK_ARG(mask->rows == img->rows && mask->cols == img->cols, ISX_ERR_SIZE, "feed: mask %dx%d does not match img %dx%d",
@@ -2533,9 +2535,7 @@ static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* 
         ISX_CHECK_ARG(b->type == ISX_BLEND_FEATHER ? !b->ftiles.empty() : b->level0_pending, ISX_ERR_UNSUPPORTED,
                       "blend: a column window needs the deferred cycle (isx_blender_set_deferred_level0) with every tile still recorded");
         ISX_CHECK_ARG(b->win_x0 < b->fw, ISX_ERR_SIZE, "blend: the window starts at column %d, the result is %d wide", b->win_x0, b->fw);
-        // a last strip padded to its peers' width keeps the columns past the mosaic's edge as they are: device mats only (a host mat
-        // is copied back as a whole from its staging buffer)
-        ISX_CHECK_ARG(dst->device >= 0 && (!dst_mask || dst_mask->device >= 0), ISX_ERR_UNSUPPORTED, "blend: a column window needs device mats");
+
     }
     ISX_CHECK_ARG(dst->rows == b->fh && dst->cols == out_cols, ISX_ERR_SIZE, "blend: dst is %dx%d, result%s is %dx%d", dst->cols, dst->rows,
                   windowed ? " window" : "", out_cols, b->fh);
@@ -2572,8 +2572,16 @@ static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* 
 }
 // the copies back to host mats and the release of the pyramids (dst_pyr_laplace_.clear(); dst_band_weights_.clear())
 static int blend_end(isx_blender* b, isx_mat* dst_mask) {
-    ISX_TRY(b->st_out.finish_out(b->stream));
-    if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
+    if (b->win_x1 > b->win_x0) {
+        // a last strip padded to its peers' width keeps the columns past the mosaic's edge as they are - also in a host mat, of which
+        // only the computed columns are copied back from the staging buffer
+        const int valid = std::min(b->win_x1, b->fw) - b->win_x0;
+        ISX_TRY(b->st_out.finish_out_cols(b->stream, 0, valid));
+        if (dst_mask) ISX_TRY(b->st_outmask.finish_out_cols(b->stream, 0, valid));
+    } else {
+        ISX_TRY(b->st_out.finish_out(b->stream));
+        if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
+    }
     b->tiles.clear();
     b->ftiles.clear();
     b->level0_pending = false;

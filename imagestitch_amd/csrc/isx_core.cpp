@@ -95,6 +95,17 @@ int MatStage::finish_out(hipStream_t s) {
     return ISX_OK;
 }
 
+int MatStage::finish_out_cols(hipStream_t s, int col0, int col1) {
+    if (!host) return ISX_OK;
+    col0 = col0 < 0 ? 0 : col0; col1 = col1 > host->cols ? host->cols : col1;
+    if (col1 <= col0) return ISX_OK;
+    const size_t es = (size_t)mat_elem_size(host->type);
+    ISX_HIP(hipMemcpy2DAsync((char*)host->data + (size_t)col0 * es, host->step, (const char*)d.data + (size_t)col0 * es, d.step, (size_t)(col1 - col0) * es,
+                             host->rows, hipMemcpyDeviceToHost, s));
+    ISX_HIP(hipStreamSynchronize(s));
+    return ISX_OK;
+}
+
 // ---- profiler ---------------------------------------------------------------------------------
 struct ProfEntry {
     std::string name;

@@ -67,6 +67,7 @@ struct MatStage {
     int use_in(const isx_mat* m, hipStream_t s, const char* what);   // H2D if needed
     int use_out(isx_mat* m, hipStream_t s, const char* what);        // allocate staging if needed
     int finish_out(hipStream_t s);                                   // D2H if needed (async)
+    int finish_out_cols(hipStream_t s, int col0, int col1);          // D2H of columns [col0, col1) only: the rest of the caller's mat keeps its contents
 };
 
 int check_mat(const isx_mat* m, const char* what);

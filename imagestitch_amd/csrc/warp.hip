@@ -1325,6 +1325,8 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(set_camera(w, K, R));
     int roi[4];
+    bool ranged = false;
+    int rc0 = 0, rc1 = 0;
     if (planned) std::copy(planned, planned + 4, roi);   // the verifying scan is enqueued behind the warp kernel (below)
     else ISX_TRY(detect_roi(w, src->cols, src->rows, roi, nullptr, false, nullptr));
     ISX_TRY(check_roi_sane(roi));
@@ -1379,10 +1381,6 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         // kernel's right crop is the range's end, its left end the block boundary at or below col0
         int bx0 = 0, wcrop = dw;
         if (w->col1 > w->col0 && !src_mask) {
-            // columns outside the range keep their contents: true for device mats, which are written in place; a host mat would be
-            // overwritten as a whole by the copy back from its staging buffer
-            ISX_CHECK_ARG(dst->device >= 0 && dst_mask->device >= 0, ISX_ERR_UNSUPPORTED,
-                          "warp_with_mask: isx_warper_set_dst_columns needs device mats (a host mat is copied back as a whole)");
             bx0 = std::min(w->col0, dw - 1) / 64; wcrop = std::min(w->col1, dw);
             bytes *= (double)(cdiv(wcrop, 64) - bx0) / cdiv(dw, 64);
         }
@@ -1398,7 +1396,11 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
 #undef ISX_WARP_TILE_K
 #undef ISX_WARP_TILE
 #undef ISX_WARP_FUSED
-        ISX_TRY(w->st_dmask.finish_out(st));
+        // a column range (isx_warper_set_dst_columns) leaves the other columns of the mats as they are - also of host mats, of which only the
+        // computed columns come back from the staging buffers
+        ranged = w->col1 > w->col0 && !src_mask;
+        rc0 = bx0 * 64; rc1 = wcrop;
+        if (ranged) ISX_TRY(w->st_dmask.finish_out_cols(st, rc0, rc1)); else ISX_TRY(w->st_dmask.finish_out(st));
         if (planned && verify_plan) {
             int scratch[4];
             ISX_TRY(detect_roi(w, src->cols, src->rows, scratch, nullptr, true, planned));
@@ -1419,7 +1421,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             default: return fail(ISX_ERR_TYPE, "warp: src type %s is not supported (CV_8UC1/3, CV_32FC1/3)", type_name(src->type));
         }
     }
-    ISX_TRY(w->st_dst.finish_out(st));
+    if (ranged) ISX_TRY(w->st_dst.finish_out_cols(st, rc0, rc1)); else ISX_TRY(w->st_dst.finish_out(st));
     if (corner) { corner[0] = roi[0]; corner[1] = roi[1]; }   // return dst_roi.tl()  W:160
     return ISX_OK;
 }

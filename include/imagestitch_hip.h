@@ -168,8 +168,8 @@ int isx_warper_join(isx_warper* w);
 int isx_warper_set_deferred_verify(isx_warper* w, int on);
 /* Column range of the warped tile (nothing in the reference; the companion of isx_blender_set_window): the isx_warper_warp_with_mask*
  * calls that follow (without a source mask) compute only the columns [col0, col1) of dst_img / dst_mask - the left end rounded down to a
- * block of 64, the right end exactly col1 - and leave the rest of the mats as it is.  Device mats only (a host mat is copied back as a
- * whole from its staging buffer: ISX_ERR_UNSUPPORTED); the same holds for the mats of a windowed blend.  For a rank that needs part of a neighbour's tile to blend its strip of a
+ * block of 64, the right end exactly col1 - and leave the rest of the mats as it is (of a host mat only the computed columns are copied
+ * back from its staging buffer; the same holds for the padded last strip of a windowed blend).  For a rank that needs part of a neighbour's tile to blend its strip of a
  * panorama (imagestitch_amd/mosaic.py: tile_columns_for_window gives the range).  (0, 0) = the whole tile again.              */
 int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1);
 int isx_warper_verify(isx_warper* w);
@@ -200,8 +200,9 @@ int isx_blender_prepare(isx_blender* b, int n, const int* corners_xy, const int*
 int isx_blender_prepare_roi(isx_blender* b, int x, int y, int width, int height);
 
 /* blender->feed(img [CV_16SC3], mask [CV_8U], tl) (W:302).  img may also be CV_32FC3 in
- * the F32 / F16ACC32 precisions.  CV_8UC3 is rejected with ISX_ERR_UNSUPPORTED (OpenCV runs a
- * different, 8-bit pyramid for it that the reference never uses) — see isx_blender_feed_u8.   */
+ * the F32 / F16ACC32 precisions, and CV_8UC3: OpenCV then takes createLaplacePyr's 8-bit branch,
+ * whose numbers are those of the CV_16S branch on the converted image (bytes never saturate in
+ * pyrDown / pyrUp) - the same path as isx_blender_feed_u8.                                        */
 int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y);
 /* images_warped.convertTo(CV_16S) (W:261,294) fused into feed: img is CV_8UC3 and is widened
  * to int16 on load; results are identical to converting first and calling isx_blender_feed.   */

@@ -124,9 +124,6 @@ def test_blender_errors(gpu):
     assert e.value.code == 3  # feed before prepare
     mb.prepare([(0, 0)], [(10, 10)])
     with pytest.raises(gpu.IsxError) as e:
-        mb.feed(img.astype(np.uint8), mask, (0, 0))
-    assert e.value.code == 6  # CV_8UC3 through feed()
-    with pytest.raises(gpu.IsxError) as e:
         mb.feed(img.astype(np.float32), mask, (0, 0))
     assert e.value.code == 2  # CV_32FC3 in I16 precision
     mb.feed(img, mask, (0, 0))
@@ -508,3 +505,31 @@ def test_deferred_blend_of_misaligned_device_views(gpu, oracle, prec_name, off_i
     d, dm = mb.blend(out_f32=out_f32)
     od, om = ob.blend(out_f32)
     assert np.array_equal(dm.cpu().numpy(), om) and np.array_equal(d.cpu().numpy(), od)
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_feed_cv8uc3_takes_opencvs_8bit_branch(gpu, oracle, deferred):
+    """MultiBandBlender::feed accepts CV_8UC3 (createLaplacePyr's 8-bit branch, OpenCV 3.4.2 blenders.cpp): its numbers are those of the
+    CV_16S branch on the converted image - isx_blender_feed(CV_8UC3) == isx_blender_feed_u8 == the oracle fed convertTo(CV_16S)."""
+    rng = np.random.default_rng(77)
+    tiles, corners = [], [(0, 0), (70, 6), (150, -4)]
+    for i in range(3):
+        h, w = 90 + 7 * i, 120 + 5 * i
+        tiles.append((rng.integers(0, 256, (h, w, 3)).astype(np.uint8), np.where(rng.random((h, w)) < 0.8, 255, 0).astype(np.uint8)))
+    sizes = [(t[0].shape[1], t[0].shape[0]) for t in tiles]
+    for prec in (I16, gpu.PREC_F32):
+        ob = oracle.MultiBand(4, prec)
+        ob.prepare(corners, sizes)
+        outs = []
+        for entry in ("feed", "feed_u8"):
+            mb = gpu.MultiBandBlender(False, 4, prec)
+            mb.set_deferred_level0(deferred)
+            mb.prepare(corners, sizes)
+            for (img, mask), c in zip(tiles, corners):
+                getattr(mb, entry)(img, mask, c)
+            outs.append(mb.blend())
+        for (img, mask), c in zip(tiles, corners):
+            ob.feed(img.astype(np.int16), mask, c)
+        od, om = ob.blend(False)
+        for d, m in outs:
+            assert np.array_equal(d, od) and np.array_equal(m, om), (prec, deferred)

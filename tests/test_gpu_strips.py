@@ -210,6 +210,49 @@ def test_window_error_contract(gpu):
         b.blend()
 
 
+def test_window_and_column_range_with_host_mats_copy_back_only_the_computed_columns(gpu):
+    """host (numpy) outputs: the staged device copy holds only the computed columns, so only those are copied back - the padded
+    columns of a last strip and the columns outside isx_warper_set_dst_columns keep what the caller's mat held"""
+    import torch
+    import imagestitch_amd as I
+    from imagestitch_amd import synth
+    from imagestitch_amd.blender import MultiBandBlender
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 255, (80, 300, 3), dtype=np.uint8)
+    msk = np.full((80, 300), 255, np.uint8)
+
+    def cycle(window, out, om):
+        b = MultiBandBlender(False, 3, I.PREC_F32, 0)
+        if window:
+            b.set_window(*window)
+        b.prepare([(0, 0)], [(300, 80)])
+        b.set_deferred_level0(True)
+        b.feed_u8(img, msk, (0, 0))
+        return b.blend(out, om)
+
+    full, fmask = cycle(None, None, None)
+    assert isinstance(full, np.ndarray) and full.shape == (80, 300, 3)
+    out, om = np.full((80, 128, 3), -7, np.int16), np.full((80, 128), 9, np.uint8)
+    cycle((256, 384), out, om)            # the result is 300 wide: 44 valid columns, 84 of padding
+    assert np.array_equal(out[:, :44], full[:, 256:300]) and np.array_equal(om[:, :44], fmask[:, 256:300])
+    assert (out[:, 44:] == -7).all() and (om[:, 44:] == 9).all()
+
+    K, Rs = synth.camera_pair(500, 300, 380.0, yaw=0.3)
+    src = synth.make_tile(300, 500, 3, noise_only=True)
+    wp = I.CylindricalWarper().create(380.0)
+    corner, wfull, wmask = wp.warp_with_mask(src, K, Rs[0])
+    assert isinstance(wfull, np.ndarray)
+    h, w = wfull.shape[:2]
+    for c0, c1 in ((70, 200), (0, 1), (w - 5, w), (130, w + 40)):
+        di, dm = np.full((h, w, 3), 77, np.uint8), np.full((h, w), 9, np.uint8)
+        wp.set_dst_columns(c0, c1)
+        assert wp.warp_with_mask(src, K, Rs[0], dst_img=di, dst_mask=dm)[0] == corner
+        wp.set_dst_columns(0, 0)
+        lo, hi = c0 // 64 * 64, min(c1, w)
+        assert np.array_equal(di[:, lo:hi], wfull[:, lo:hi]) and np.array_equal(dm[:, lo:hi], wmask[:, lo:hi]), (c0, c1)
+        assert (di[:, :lo] == 77).all() and (dm[:, :lo] == 9).all() and (di[:, hi:] == 77).all() and (dm[:, hi:] == 9).all(), (c0, c1)
+
+
 def test_feather_and_multiband_strip_fuzz_slice(gpu):
     """a few hundred random strips of random tile rows against the ORACLE's whole blends (tools/fuzz_parity.py: case_strip,
     case_strip_feather), every precision and input type"""
