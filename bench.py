@@ -576,6 +576,15 @@ def main():
     lib.isx_profile_sample(1)
     for p in pairs:
         p.check_plan()   # raises if any planned step saw a ROI that differs from the plan
+    # host time to ENQUEUE one step (the queue empty when it starts, nothing waited for): what the launch chain costs the caller's thread
+    enq = []
+    for _ in range(5):
+        fence()
+        te = time.perf_counter()
+        step()
+        enq.append(time.perf_counter() - te)
+    fence()
+    host_enqueue_ms = sorted(enq)[len(enq) // 2] * 1e3
     split = None
     if use_dist:
         # outside the timed region ("report Mpix/s with and without the gather"): the same K steps
@@ -652,7 +661,7 @@ def main():
                 "tiles_per_mosaic": NT,
                 **({"shard": "strips", "strip": "%d/%d" % (strip_rank, strip_world), "window": list(window), "panorama_cols": fw_all,
                     "tiles_this_rank": pairs[0].active} if strips else {}),
-                "pairs_per_gpu": args.pairs, "streams": len(pstreams), "batched_blend": bool(args.batch), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "pairs_per_gpu": args.pairs, "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
             # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them

@@ -330,13 +330,13 @@ constexpr int PD_OW = WAVE - 2;
 constexpr int PD_WAVES = 8;
 constexpr int PD_RPW = (PD_NR + PD_WAVES - 1) / PD_WAVES;
 
+template <int M> __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv);
+
 template <int M, int SK>
-__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by) {
+__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by, Px<M> (*hb)[WAVE]) {
     using WT = typename WorkT<M>::t;
-    __shared__ Px<M> hb[PD_NR][WAVE];
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
     const int sh = (SK == SK_LEVEL) ? src.rows : s0.height;
-    const int dw = dst.cols, dh = dst.rows;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
     const int cA = reflect101(2 * ox, sw), cB = reflect101(2 * ox + 1, sw);
@@ -385,35 +385,49 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
         }
     }
     __syncthreads();
+    pyr_down_columns<M>(hb, dst, ox, oy0, lane, wv);
+}
+
+// pyrDown's column filter over five row-filtered rows + the 1/256 (the (v + 128) >> 8 of the 16-bit pyramid)
+template <int M>
+__device__ __forceinline__ Px<M> pyr_down_col5(const Px<M>& r0, const Px<M>& r1, const Px<M>& r2, const Px<M>& r3, const Px<M>& r4) {
+    using WT = typename WorkT<M>::t;
+    Px<M> o;
+    if constexpr (M != M_I16) {   // packed the same way as the row filter
+        const f32x2 p0[5] = {{r0.c0, r0.c1}, {r1.c0, r1.c1}, {r2.c0, r2.c1}, {r3.c0, r3.c1}, {r4.c0, r4.c1}};
+        const f32x2 p1[5] = {{r0.c2, r0.w}, {r1.c2, r1.w}, {r2.c2, r2.w}, {r3.c2, r3.w}, {r4.c2, r4.w}};
+        const f32x2 v0 = (((p0[2] * splat2(6.f) + (p0[1] + p0[3]) * splat2(4.f)) + p0[0]) + p0[4]) * splat2(1.f / 256.f);
+        const f32x2 v1 = (((p1[2] * splat2(6.f) + (p1[1] + p1[3]) * splat2(4.f)) + p1[0]) + p1[4]) * splat2(1.f / 256.f);
+        o.c0 = v0.x; o.c1 = v0.y; o.c2 = v1.x; o.w = v1.y;
+    } else {
+        const WT a0 = tap5<WT>(r2.c0, r1.c0, r3.c0, r0.c0, r4.c0);
+        const WT a1 = tap5<WT>(r2.c1, r1.c1, r3.c1, r0.c1, r4.c1);
+        const WT a2 = tap5<WT>(r2.c2, r1.c2, r3.c2, r0.c2, r4.c2);
+        const float aw = tap5<float>(r2.w, r1.w, r3.w, r0.w, r4.w);
+        o.c0 = (a0 + 128) >> 8; o.c1 = (a1 + 128) >> 8; o.c2 = (a2 + 128) >> 8;   // weights sum to 256: no clamp can act
+        o.w = aw * (1.f / 256.f);
+    }
+    return o;
+}
+
+// the column filter of a block out of the row-filtered rows in LDS (after the block's barrier)
+template <int M>
+__device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv) {
+    const int dw = dst.cols, dh = dst.rows;
     if (lane == 0 || lane == 63 || ox >= dw) return;
 #pragma unroll
     for (int i = 0; i < PD_TY / PD_WAVES; ++i) {
         int ty = wv + PD_WAVES * i, oy = oy0 + ty;
         if (oy >= dh) break;
-        Px<M> r0 = hb[2 * ty][lane], r1 = hb[2 * ty + 1][lane], r2 = hb[2 * ty + 2][lane], r3 = hb[2 * ty + 3][lane], r4 = hb[2 * ty + 4][lane];
-        Px<M> o;
-        if constexpr (M != M_I16) {   // the column filter and the 1/256, packed the same way
-            const f32x2 p0[5] = {{r0.c0, r0.c1}, {r1.c0, r1.c1}, {r2.c0, r2.c1}, {r3.c0, r3.c1}, {r4.c0, r4.c1}};
-            const f32x2 p1[5] = {{r0.c2, r0.w}, {r1.c2, r1.w}, {r2.c2, r2.w}, {r3.c2, r3.w}, {r4.c2, r4.w}};
-            const f32x2 v0 = (((p0[2] * splat2(6.f) + (p0[1] + p0[3]) * splat2(4.f)) + p0[0]) + p0[4]) * splat2(1.f / 256.f);
-            const f32x2 v1 = (((p1[2] * splat2(6.f) + (p1[1] + p1[3]) * splat2(4.f)) + p1[0]) + p1[4]) * splat2(1.f / 256.f);
-            o.c0 = v0.x; o.c1 = v0.y; o.c2 = v1.x; o.w = v1.y;
-        } else {
-        WT a0 = tap5<WT>(r2.c0, r1.c0, r3.c0, r0.c0, r4.c0);
-        WT a1 = tap5<WT>(r2.c1, r1.c1, r3.c1, r0.c1, r4.c1);
-        WT a2 = tap5<WT>(r2.c2, r1.c2, r3.c2, r0.c2, r4.c2);
-        float aw = tap5<float>(r2.w, r1.w, r3.w, r0.w, r4.w);
-        if constexpr (M == M_I16) { o.c0 = (a0 + 128) >> 8; o.c1 = (a1 + 128) >> 8; o.c2 = (a2 + 128) >> 8; }   // weights sum to 256: no clamp can act
-        else { o.c0 = a0 * (1.f / 256.f); o.c1 = a1 * (1.f / 256.f); o.c2 = a2 * (1.f / 256.f); }
-        o.w = aw * (1.f / 256.f);
-        }
+        const Px<M> o = pyr_down_col5<M>(hb[2 * ty][lane], hb[2 * ty + 1][lane], hb[2 * ty + 2][lane], hb[2 * ty + 3][lane], hb[2 * ty + 4][lane]);
         store_px<M, false>(dst, ox, oy, o);
     }
 }
 
 template <int M, int SK>
 __global__ __launch_bounds__(512) void k_pyr_down(Src0 s0, LevelBuf src, LevelBuf dst) {
-    pyr_down_block<M, SK>(s0, src, dst, blockIdx.x, blockIdx.y);
+    __shared__ Px<M> hb[PD_NR][WAVE];
+    pyr_down_block<M, SK>(s0, src, dst, blockIdx.x, blockIdx.y, hb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -842,7 +856,8 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
     if (blockIdx.x * PD_OW >= dst.cols || blockIdx.y * PD_TY >= dst.rows || (int)blockIdx.x < ts.bx_lo[t] || (int)blockIdx.x >= ts.bx_hi[t]) return;
-    pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y);
+    __shared__ Px<M> hb[PD_NR][WAVE];
+    pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y, hb);
 }
 
 // top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t})) at level-L pixel (x, y); the tile rectangles of
@@ -1185,6 +1200,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 }
 
 #include "collapse_roll.inc"
+#include "pyrdown_l0.inc"
+
+// level 0 -> 1 of every recorded tile: CV_8UC3 tiles through k_pyr_down0_u8 (ISX_PD0=0: the general kernel, for A/B runs)
+template <int M, int SK>
+int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st) {
+    static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
+    if constexpr (SK == SK_U8) {
+        if (fast) { ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down0_u8<M>), grid, dim3(512), 0, ts); return ISX_OK; }
+    }
+    ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
+    return ISX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // N2  FeatherBlender (W:278-281,302,313; OpenCV 3.4.2 blenders.cpp createWeightMap / feed / blend)
@@ -1818,7 +1845,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             bytes += share * ((double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec));
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
-        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
+        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st)));
         else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
         // the full-size level-0 kernel is behind us: from here to the last collapse step the launches are small
         if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
@@ -1978,7 +2005,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
             bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), nt);
-        if (k == 0) ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
+        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st)));
         else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
         for (int m = 0; m < nb; ++m)
             if (k == bs[m]->mark_level && bs[m]->mark_event) ISX_HIP(hipEventRecord(bs[m]->mark_event, st));

@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # the last occurrence of the final collapse kernel that is preceded by a complete step
-idx = [i for i, n in enumerate(names) if "k_collapse_gather<" in n and ", true, false>" in n]
+idx = [i for i, n in enumerate(names) if "k_collapse_roll<" in n or ("k_collapse_gather<" in n and ", true, false>" in n)]
 end = idx[-3]
 start = end
 while start > 0 and "k_warp_tile" not in names[start]:
