@@ -30,29 +30,107 @@ namespace {
 struct Pt { int x, y; };
 enum { FIRST = 1, SECOND = 2, INTERS = 4 };
 
+// first index in [e, x1) whose label differs from l (x1 if none): eight labels per step while they all match
+inline int label_run_end(const int* row, int e, int x1, int l) {
+    const unsigned long long pat = (unsigned)l | ((unsigned long long)(unsigned)l << 32);
+    while (e + 8 <= x1) {
+        unsigned long long v[4];
+        memcpy(v, row + e, 32);
+        if (((v[0] ^ pat) | (v[1] ^ pat) | (v[2] ^ pat) | (v[3] ^ pat)) != 0) break;
+        e += 8;
+    }
+    while (e < x1 && row[e] == l) ++e;
+    return e;
+}
+// first index in [x, x1) whose label IS l (x1 if none): eight labels per step while none matches (zero test on the 32-bit halves of v ^ pattern)
+inline int label_skip_to(const int* row, int x, int x1, int l) {
+    const unsigned long long pat = (unsigned)l | ((unsigned long long)(unsigned)l << 32);
+    auto has_zero32 = [](unsigned long long t) { return ((t - 0x0000000100000001ull) & ~t & 0x8000000080000000ull) != 0; };
+    while (x + 8 <= x1) {
+        unsigned long long v[4];
+        memcpy(v, row + x, 32);
+        if (has_zero32(v[0] ^ pat) || has_zero32(v[1] ^ pat) || has_zero32(v[2] ^ pat) || has_zero32(v[3] ^ pat)) break;
+        x += 8;
+    }
+    while (x < x1 && row[x] != l) ++x;
+    return x;
+}
+
+// dst[i] = 0 wherever cond[i] != 0 (two different masks: no overlap, said so for the vectoriser)
+inline void clear_where(unsigned char* __restrict dst, const unsigned char* __restrict cond, int n) {
+    for (int i = 0; i < n; ++i) dst[i] = cond[i] ? (unsigned char)0 : dst[i];
+}
+
 struct Finder {
     int device = 0;
     hipStream_t stream = nullptr;
     int utlx = 0, utly = 0, uw = 0, uh = 0;
-    std::vector<unsigned char> mask1_, mask2_;
+    // the two masks of the pair, read in place through the union's coordinates (zero outside a tile's rectangle): no union-sized copies
+    struct MaskView {
+        const unsigned char* p = nullptr; size_t step = 0; int ox = 0, oy = 0, rows = 0, cols = 0;   // (ox, oy) = the tile's corner in the union
+        bool at(int y, int x) const {
+            const int ty = y - oy, tx = x - ox;
+            return (unsigned)ty < (unsigned)rows && (unsigned)tx < (unsigned)cols && p[(size_t)ty * step + tx] != 0;
+        }
+    };
+    MaskView mask1_, mask2_;
     int ncomps = 0;
+    // labels_ is only ever read (S:311-392, 607-706, 806-1093 and the write-back S:495-523) next to a contour pixel of some component, inside the
+    // rectangle of an intersection component, or inside the intersection of the two tiles; everything that is not a contour test of the
+    // first pass lies in the intersection rectangle widened by one pixel.  The label IMAGE therefore covers only that window (a quarter of a
+    // 4K pair's union); outside it a label is looked up in the row runs of find_components, which nothing ever changes there.
+    int wx0 = 0, wy0 = 0, ww = 0, wh = 0;
     std::vector<int> labels;
     std::vector<int> states;
     std::vector<Pt> tls, brs;
     std::vector<std::vector<Pt>> contours;
     std::set<std::pair<int, int>> edges;
+    struct Run { int x0, x1, cls, id; };
+    std::vector<Run> runs;
+    std::vector<int> row_start;
 
     std::vector<int> seam_mask_;
-    int L(int y, int x) const { return labels[(size_t)y * uw + x]; }
-    bool on_contour(int y, int x, int l) const {   // S:249-253
-        return (x == 0 || L(y, x - 1) != l) || (x == uw - 1 || L(y, x + 1) != l) || (y == 0 || L(y - 1, x) != l) || (y == uh - 1 || L(y + 1, x) != l);
+    std::vector<unsigned short> seam_mask16_;
+    int run_label(int y, int x) const {
+        int lo = row_start[y], hi = row_start[y + 1];
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (runs[mid].x1 <= x) lo = mid + 1; else hi = mid; }
+        return (lo < row_start[y + 1] && runs[lo].x0 <= x) ? runs[lo].id : 0;
     }
+    bool in_window(int y, int x) const { return (unsigned)(y - wy0) < (unsigned)wh && (unsigned)(x - wx0) < (unsigned)ww; }
+    int& LW(int y, int x) { return labels[(size_t)(y - wy0) * ww + (x - wx0)]; }
+    int L(int y, int x) const { return in_window(y, x) ? labels[(size_t)(y - wy0) * ww + (x - wx0)] : run_label(y, x); }
 
     // contour1mask_ / contour2mask_ (S:168-186) are only ever read through closeToContour (S:585-604) at the contour pixels
     // of one component: evaluated on demand from the masks instead of being materialised for the whole union
-    bool is_mask_contour(const std::vector<unsigned char>& m, int y, int x) const {
-        const size_t i = (size_t)y * uw + x;
-        return m[i] && ((x == 0 || !m[i - 1]) || (x == uw - 1 || !m[i + 1]) || (y == 0 || !m[i - uw]) || (y == uh - 1 || !m[i + uw]));
+    bool is_mask_contour(const MaskView& m, int y, int x) const {
+        return m.at(y, x) && ((x == 0 || !m.at(y, x - 1)) || (x == uw - 1 || !m.at(y, x + 1)) || (y == 0 || !m.at(y - 1, x)) || (y == uh - 1 || !m.at(y + 1, x)));
+    }
+
+    // maximal runs of non-zero bytes of p[0, n), shifted by xoff, appended to out: eight pixels per step on the per-byte "non-zero" flags
+    static void nonzero_runs(const unsigned char* p, int n, int xoff, std::vector<std::pair<int, int>>& out) {
+        const unsigned long long HI = 0x8080808080808080ull, LO = 0x7f7f7f7f7f7f7f7full;
+        auto flags = [&](unsigned long long v) { return (((v & LO) + LO) | v) & HI; };   // bit 7 of every non-zero byte
+        int x = 0;
+        while (x < n) {
+            // first non-zero byte at or after x: 32 bytes per step while all are zero
+            while (x + 32 <= n) { unsigned long long v[4]; memcpy(v, p + x, 32); if (v[0] | v[1] | v[2] | v[3]) break; x += 32; }
+            while (x + 8 <= n) { unsigned long long v; memcpy(&v, p + x, 8); if (v) { x += __builtin_ctzll(v) >> 3; break; } x += 8; }
+            while (x < n && !p[x]) ++x;
+            if (x >= n) break;
+            // first zero byte after x: 32 bytes per step while none is zero (little-endian: the lowest clear flag is the first zero pixel)
+            int e = x + 1;
+            while (e + 32 <= n) { unsigned long long v[4]; memcpy(v, p + e, 32); if ((flags(v[0]) & flags(v[1]) & flags(v[2]) & flags(v[3])) != HI) break; e += 32; }
+            while (e + 8 <= n) {
+                unsigned long long v; memcpy(&v, p + e, 8);
+                const unsigned long long nz = flags(v);
+                if (nz != HI) { e += __builtin_ctzll(~nz & HI) >> 3; goto have_end; }
+                e += 8;
+            }
+            while (e < n && p[e]) ++e;
+        have_end:
+            out.push_back({x + xoff, e + xoff});
+            x = e;
+        }
     }
 
     // S:196-308.  The reference scans the union in raster order and flood-fills (4-connectivity, equal class) from the
@@ -60,36 +138,35 @@ struct Finder {
     // union-find over vertically overlapping runs of the same class, components numbered by their first run in raster
     // order (= their first pixel); bounding boxes from the runs; contour pixels = run ends plus the interior pixels not
     // covered by the same component in the row above or below (interval arithmetic on the sorted run lists).
-    struct Run { int x0, x1, cls, id; };
     void find_components() {
-        labels.assign((size_t)uw * uh, 0);
+        labels.assign((size_t)ww * wh, 0);
         states.clear(); tls.clear(); brs.clear(); contours.clear();
-        std::vector<Run> runs;
-        std::vector<int> row_start((size_t)uh + 1, 0);
+        runs.clear();
+        row_start.assign((size_t)uh + 1, 0);
+        std::vector<std::pair<int, int>> ra, rb;
         for (int y = 0; y < uh; ++y) {
             row_start[y] = (int)runs.size();
-            const unsigned char* a = &mask1_[(size_t)y * uw];
-            const unsigned char* b = &mask2_[(size_t)y * uw];
+            ra.clear(); rb.clear();
+            const int y1 = y - mask1_.oy, y2 = y - mask2_.oy;
+            if ((unsigned)y1 < (unsigned)mask1_.rows) nonzero_runs(mask1_.p + (size_t)y1 * mask1_.step, mask1_.cols, mask1_.ox, ra);
+            if ((unsigned)y2 < (unsigned)mask2_.rows) nonzero_runs(mask2_.p + (size_t)y2 * mask2_.step, mask2_.cols, mask2_.ox, rb);
+            // maximal runs of constant (mask1 != 0, mask2 != 0): sweep over the two sorted run lists
+            size_t ia = 0, ib = 0;
             int x = 0;
-            while (x < uw) {
-                const bool ca = a[x] != 0, cb = b[x] != 0;
-                const int cls = (ca && cb) ? INTERS : (ca ? FIRST : (cb ? SECOND : 0));
-                int e = x + 1;
-                // the run goes on while (a != 0, b != 0) stays (ca, cb): eight pixels per step on the per-byte "non-zero" flags
-                const unsigned long long pa = ca ? 0x8080808080808080ull : 0ull, pb = cb ? 0x8080808080808080ull : 0ull;
-                while (e + 8 <= uw) {
-                    unsigned long long va, vb;
-                    memcpy(&va, a + e, 8); memcpy(&vb, b + e, 8);
-                    const unsigned long long na = (((va & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | va) & 0x8080808080808080ull;
-                    const unsigned long long nb = (((vb & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | vb) & 0x8080808080808080ull;
-                    const unsigned long long diff = (na ^ pa) | (nb ^ pb);
-                    if (diff) { e += __builtin_ctzll(diff) >> 3; goto run_done; }   // little-endian: the lowest set flag is the first differing pixel
-                    e += 8;
-                }
-                while (e < uw && (a[e] != 0) == ca && (b[e] != 0) == cb) ++e;
-            run_done:
-                if (cls) runs.push_back({x, e, cls, 0});
+            while (ia < ra.size() || ib < rb.size()) {
+                const int sa = ia < ra.size() ? ra[ia].first : INT_MAX, sb = ib < rb.size() ? rb[ib].first : INT_MAX;
+                const bool ca = sa <= x, cb = sb <= x;
+                if (!ca && !cb) { x = std::min(sa, sb); continue; }
+                // the class holds up to the next boundary of either list
+                int e = INT_MAX;
+                if (ca) e = std::min(e, ra[ia].second); else e = std::min(e, sa);
+                if (cb) e = std::min(e, rb[ib].second); else e = std::min(e, sb);
+                const int cls = (ca && cb) ? INTERS : (ca ? FIRST : SECOND);
+                if (!runs.empty() && (int)runs.size() > row_start[y] && runs.back().x1 == x && runs.back().cls == cls) runs.back().x1 = e;
+                else runs.push_back({x, e, cls, 0});
                 x = e;
+                if (ca && ra[ia].second == e) ++ia;
+                if (cb && rb[ib].second == e) ++ib;
             }
         }
         row_start[uh] = (int)runs.size();
@@ -121,7 +198,10 @@ struct Finder {
                 }
                 const int l = comp_of[r];
                 runs[k].id = l;
-                std::fill(labels.begin() + (size_t)y * uw + runs[k].x0, labels.begin() + (size_t)y * uw + runs[k].x1, l);
+                if ((unsigned)(y - wy0) < (unsigned)wh) {   // the label image covers the window only
+                    const int a = std::max(runs[k].x0, wx0), b = std::min(runs[k].x1, wx0 + ww);
+                    if (a < b) std::fill(labels.begin() + (size_t)(y - wy0) * ww + (a - wx0), labels.begin() + (size_t)(y - wy0) * ww + (b - wx0), l);
+                }
                 Pt& tl = tls[l - 1]; Pt& br = brs[l - 1];
                 tl.x = std::min(tl.x, runs[k].x0); tl.y = std::min(tl.y, y);
                 br.x = std::max(br.x, runs[k].x1); br.y = std::max(br.y, y + 1);
@@ -170,13 +250,17 @@ struct Finder {
             if (e.second > 0) edges.insert(e.first);
     }
 
+    // phase times of resolveConflicts (ISX_SEAMFIND_TIMING)
+    double t_tips = 0, t_est = 0, t_upd = 0, t_rec = 0, t_wb = 0;
+    static double tnow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
     bool has_only_one_neighbor(int comp) const {   // S:574-582
         auto b = edges.lower_bound({comp, INT_MIN});
         auto e = edges.upper_bound({comp, INT_MAX});
         return b != e && std::next(b) == e;
     }
 
-    bool close_to_contour(int y, int x, const std::vector<unsigned char>& m) const {   // S:585-604 on the contour mask of m
+    bool close_to_contour(int y, int x, const MaskView& m) const {   // S:585-604 on the contour mask of m
         for (int dy = -2; dy <= 2; ++dy)
             if (y + dy >= 0 && y + dy < uh)
                 for (int dx = -2; dx <= 2; ++dx)
@@ -249,7 +333,7 @@ struct Finder {
         const int rx = tls[comp].x, ry = tls[comp].y, rw = brs[comp].x - rx, rh = brs[comp].y - ry;
         const int roi[4] = {0, 0, rw, rh};
         isx_mat lab;
-        lab.data = labels.data() + (size_t)ry * uw + rx; lab.rows = rh; lab.cols = rw; lab.type = ISX_32SC1; lab.step = (size_t)uw * 4; lab.device = -1;
+        lab.data = &LW(ry, rx); lab.rows = rh; lab.cols = rw; lab.type = ISX_32SC1; lab.step = (size_t)ww * 4; lab.device = -1;
         std::vector<int> xy((size_t)2 * (rw + rh + 2));
         int len = 0, h = 0;
         ISX_TRY(isx_seam_estimate(image1, image2, tl1.x, tl1.y, tl2.x, tl2.y, utlx + rx, utly + ry, &lab, comp + 1, roi, p1.x - rx, p1.y - ry, p2.x - rx, p2.y - ry,
@@ -261,60 +345,68 @@ struct Finder {
         return ISX_OK;
     }
 
-    void update_labels_using_seam(int comp1, int comp2, const std::vector<Pt>& seam, bool horiz) {   // S:960-1093
+    // S:960-1093.  The work image `mask` (the component's rectangle; 255 = contour / seam pixel, else the number of the pixel's region)
+    // holds T = 16-bit values while the regions number fewer than 65 535 - the same numbers, so also the same collision of region 255 with
+    // the marker that the reference's int image has; more regions than that: the caller runs it again with T = int.
+    template <class T>
+    bool update_labels_t(std::vector<T>& mask, int comp1, int comp2, const std::vector<Pt>& seam, bool horiz) {
         const Pt tl = tls[comp1], br = brs[comp1];
         const int h = br.y - tl.y, w = br.x - tl.x;
-        std::vector<int>& mask = seam_mask_;     // member: keeps its storage between calls
         mask.assign((size_t)h * w, 0);
-        auto M = [&](int y, int x) -> int& { return mask[(size_t)y * w + x]; };
+        auto M = [&](int y, int x) -> T& { return mask[(size_t)y * w + x]; };
         for (const Pt& p : contours[comp1]) M(p.y - tl.y, p.x - tl.x) = 255;
         for (const Pt& p : seam) M(p.y - tl.y, p.x - tl.x) = 255;
         const int l1 = comp1 + 1, l2 = comp2 + 1;
-        // S:976-981: flood fills of the zero pixels of `mask`, seeded in raster order at zero pixels that carry label l1 —
+        // S:976-981: flood fills of the zero pixels of `mask`, seeded in raster order at zero pixels that carry label l1 -
         // done on row runs of zeros (union-find over vertically overlapping runs); a zero region without any l1 pixel is
         // never seeded and stays 0
         int nc = 0;
-        {
-            struct ZRun { int y, x0, x1; };
-            std::vector<ZRun> zr;
-            std::vector<int> rs((size_t)h + 1, 0);
-            for (int y = 0; y < h; ++y) {
-                rs[y] = (int)zr.size();
-                const int* row = &mask[(size_t)y * w];
-                int x = 0;
-                while (x < w) {
-                    while (x < w && row[x]) ++x;
-                    if (x >= w) break;
-                    int e = x + 1;
-                    while (e < w && !row[e]) ++e;
-                    zr.push_back({y, x, e});
-                    x = e;
+        struct ZRun { int y, x0, x1; };
+        std::vector<ZRun> zr;
+        std::vector<int> rs((size_t)h + 1, 0);
+        constexpr int PER8 = 8 / (int)sizeof(T);
+        for (int y = 0; y < h; ++y) {
+            rs[y] = (int)zr.size();
+            const T* row = &mask[(size_t)y * w];
+            int x = 0;
+            while (x < w) {
+                while (x < w && row[x]) ++x;
+                if (x >= w) break;
+                int e = x + 1;
+                while (e + PER8 <= w) { unsigned long long v; memcpy(&v, row + e, 8); if (v) break; e += PER8; }   // eight bytes of zeros per step
+                while (e < w && !row[e]) ++e;
+                zr.push_back({y, x, e});
+                x = e;
+            }
+        }
+        rs[h] = (int)zr.size();
+        std::vector<int> parent(zr.size());
+        for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+        auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+        for (int y = 1; y < h; ++y) {
+            int i = rs[y - 1], j = rs[y];
+            const int ie = rs[y], je = rs[y + 1];
+            while (i < ie && j < je) {
+                if (zr[i].x0 < zr[j].x1 && zr[j].x0 < zr[i].x1) { const int a = find(i), b = find(j); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+                if (zr[i].x1 <= zr[j].x1) ++i; else ++j;
+            }
+        }
+        std::vector<int> number(zr.size(), 0);
+        for (size_t k = 0; k < zr.size(); ++k) {   // raster order of the runs = raster order of their first l1 pixels
+            const int r = find((int)k);
+            if (number[r]) continue;
+            const int* lrow = &LW(zr[k].y + tl.y, tl.x);     // an intersection component's rectangle lies inside the window
+            for (int x = zr[k].x0; x < zr[k].x1; ++x)
+                if (lrow[x] == l1) {
+                    if (sizeof(T) < sizeof(int) && nc >= 65534) return false;
+                    number[r] = ++nc;
+                    break;
                 }
-            }
-            rs[h] = (int)zr.size();
-            std::vector<int> parent(zr.size());
-            for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
-            auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
-            for (int y = 1; y < h; ++y) {
-                int i = rs[y - 1], j = rs[y];
-                const int ie = rs[y], je = rs[y + 1];
-                while (i < ie && j < je) {
-                    if (zr[i].x0 < zr[j].x1 && zr[j].x0 < zr[i].x1) { const int a = find(i), b = find(j); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
-                    if (zr[i].x1 <= zr[j].x1) ++i; else ++j;
-                }
-            }
-            std::vector<int> number(zr.size(), 0);
-            for (size_t k = 0; k < zr.size(); ++k) {   // raster order of the runs = raster order of their first l1 pixels
-                const int r = find((int)k);
-                if (number[r]) continue;
-                const int* lrow = &labels[(size_t)(zr[k].y + tl.y) * uw + tl.x];
-                for (int x = zr[k].x0; x < zr[k].x1; ++x)
-                    if (lrow[x] == l1) { number[r] = ++nc; break; }
-            }
-            for (size_t k = 0; k < zr.size(); ++k) {
-                const int v = number[find((int)k)];
-                if (v) std::fill(mask.begin() + (size_t)zr[k].y * w + zr[k].x0, mask.begin() + (size_t)zr[k].y * w + zr[k].x1, v);
-            }
+        }
+        for (size_t k = 0; k < zr.size(); ++k) {
+            const int v = number[find((int)k)];
+            number[k] = v;                        // from here on: the region number of run k itself
+            if (v) std::fill(mask.begin() + (size_t)zr[k].y * w + zr[k].x0, mask.begin() + (size_t)zr[k].y * w + zr[k].x1, (T)v);
         }
         static const int dx[] = {-1, +1, 0, 0, -1, +1, -1, +1}, dy[] = {0, 0, -1, +1, -1, -1, +1, +1};
         for (const Pt& p : contours[comp1]) {
@@ -328,8 +420,8 @@ struct Finder {
         }
         for (const Pt& p : seam) {
             const int x = p.x - tl.x, y = p.y - tl.y;
-            if (horiz) M(y, x) = (y < h - 1 && M(y + 1, x) && M(y + 1, x) != 255) ? M(y + 1, x) : 0;
-            else M(y, x) = (x < w - 1 && M(y, x + 1) && M(y, x + 1) != 255) ? M(y, x + 1) : 0;
+            if (horiz) M(y, x) = (y < h - 1 && M(y + 1, x) && M(y + 1, x) != 255) ? M(y + 1, x) : (T)0;
+            else M(y, x) = (x < w - 1 && M(y, x + 1) && M(y, x + 1) != 255) ? M(y, x + 1) : (T)0;
         }
         std::map<int, int> connect2, connect_other;
         for (int i = 1; i <= nc; ++i) { connect2[i] = 0; connect_other[i] = 0; }
@@ -355,11 +447,19 @@ struct Finder {
             }
             if (kv.first >= 0) is_adj[kv.first] = res;
         }
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x) {
-                const int m = M(y, x);
-                if (m && m <= maxkey && is_adj[m]) labels[(size_t)(y + tl.y) * uw + x + tl.x] = l2;
-            }
+        // S:1081-1092 walks the whole rectangle; a pixel of it is either in a zero run (its value = the run's region number) or a contour / seam
+        // pixel (its value as the two loops above left it): the same assignments from the runs and the two point lists
+        auto adjacent = [&](int m) { return m && m <= maxkey && is_adj[m]; };
+        for (size_t k = 0; k < zr.size(); ++k)
+            if (adjacent(number[k])) std::fill(&LW(zr[k].y + tl.y, zr[k].x0 + tl.x), &LW(zr[k].y + tl.y, zr[k].x0 + tl.x) + (zr[k].x1 - zr[k].x0), l2);
+        for (const Pt& p : contours[comp1])
+            if (adjacent(M(p.y - tl.y, p.x - tl.x))) LW(p.y, p.x) = l2;
+        for (const Pt& p : seam)
+            if (adjacent(M(p.y - tl.y, p.x - tl.x))) LW(p.y, p.x) = l2;
+        return true;
+    }
+    void update_labels_using_seam(int comp1, int comp2, const std::vector<Pt>& seam, bool horiz) {
+        if (!update_labels_t<unsigned short>(seam_mask16_, comp1, comp2, seam, horiz)) update_labels_t<int>(seam_mask_, comp1, comp2, seam, horiz);
     }
 
     // S:457-487: bounding box and contour pixels of label l, scanning the component's OLD rectangle only (pixels of l
@@ -373,17 +473,29 @@ struct Finder {
         if (x0 >= x1 || y0 >= y1) return;
         // runs of label l in row y, clipped to the old rectangle widened by one pixel: everything below only asks whether a
         // pixel of [x0, x1) has a same-label neighbour left / right / above / below, which that window decides
-        const int wx0 = std::max(x0 - 1, 0), wx1 = std::min(x1 + 1, uw);
+        const int qx0 = std::max(x0 - 1, 0), qx1 = std::min(x1 + 1, uw);
         auto runs_of = [&](int y, std::vector<std::pair<int, int>>& out) {
             out.clear();
             if (y < 0 || y >= uh) return;
-            const int* row = &labels[(size_t)y * uw];
-            int x = wx0;
-            while (x < wx1) {
-                while (x < wx1 && row[x] != l) ++x;
-                if (x >= wx1) break;
+            if ((unsigned)(y - wy0) < (unsigned)wh && qx0 >= wx0 && qx1 <= wx0 + ww) {   // inside the label image (every intersection component is)
+                const int* row = &labels[(size_t)(y - wy0) * ww];
+                int x = qx0 - wx0;
+                const int xe = qx1 - wx0;
+                while (x < xe) {
+                    x = label_skip_to(row, x, xe, l);
+                    if (x >= xe) break;
+                    const int e = label_run_end(row, x + 1, xe, l);
+                    out.push_back({x + wx0, e + wx0});
+                    x = e;
+                }
+                return;
+            }
+            int x = qx0;
+            while (x < qx1) {
+                while (x < qx1 && L(y, x) != l) ++x;
+                if (x >= qx1) break;
                 int e = x + 1;
-                while (e < wx1 && row[e] == l) ++e;
+                while (e < qx1 && L(y, e) == l) ++e;
                 out.push_back({x, e});
                 x = e;
             }
@@ -434,20 +546,32 @@ struct Finder {
             if (has_only_one_neighbor(c1)) {
                 for (int y = tls[c1].y; y < brs[c1].y; ++y)
                     for (int x = tls[c1].x; x < brs[c1].x; ++x)
-                        if (L(y, x) == l1) labels[(size_t)y * uw + x] = l2;
+                        if (L(y, x) == l1) LW(y, x) = l2;
                 states[c1] = states[c2] == FIRST ? SECOND : FIRST;
             } else {
                 Pt p1, p2;
-                if (get_seam_tips(c1, c2, p1, p2)) {
+                const double ta = tnow();
+                const bool tips = get_seam_tips(c1, c2, p1, p2);
+                t_tips += tnow() - ta;
+                if (tips) {
                     std::vector<Pt> seam;
                     bool horiz = false, found = false;
+                    const double tb = tnow();
                     ISX_TRY(estimate_seam(image1, image2, tl1, tl2, c1, p1, p2, seam, horiz, found));
+                    const double tc = tnow();
                     if (found) update_labels_using_seam(c1, c2, seam, horiz);
+                    t_est += tc - tb; t_upd += tnow() - tc;
                 }
                 states[c1] = states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
             }
+            // S:457-487 recomputes the rectangle and contour of both labels.  Those of c2 are never read again unless c2 is itself an
+            // intersection component: only such a component is ever the first of a conflicting edge (its neighbours are FIRST- or SECOND-only
+            // components, whose states never change), and tls_ / brs_ / contours_ are read for the first component only - so the scan of a
+            // whole tile's rectangle that the second call would be is skipped, with nothing observable changed
+            const double td = tnow();
             recompute_region(c1, l1);
-            recompute_region(c2, l2);
+            if (states[c2] & INTERS) recompute_region(c2, l2);
+            t_rec += tnow() - td;
             edges.erase({c1, c2});
             edges.erase({c2, c1});
         }
@@ -459,14 +583,23 @@ struct Finder {
         for (size_t i = 0; i < states.size(); ++i) { is_first[i + 1] = (states[i] & FIRST) ? 1 : 0; is_second[i + 1] = (states[i] & SECOND) ? 1 : 0; }
         const int ux0 = std::max(tl1.x, tl2.x) - utlx, ux1 = std::min(tl1.x + cols1, tl2.x + cols2) - utlx;   // intersection in union coordinates
         const int uy0 = std::max(tl1.y, tl2.y) - utly, uy1 = std::min(tl1.y + rows1, tl2.y + rows2) - utly;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int uy = uy0; uy < uy1; ++uy) {
-                const int* lrow = &labels[(size_t)uy * uw];
-                unsigned char* m1 = mask1 + (size_t)(uy + dy1) * step1 + dx1;   // indexed by the union x
-                unsigned char* m2 = mask2 + (size_t)(uy + dy2) * step2 + dx2;
-                if (pass == 0) { for (int ux = ux0; ux < ux1; ++ux) if (is_first[lrow[ux]] & (m1[ux] != 0)) m2[ux] = 0; }
-                else { for (int ux = ux0; ux < ux1; ++ux) if (is_second[lrow[ux]] & (m2[ux] != 0)) m1[ux] = 0; }
+        const double te = tnow();
+        // one pass: at a pixel the second loop of the reference (S:509-523) reads mask2 as its first loop (S:495-507) left it AT THAT PIXEL.
+        // Row by row over the runs of equal label (eight labels per step), so that what is done per pixel is a byte select
+        for (int uy = uy0; uy < uy1; ++uy) {
+            const int* lrow = &labels[(size_t)(uy - wy0) * ww] - wx0;   // indexed by the union x; the intersection rectangle lies inside the window
+            unsigned char* m1 = mask1 + (size_t)(uy + dy1) * step1 + dx1;
+            unsigned char* m2 = mask2 + (size_t)(uy + dy2) * step2 + dx2;
+            int ux = ux0;
+            while (ux < ux1) {
+                const int l = lrow[ux];
+                const int e = label_run_end(lrow, ux + 1, ux1, l);
+                if (is_first[l]) clear_where(m2 + ux, m1 + ux, e - ux);
+                if (is_second[l]) clear_where(m1 + ux, m2 + ux, e - ux);
+                ux = e;
             }
+        }
+        t_wb += tnow() - te;
         return ISX_OK;
     }
 
@@ -478,20 +611,22 @@ struct Finder {
         utlx = std::min(tl1.x, tl2.x); utly = std::min(tl1.y, tl2.y);
         uw = std::max(tl1.x + c1, tl2.x + c2) - utlx;
         uh = std::max(tl1.y + r1, tl2.y + r2) - utly;
-        mask1_.assign((size_t)uw * uh, 0);
-        mask2_.assign((size_t)uw * uh, 0);
-        for (int y = 0; y < r1; ++y) memcpy(&mask1_[(size_t)(y + tl1.y - utly) * uw + (tl1.x - utlx)], mask1 + (size_t)y * step1, (size_t)c1);
-        for (int y = 0; y < r2; ++y) memcpy(&mask2_[(size_t)(y + tl2.y - utly) * uw + (tl2.x - utlx)], mask2 + (size_t)y * step2, (size_t)c2);
+        mask1_.p = mask1; mask1_.step = step1; mask1_.ox = tl1.x - utlx; mask1_.oy = tl1.y - utly; mask1_.rows = r1; mask1_.cols = c1;
+        mask2_.p = mask2; mask2_.step = step2; mask2_.ox = tl2.x - utlx; mask2_.oy = tl2.y - utly; mask2_.rows = r2; mask2_.cols = c2;
+        // the label image's window: the intersection rectangle widened by one pixel, clipped to the union
+        wx0 = std::max(itlx - utlx - 1, 0); wy0 = std::max(itly - utly - 1, 0);
+        ww = std::min(ibrx - utlx + 1, uw) - wx0; wh = std::min(ibry - utly + 1, uh) - wy0;
         const bool tm = getenv("ISX_SEAMFIND_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        double t0 = now();
+        t_tips = t_est = t_upd = t_rec = t_wb = 0;
         double t1 = now();
         find_components();
         double t2 = now();
         find_edges();
         double t3 = now();
         int rc = resolve_conflicts(image1, image2, tl1, tl2, mask1, step1, r1, c1, mask2, step2, r2, c2);
-        if (tm) fprintf(stderr, "seamfind: (contour masks on demand) %.1f ms, components %.1f ms, edges %.1f ms, resolve %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
+        if (tm) fprintf(stderr, "seamfind: components %.2f ms, edges %.2f ms, resolve %.2f ms (tips %.2f, estimateSeam %.2f, label update %.2f, region recompute %.2f, mask write-back %.2f)\n",
+                        t2 - t1, t3 - t2, now() - t3, t_tips, t_est, t_upd, t_rec, t_wb);
         return rc;
     }
 };
