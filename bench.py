@@ -229,6 +229,24 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
             out["%s_%s" % (mem, pname)] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),
                                            "d2h_MB": round(d2h / 1e6, 1), "pcie_GBs": round((h2d + d2h) / dt / 1e9, 1), "steps": n_host}
             del warper, blender
+    # the link alone, one direction at a time (pageable host memory, as a cv::Mat is): what the host legs above are made of
+    nb = int(max(v["h2d_MB"] for k, v in out.items() if k.startswith("host_")) * 1e6 / 2)
+    hbuf, dbuf = np.empty(nb, np.uint8), torch.empty(nb, dtype=torch.uint8, device=dev)
+    ht = torch.from_numpy(hbuf)
+    rates = {}
+    for name, fn in (("h2d_GBs", lambda: dbuf.copy_(ht)), ("d2h_GBs", lambda: ht.copy_(dbuf))):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        rates[name] = round(5 * nb / (time.perf_counter() - t0) / 1e9, 1)
+    hl = out.get("host_f32")
+    if hl:
+        rates["serial_bound_ms"] = round(hl["h2d_MB"] / rates["h2d_GBs"] + hl["d2h_MB"] / rates["d2h_GBs"], 3)
+        rates["overlap"] = ("none: every cv::Mat call returns with its outputs delivered and its inputs consumed, so copies of different calls cannot "
+                            "overlap; measured / serial bound = %.2f" % (hl["ms_per_pair"] / max(rates["serial_bound_ms"], 1e-9)))
+    out["link"] = rates
     torch.cuda.empty_cache()
     return out
 

@@ -19,6 +19,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <cstdio>
 #include <vector>
 
 #include "imagestitch_hip.h"
@@ -152,6 +153,22 @@ public:
         dst_mask.create(h, w, ISX_8UC1);
         check(isx_blender_blend(h_, dst.c(), dst_mask.c()));
     }
+    // Not in the reference: blend() of several prepared + fed blenders of one rig in ONE chain of launches (isx_blender_blend_batch);
+    // dsts / dst_masks are allocated like blend()'s, every result is bit-identical to the blender's own blend().
+    static void blendBatch(const std::vector<Blender*>& bs, std::vector<Mat>& dsts, std::vector<Mat>& dst_masks) {
+        std::vector<isx_blender*> hs;
+        std::vector<isx_mat> d, m;
+        dsts.resize(bs.size()); dst_masks.resize(bs.size());
+        for (size_t i = 0; i < bs.size(); ++i) {
+            int w, h;
+            check(isx_blender_result_size(bs[i]->h_, &w, &h));
+            if (bs[i]->win_x1_ > bs[i]->win_x0_) w = bs[i]->win_x1_ - bs[i]->win_x0_;
+            if (dsts[i].empty() || dsts[i].rows() != h || dsts[i].cols() != w) dsts[i].create(h, w, ISX_16SC3);
+            dst_masks[i].create(h, w, ISX_8UC1);
+            hs.push_back(bs[i]->h_); d.push_back(*dsts[i].c()); m.push_back(*dst_masks[i].c());
+        }
+        if (!bs.empty()) check(isx_blender_blend_batch(hs.data(), (int)bs.size(), d.data(), m.data()));
+    }
     void setStream(void* hip_stream) { check(isx_blender_set_stream(h_, hip_stream)); }
     // Not in the reference (see imagestitch_hip.h): the deferred cycle (1: fed device mats stay valid until blend(); 2: feed() copies
     // them, OpenCV's contract) and the column window of a panorama that is cut into strips across GPUs.
@@ -211,13 +228,17 @@ private:
     int device_;
 };
 
-// cv::imread(path) for .bmp files (W:166) / cv::imwrite(path, img) for .bmp and .jpg (W:155-156,315; "pano.jpg" S:1282)
+// cv::imread(path) (W:166): the decoder follows the file's signature, as OpenCV's does - "BM" bitmaps and JFIF / Exif JPEGs;
+// cv::imwrite(path, img) for .bmp and .jpg (W:155-156,315; "pano.jpg" S:1282)
 inline Mat imread(const char* path) {
+    unsigned char sig[2] = {0, 0};
+    if (FILE* f = std::fopen(path, "rb")) { if (std::fread(sig, 1, 2, f) != 2) sig[0] = sig[1] = 0; std::fclose(f); }
+    const bool jpeg = sig[0] == 0xFF && sig[1] == 0xD8;
     int rows = 0, cols = 0;
-    check(isx_bmp_size(path, &rows, &cols));
+    check(jpeg ? isx_jpeg_size(path, &rows, &cols) : isx_bmp_size(path, &rows, &cols));
     Mat m;
     m.create(rows, cols, ISX_8UC3);
-    check(isx_bmp_read(path, m.c()));
+    check(jpeg ? isx_jpeg_read(path, m.c()) : isx_bmp_read(path, m.c()));
     return m;
 }
 // the format follows the extension, as in OpenCV: .jpg / .jpeg -> baseline JFIF at cv::IMWRITE_JPEG_QUALITY (default 95), else .bmp

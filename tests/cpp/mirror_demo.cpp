@@ -104,6 +104,21 @@ int main(int argc, char** argv) {
             dump(argv[6], strip == 0 ? "stripmask0" : "stripmask1", part_mask);
         }
         blender->setWindow(0, 0);
+        // two mosaics of the rig in ONE chain of launches (Blender::blendBatch), fed the CV_8UC3 tiles as they come out of warp()
+        {
+            auto b0 = isx::Blender::createDefault(isx::Blender::MULTI_BAND, false), b1 = isx::Blender::createDefault(isx::Blender::MULTI_BAND, false);
+            for (isx::Blender* b : {b0.get(), b1.get()}) {
+                static_cast<isx::MultiBandBlender*>(b)->setNumBands(4);
+                b->setDeferredLevel0(2);
+                b->prepare(corners, sizes);
+                for (int k = 0; k < num_images; ++k) b->feed(images_warped[k], masks_warped[k], corners[k]);
+            }
+            std::vector<isx::Mat> outs, out_masks;
+            isx::Blender::blendBatch({b0.get(), b1.get()}, outs, out_masks);
+            dump(argv[6], "batch0", outs[0]);
+            dump(argv[6], "batch1", outs[1]);
+            dump(argv[6], "batchmask1", out_masks[1]);
+        }
         // error behaviour: feed after blend must throw like a CV_Assert would
         try { blender->feed(result, result_mask, isx::Point(0, 0)); printf("no-throw\n"); return 4; }
         catch (const isx::Exception& e) { printf("throws %d\n", e.code); }

@@ -74,6 +74,9 @@ def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path, demo):
             x0, xe = 384 * k, min(384 * (k + 1), c)
             assert (sr, sc) == (r, 384)
             assert np.array_equal(part[:, :xe - x0], od[:, x0:xe]) and np.array_equal(pm[:, :xe - x0], om[:, x0:xe])
+        for k in range(2):        # Blender::blendBatch of two blenders fed CV_8UC3 tiles: both mosaics are the serial blend's
+            assert np.array_equal(np.fromfile(str(tmp_path / ("o_batch%d.raw" % k)), np.int16).reshape(r, c, 3), od)
+        assert np.array_equal(np.fromfile(str(tmp_path / "o_batchmask1.raw"), np.uint8).reshape(r, c), om)
 
 
 def test_cpp_mirror_default_demo_stage(gpu, oracle, tmp_path):
