@@ -29,9 +29,14 @@ b cycle_copy_i16 --cycle copy --precision i16
 b config3_16pairs_graph --pairs 16 --graph
 b config3_16pairs_streams --pairs 16
 b config4_4pairs_per_gpu_streams --pairs 4
+b config3_16pairs_batch_one_stream --pairs 16 --batch
+b config3_16pairs_batch_3streams --pairs 16 --batch --streams 3
+b config3_16pairs_one_stream --pairs 16 --streams 1
+b config4_4pairs_batch_one_stream --pairs 4 --batch
 b config4_forcedist_chunk --force-dist --pairs 4 --gather chunk
 b config4_forcedist_single --force-dist --pairs 4 --gather single
 b config4_forcedist_chunk_isx --force-dist --pairs 4 --gather chunk --gather-backend isx
+b config4_forcedist_chunk_p2p --force-dist --pairs 4 --gather chunk --gather-backend p2p
 b config5_ring8_8k --kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 5 --warmup 2
 b config5_8k_pair --kind spherical --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3
 # 4b. config 5 as ONE panorama in column strips: every rank's share at 2 / 4 / 8 ranks, each alone on this GPU (no gather)
