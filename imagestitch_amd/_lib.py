@@ -64,6 +64,7 @@ _SIGS = {
     "isx_remap": [_MP, _MP, _MP, C.c_int, C.c_int, _MP, C.c_int, C.c_void_p],
     "isx_warper_set_roi_cache": [C.c_void_p, C.c_int],
     "isx_warper_verify": [C.c_void_p],
+    "isx_warper_verify_is_light": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "isx_warper_verify_after": [C.c_void_p, C.c_void_p],
     "isx_blender_set_mark_event": [C.c_void_p, C.c_void_p, C.c_int],
     "isx_blender_set_window": [C.c_void_p, C.c_int, C.c_int],

@@ -1068,7 +1068,18 @@ int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
         ISX_HIP(hipEventCreateWithFlags(&w->ev_warp, hipEventDisableTiming));
         ISX_HIP(hipEventCreateWithFlags(&w->ev_scan, hipEventDisableTiming));
     }
-    if (after) ISX_HIP(hipStreamWaitEvent(w->side, after, 0));
+    // The scans read the projection and the source size, never an image: nothing they need comes from the main stream.  The event only
+    // PLACES them (full scans are VALU-bound and should start under memory-bound work).  A border scan is one workgroup: it starts right
+    // away, with no event on the main stream at all - unless that stream is being captured, where the wait is what forks the side
+    // stream into the graph.
+    bool cheap = getenv("ISX_VERIFY_ORDERED") == nullptr;
+    for (const isx_warper::Pending& pd : w->pending)
+        cheap = cheap && (pd.proj.kind == ISX_WARP_SPHERICAL || cyl_extrema_on_border(pd.proj, pd.k, pd.rinv, pd.sw, pd.sh));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (cheap) ISX_HIP(hipStreamIsCapturing(st, &cs));
+    if (cheap && cs == hipStreamCaptureStatusNone) {
+        // nothing to wait for
+    } else if (after) ISX_HIP(hipStreamWaitEvent(w->side, after, 0));
     else {
         ISX_HIP(hipEventRecord(w->ev_warp, st));
         ISX_HIP(hipStreamWaitEvent(w->side, w->ev_warp, 0));
@@ -1625,6 +1636,14 @@ int isx_selftest_division(int device, int n, unsigned long long seed, int* misma
 int isx_warper_set_deferred_verify(isx_warper* w, int on) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_deferred_verify: null warper");
     w->defer_verify = on != 0;
+    return ISX_OK;
+}
+
+int isx_warper_verify_is_light(isx_warper* w, int src_cols, int src_rows, const float K[9], const float R[9], int* light) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr && light != nullptr && src_cols > 0 && src_rows > 0, ISX_ERR_INVALID, "isx_warper_verify_is_light: bad argument");
+    ISX_TRY(set_camera(w, K, R));
+    *light = (w->kind == ISX_WARP_SPHERICAL || cyl_extrema_on_border(w->proj, w->k, w->rinv, src_cols, src_rows)) ? 1 : 0;
     return ISX_OK;
 }
 

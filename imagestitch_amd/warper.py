@@ -156,6 +156,14 @@ class RotationWarper:
     def set_deferred_verify(self, on=True):
         check(self._lib.isx_warper_set_deferred_verify(self._h, int(bool(on))))
 
+    def verify_is_light(self, src_size, K, R):
+        """isx_warper_verify_is_light: the planned warp's ROI verification is a one-workgroup border scan (no need to place it)."""
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        v = C.c_int()
+        check(self._lib.isx_warper_verify_is_light(self._h, int(src_size[0]), int(src_size[1]), kp, rp, C.byref(v)))
+        return bool(v.value)
+
     def verify(self):
         """Enqueue the queued verification scans of planned warps behind the stream's current position."""
         check(self._lib.isx_warper_verify(self._h))

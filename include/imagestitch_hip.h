@@ -173,6 +173,12 @@ int isx_warper_set_deferred_verify(isx_warper* w, int on);
  * panorama (imagestitch_amd/mosaic.py: tile_columns_for_window gives the range).  (0, 0) = the whole tile again.              */
 int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1);
 int isx_warper_verify(isx_warper* w);
+/* Scheduling hint (nothing in the reference): is the verification of a planned warp of a src_cols x src_rows source under (K, R) a
+ * border scan - one workgroup over the 2 (W + H) border pixels, which starts at once, with no event on the handle's stream - (1), or
+ * the full detectResultRoi scan of every source pixel (0), which is worth placing under memory-bound work
+ * (isx_blender_set_mark_event + isx_warper_verify_after)?  Spherical: always 1.  Cylindrical: 1 when the extrema provably lie on the
+ * border (the image in front of the camera, no pole within two pixels of it).                                                          */
+int isx_warper_verify_is_light(isx_warper* w, int src_cols, int src_rows, const float K[9], const float R[9], int* light);
 /* Same, but the scans start once `hip_event` (a hipEvent_t already recorded, e.g. by
  * isx_blender_set_mark_event during blend()) has completed instead of at the stream's current position.  */
 int isx_warper_verify_after(isx_warper* w, void* hip_event);
