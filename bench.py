@@ -451,8 +451,11 @@ def main():
         if use_dist:
             for p, v in zip(pairs, views[0]):
                 p.out = v
-        for p in pairs:
-            p.capture()
+        if args.batch and not use_dist:
+            batch_graph, _ = PairStitcher.capture_batch(pairs)      # ONE graph: the batched launch chain of all pairs
+        else:
+            for p in pairs:
+                p.capture()
     state = {"i": 0}
 
     def post_chunk(b, i):
@@ -495,6 +498,9 @@ def main():
                 p.out = v
         if args.graph:
             b = 0                                  # the graphs run on their own streams and always write send[0]
+            if args.batch and not use_dist:
+                batch_graph.replay()
+                return
         if args.batch and not args.graph and not args.sync_roi:
             for g, ps in enumerate(pstreams):           # one batched chain per stream: the pairs created on that stream
                 group = pairs[g::len(pstreams)]

@@ -231,6 +231,38 @@ class PairStitcher:
         self.graph.replay()
         return self.out, self.out_mask
 
+    @staticmethod
+    def capture_batch(stitchers):
+        """step_batch of several stitchers captured into ONE hipGraph (BASELINE config 3: a batch of independent pairs as a graph
+        whose every launch spans all of them).  Returns (graph, stream); graph.replay() redoes the step of every stitcher."""
+        s0 = stitchers[0]
+        torch = s0.torch
+        gstream = torch.cuda.Stream(device=s0.device)
+        for s in stitchers:
+            va = s._verify_at_cfg
+            if s.mark is None and va is not None and va >= 0 and s.L >= 1 and not s.interleave and os.environ.get("ISX_VERIFY_AT", "") == "":
+                s.mark = torch.cuda.Event()
+                s.mark.record()
+                s.blender.set_mark_event(s.mark, min(va, s.L - 1))
+            s.gstream = gstream
+            s.warper.set_stream(gstream)
+            s.blender.set_stream(gstream)
+        gstream.wait_stream(torch.cuda.current_stream(s0.device))
+
+        def one():
+            PairStitcher.step_batch(stitchers)
+            for s in stitchers:
+                s.warper.join()
+        with torch.cuda.stream(gstream):
+            one()
+        torch.cuda.synchronize(s0.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=gstream, capture_error_mode="relaxed"):
+            one()
+        for s in stitchers:
+            s.graph = graph
+        return graph, gstream
+
     def check_plan(self):
         """Synchronises; raises IsxError(ISX_ERR_PLAN) if any planned step saw a different ROI."""
         return self.warper.plan_status()

@@ -313,6 +313,41 @@ def test_batched_blend_equals_the_serial_blends(gpu, prec_name):
             assert torch.equal(res[p][0], serial[p][0]), (prec_name, rep, p)
 
 
+def test_batched_chain_captured_as_one_hipgraph(gpu):
+    """BASELINE config 3 as ONE hipGraph: the batched launch chain of several pairs (PairStitcher.capture_batch) replayed - every mosaic equal
+    to the pair's own serial step, the planned ROIs verified inside the graph (a stale plan raises the flag on replay)."""
+    import torch
+    from imagestitch_amd._lib import IsxError
+    from imagestitch_amd.pipeline import PairStitcher
+    W, H, F, NP = 1280, 720, 1000.0, 7
+    dev = torch.device("cuda:0")
+    pairs, serial = [], []
+    for p in range(NP):
+        K, Rs = synth.camera_pair(W, H, F, yaw=(0.30, 0.36)[p % 2])
+        imgs = [torch.from_numpy(synth.make_tile(H, W, 1700 + 2 * p + i)).to(dev) for i in range(2)]
+        ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16")
+        out, mask = ps.step()
+        serial.append((out.clone(), mask.clone()))
+        pairs.append(ps)
+    graph, gstream = PairStitcher.capture_batch(pairs)
+    for rep in range(3):
+        for ps in pairs:
+            ps.out.fill_(-3); ps.out_mask.fill_(9)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        for p, ps in enumerate(pairs):
+            ps.check_plan()
+            assert torch.equal(ps.out_mask, serial[p][1]) and torch.equal(ps.out, serial[p][0]), (rep, p)
+    # new images, same rig: the replay reads the tensors in place
+    pairs[3].imgs[0].copy_(torch.from_numpy(synth.make_tile(H, W, 4242)).to(dev))
+    fresh = PairStitcher([t.clone() for t in pairs[3].imgs], pairs[3].K, pairs[3].Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16")
+    exp = [t.clone() for t in fresh.step()]
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pairs[3].out, exp[0]) and torch.equal(pairs[3].out_mask, exp[1])
+
+
 def test_batched_blend_falls_back_for_blenders_that_do_not_qualify(gpu):
     """a batch that mixes a deferred multi-band blender, an eager one and a windowed one: all blended, each as alone"""
     import torch

@@ -33,6 +33,8 @@ b config3_16pairs_batch_one_stream --pairs 16 --batch
 b config3_16pairs_batch_3streams --pairs 16 --batch --streams 3
 b config3_16pairs_one_stream --pairs 16 --streams 1
 b config4_4pairs_batch_one_stream --pairs 4 --batch
+b config3_16pairs_batch_graph --pairs 16 --batch --graph
+b config4_4pairs_batch_graph --pairs 4 --batch --graph
 b config4_forcedist_chunk --force-dist --pairs 4 --gather chunk
 b config4_forcedist_single --force-dist --pairs 4 --gather single
 b config4_forcedist_chunk_isx --force-dist --pairs 4 --gather chunk --gather-backend isx
