@@ -299,6 +299,8 @@ def main():
     ap.add_argument("--batch", action="store_true",
                     help="blend the pairs of a step in ONE chain of launches (isx_blender_blend_batch: every pyramid level of up to 6 mosaics per "
                          "launch) on one stream, instead of pair by pair spread over --streams")
+    ap.add_argument("--batch-size", type=int, default=6,
+                    help="--batch: pairs per launch chain (at most 6 = the library's limit): the warps of a chain's pairs are issued right before it")
     ap.add_argument("--shard", default="pairs", choices=["pairs", "strips"],
                     help="N > 1: pairs = every rank blends its own independent pairs (BASELINE config 4); strips = ONE panorama of --tiles tiles "
                          "per step, cut into N column strips: rank r warps and feeds only the tiles near its strip, blends the strip "
@@ -507,7 +509,8 @@ def main():
                 if ps is not None and use_dist:
                     ps.wait_event(ev_gather[b])
                 with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
-                    PairStitcher.step_batch(group)
+                    for q in range(0, len(group), max(args.batch_size, 1)):
+                        PairStitcher.step_batch(group[q:q + max(args.batch_size, 1)])
             if use_dist:
                 for i in range(len(pairs)):
                     ev_pair[b][i].record(pstreams[i % len(pstreams)] if pstreams[0] is not None else main)
