@@ -328,27 +328,49 @@ constexpr int PD_TY = 16;
 constexpr int PD_NR = 2 * PD_TY + 3;
 constexpr int PD_OW = WAVE - 2;
 constexpr int PD_WAVES = 8;
-constexpr int PD_RPW = (PD_NR + PD_WAVES - 1) / PD_WAVES;
 
 template <int M> __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv);
 
-template <int M, int SK>
-__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by, Px<M> (*hb)[WAVE]) {
+// pyrDown's row filter at one output column: c = pixel 2x, l1 / r1 = pixels 2x - 1 / 2x + 1, l2 / r2 = pixels 2x - 2 / 2x + 2;
+// tap5's association, the float precisions on (b, g) / (r, w) register pairs (packed fp32, each half rounded on its own)
+template <int M>
+__device__ __forceinline__ Px<M> pyr_down_row5(const Px<M>& c, const Px<M>& l1, const Px<M>& r1, const Px<M>& l2, const Px<M>& r2) {
     using WT = typename WorkT<M>::t;
+    Px<M> h;
+    if constexpr (M != M_I16) {
+        const f32x2 a0 = {c.c0, c.c1}, a1 = {c.c2, c.w}, b0 = {r1.c0, r1.c1}, b1 = {r1.c2, r1.w};
+        const f32x2 am0 = {l2.c0, l2.c1}, am1 = {l2.c2, l2.w}, bm0 = {l1.c0, l1.c1}, bm1 = {l1.c2, l1.w}, ap0 = {r2.c0, r2.c1}, ap1 = {r2.c2, r2.w};
+        const f32x2 h0 = ((a0 * splat2(6.f) + (bm0 + b0) * splat2(4.f)) + am0) + ap0;    // tap5: c * 6 + (l1 + r1) * 4 + l2 + r2
+        const f32x2 h1 = ((a1 * splat2(6.f) + (bm1 + b1) * splat2(4.f)) + am1) + ap1;
+        h.c0 = h0.x; h.c1 = h0.y; h.c2 = h1.x; h.w = h1.y;
+    } else {
+        h.c0 = tap5<WT>(c.c0, l1.c0, r1.c0, l2.c0, r2.c0);
+        h.c1 = tap5<WT>(c.c1, l1.c1, r1.c1, l2.c1, r2.c1);
+        h.c2 = tap5<WT>(c.c2, l1.c2, r1.c2, l2.c2, r2.c2);
+        h.w = tap5<float>(c.w, l1.w, r1.w, l2.w, r2.w);
+    }
+    return h;
+}
+
+// The row phase of a block: NR input rows starting at row `row0` of the source level (each through REFLECT_101), row-filtered for the
+// output column `ox` of this lane, into hb[0 .. NR).  (pyr_down_block: NR = NR rows from 2 oy0 - 2; the fused level-0 + level-1 kernel
+// of pyrdown_l0.inc: 41 rows.)
+template <int M, int SK, int NR>
+__device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& src, int ox, int row0, Px<M> (*hb)[WAVE]) {
+    constexpr int RPW = (NR + PD_WAVES - 1) / PD_WAVES;
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
     const int sh = (SK == SK_LEVEL) ? src.rows : s0.height;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
     const int cA = reflect101(2 * ox, sw), cB = reflect101(2 * ox + 1, sw);
     // Level 0: every row's two windows are issued before the first one is decoded (RawPair) - decoding inside the
     // loading loop made each of the wave's rows wait for its own loads, five memory latencies in a row.
-    Px<M> A[PD_RPW], B[PD_RPW];
-    RawPair rw[SK != SK_LEVEL ? PD_RPW : 1];
+    Px<M> A[RPW], B[RPW];
+    RawPair rw[SK != SK_LEVEL ? RPW : 1];
 #pragma unroll
-    for (int i = 0; i < PD_RPW; ++i) {
+    for (int i = 0; i < RPW; ++i) {
         int r = wv + PD_WAVES * i;
-        if (r < PD_NR) {
-            int iy = reflect101(2 * oy0 - 2 + r, sh);
+        if (r < NR) {
+            int iy = reflect101(row0 + r, sh);
             if constexpr (SK != SK_LEVEL) {
                 if (cB == cA + 1) rw[i] = src0_pair_issue<SK>(s0, cA, iy);
                 else rw[i].fast = false;
@@ -359,31 +381,25 @@ __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& s
         }
     }
 #pragma unroll
-    for (int i = 0; i < PD_RPW; ++i) {
+    for (int i = 0; i < RPW; ++i) {
         int r = wv + PD_WAVES * i;
-        if (r < PD_NR) {
+        if (r < NR) {
             if constexpr (SK != SK_LEVEL) {
-                int iy = reflect101(2 * oy0 - 2 + r, sh);
+                int iy = reflect101(row0 + r, sh);
                 if (rw[i].fast) src0_pair_finish<M, SK>(s0, cA, iy, rw[i], A[i], B[i]);
                 else { A[i] = load_src0<M, SK>(s0, cA, iy); B[i] = load_src0<M, SK>(s0, cB, iy); }
             }
-            Px<M> Am = shfl_up1<M>(A[i]), Bm = shfl_up1<M>(B[i]), Ap = shfl_down1<M>(A[i]);
-            Px<M> h;
-            if constexpr (M != M_I16) {   // the [1 4 6 4 1] row filter on (b, g) / (r, w) register pairs: packed fp32, each half rounded on its own
-                const f32x2 a0 = {A[i].c0, A[i].c1}, a1 = {A[i].c2, A[i].w}, b0 = {B[i].c0, B[i].c1}, b1 = {B[i].c2, B[i].w};
-                const f32x2 am0 = {Am.c0, Am.c1}, am1 = {Am.c2, Am.w}, bm0 = {Bm.c0, Bm.c1}, bm1 = {Bm.c2, Bm.w}, ap0 = {Ap.c0, Ap.c1}, ap1 = {Ap.c2, Ap.w};
-                const f32x2 h0 = ((a0 * splat2(6.f) + (bm0 + b0) * splat2(4.f)) + am0) + ap0;    // tap5: c * 6 + (l1 + r1) * 4 + l2 + r2
-                const f32x2 h1 = ((a1 * splat2(6.f) + (bm1 + b1) * splat2(4.f)) + am1) + ap1;
-                h.c0 = h0.x; h.c1 = h0.y; h.c2 = h1.x; h.w = h1.y;
-            } else {
-            h.c0 = tap5<WT>(A[i].c0, Bm.c0, B[i].c0, Am.c0, Ap.c0);
-            h.c1 = tap5<WT>(A[i].c1, Bm.c1, B[i].c1, Am.c1, Ap.c1);
-            h.c2 = tap5<WT>(A[i].c2, Bm.c2, B[i].c2, Am.c2, Ap.c2);
-            h.w = tap5<float>(A[i].w, Bm.w, B[i].w, Am.w, Ap.w);
-            }
+            const Px<M> h = pyr_down_row5<M>(A[i], shfl_up1<M>(B[i]), B[i], shfl_up1<M>(A[i]), shfl_down1<M>(A[i]));
             hb[r][lane] = h;
         }
     }
+}
+
+template <int M, int SK>
+__device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by, Px<M> (*hb)[WAVE]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
+    pyr_down_rows<M, SK, PD_NR>(s0, src, ox, 2 * oy0 - 2, hb);
     __syncthreads();
     pyr_down_columns<M>(hb, dst, ox, oy0, lane, wv);
 }

@@ -40,6 +40,8 @@ def launch_name(kname, full):
         return "collapse_gather_final"
     if kname == "k_collapse_gather":
         return "collapse_gather_final" if re.search(r"k_collapse_gather<\d+, -?\d+, true", full) else "collapse_gather"
+    if kname == "k_pyr_down0_u8":        # round 3: level 0 -> 1 of CV_8UC3 tiles
+        return "pyr_down_l0"
     if kname in ("k_pyr_down", "k_pyr_down_multi"):
         return "pyr_down" if re.search(r"<\d+, -1>", full) else "pyr_down_l0"
     if kname == "k_collapse":
