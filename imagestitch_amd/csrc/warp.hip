@@ -1231,9 +1231,20 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
     // previous consumer); the mismatch counter keys[5] is sticky
+    // Round 3: where both extrema of u and v provably lie on the image's border (cyl_extrema_on_border: the image in front of the camera, no
+    // pole of the cylinder within two pixels of it) the scan is the 2 (W + H) border pixels in one workgroup instead of all W x H: away from
+    // the poles neither u nor v has a stationary point, so a pixel one step inside the border differs from the border's extremum by about a
+    // whole unit (|grad| ~ scale / focal per pixel), four orders of magnitude above the rounding of mapForward - the extrema over the border
+    // ARE the extrema over the image, and the candidates below are evaluated exactly as before.  (ISX_ROI_FULL_SCAN: the full scan always.)
+    static const bool full_always = getenv("ISX_ROI_FULL_SCAN") != nullptr;
+    const bool border_only = !full_always && cyl_extrema_on_border(w->proj, w->k, w->rinv, sw, sh);
     dim3 grid(cdiv(sw, 256), cdiv(sh, SYNC_ROWS));
+    float4* blk = nullptr;
+    if (border_only) {
+        ISX_LAUNCH("roi_border", 0.0, st, k_roi_border_sph, dim3(1), dim3(1024), 0, w->proj, sw, sh, (unsigned*)nullptr, cand, CAND_CAP, count);
+    } else {
     ISX_TRY(w->scan_blk.reserve((size_t)grid.x * grid.y * sizeof(float4)));
-    float4* blk = (float4*)w->scan_blk.p;
+    blk = (float4*)w->scan_blk.p;
     ISX_LAUNCH("roi_scan", 0.0, st, k_roi_scan, grid, dim3(256), 0, w->proj, sw, sh, (unsigned*)nullptr, SYNC_ROWS, blk);
     // The scan ranked the pixels by the stand-ins (d, q).  Collect every pixel whose stand-in is within
     // a tolerance of one of the four extrema and evaluate mapForward on exactly those with the host's
@@ -1243,6 +1254,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     static_assert(SYNC_ROWS % CAND_ROWS == 0, "a candidate block lies inside one scan block");
     ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(grid.x, cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, cand, CAND_CAP, count, CAND_ROWS,
                (const float4*)blk, SYNC_ROWS, (int)grid.y);
+    }
     if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
     ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
     ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
