@@ -146,7 +146,7 @@ void idct_islow(const short* coef, const unsigned short* q, unsigned char* out, 
                    d4 = (long)coef[32 + x] * q[32 + x], d5 = (long)coef[40 + x] * q[40 + x], d6 = (long)coef[48 + x] * q[48 + x], d7 = (long)coef[56 + x] * q[56 + x];
         long z1 = (d2 + d6) * F_0_541196100;
         long tmp2 = z1 + d6 * (-F_1_847759065), tmp3 = z1 + d2 * F_0_765366865;
-        long tmp0 = (d0 + d4) << CB, tmp1 = (d0 - d4) << CB;
+        long tmp0 = (d0 + d4) * (1L << CB), tmp1 = (d0 - d4) * (1L << CB);      // libjpeg's LEFT_SHIFT of a possibly negative value, as a multiplication
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = d7; tmp1 = d5; tmp2 = d3; tmp3 = d1;
         z1 = tmp0 + tmp3; long z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3;
@@ -164,7 +164,7 @@ void idct_islow(const short* coef, const unsigned short* q, unsigned char* out, 
         const int* w = ws + 8 * y;
         long z1 = ((long)w[2] + w[6]) * F_0_541196100;
         long tmp2 = z1 + (long)w[6] * (-F_1_847759065), tmp3 = z1 + (long)w[2] * F_0_765366865;
-        long tmp0 = ((long)w[0] + w[4]) << CB, tmp1 = ((long)w[0] - w[4]) << CB;
+        long tmp0 = ((long)w[0] + w[4]) * (1L << CB), tmp1 = ((long)w[0] - w[4]) * (1L << CB);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; long z2 = tmp1 + tmp2, z3 = tmp0 + tmp2, z4 = tmp1 + tmp3;
