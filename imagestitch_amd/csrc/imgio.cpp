@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -40,7 +41,7 @@ int parse_header(FILE* f, const char* path, BmpInfo& bi) {
     bi.width = (int)rd32(h + 18);
     const int hh = (int)rd32(h + 22);
     bi.top_down = hh < 0;
-    bi.height = hh < 0 ? -hh : hh;
+    bi.height = hh == INT_MIN ? 0 : (hh < 0 ? -hh : hh);      // INT_MIN has no negation: refused below as a bad size
     bi.bpp = (int)rd16(h + 28);
     const unsigned comp = rd32(h + 30);
     bi.ncolors = rd32(h + 46);
