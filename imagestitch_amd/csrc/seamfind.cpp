@@ -616,7 +616,7 @@ struct Finder {
         // the label image's window: the intersection rectangle widened by one pixel, clipped to the union
         wx0 = std::max(itlx - utlx - 1, 0); wy0 = std::max(itly - utly - 1, 0);
         ww = std::min(ibrx - utlx + 1, uw) - wx0; wh = std::min(ibry - utly + 1, uh) - wy0;
-        const bool tm = getenv("ISX_SEAMFIND_TIMING") != nullptr;
+        static const bool tm = getenv("ISX_SEAMFIND_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         t_tips = t_est = t_upd = t_rec = t_wb = 0;
         double t1 = now();

@@ -1072,7 +1072,8 @@ int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
     // PLACES them (full scans are VALU-bound and should start under memory-bound work).  A border scan is one workgroup: it starts right
     // away, with no event on the main stream at all - unless that stream is being captured, where the wait is what forks the side
     // stream into the graph.
-    bool cheap = getenv("ISX_VERIFY_ORDERED") == nullptr;
+    static const bool ordered_always = getenv("ISX_VERIFY_ORDERED") != nullptr;      // A/B aid: the placed form for every scan
+    bool cheap = !ordered_always;
     for (const isx_warper::Pending& pd : w->pending)
         cheap = cheap && (pd.proj.kind == ISX_WARP_SPHERICAL || cyl_extrema_on_border(pd.proj, pd.k, pd.rinv, pd.sw, pd.sh));
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -68,6 +68,30 @@ for i in range(N):
     bad += not (torch.equal(a.out, ref) and torch.equal(b.out, ref))
 res["two_steps_in_flight"] = {"differing_steps": int(bad)}
 del a, b
+# round 3: six pairs as ONE launch chain (isx_blender_blend_batch), eager and captured into one hipGraph
+pairs = [PairStitcher(tiles(40 + i), K, Rs, F, "cylindrical", 5, _lib.PREC_F32, 0, None, "int16") for i in range(6)]
+refs = []
+for ps in pairs:
+    o, m = ps.step()
+    refs.append((o.clone(), m.clone()))
+bad = 0
+for _ in range(N // 4):
+    PairStitcher.step_batch(pairs)
+    torch.cuda.synchronize()
+    bad += sum(not (torch.equal(ps.out, r[0]) and torch.equal(ps.out_mask, r[1])) for ps, r in zip(pairs, refs))
+for ps in pairs:
+    ps.check_plan()
+res["six_pairs_one_chain"] = {"differing_mosaics": int(bad), "mosaics_checked": (N // 4) * 6}
+graph, _gs = PairStitcher.capture_batch(pairs)
+bad = 0
+for _ in range(N // 4):
+    graph.replay()
+    torch.cuda.synchronize()
+    bad += sum(not (torch.equal(ps.out, r[0]) and torch.equal(ps.out_mask, r[1])) for ps, r in zip(pairs, refs))
+for ps in pairs:
+    ps.check_plan()
+res["six_pairs_one_chain_as_a_graph"] = {"differing_mosaics": int(bad), "mosaics_checked": (N // 4) * 6}
+del pairs, refs, graph
 K6, R6 = synth.camera_ring(1920, 1080, 1500.0, 6, 0.55)
 gen.manual_seed(5)
 t6 = [torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, device=dev, generator=gen) for _ in range(6)]
