@@ -345,6 +345,11 @@ def main():
         args.streams = 1 if args.pairs == 1 else min(args.pairs, 4)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_dist.py): every rank on cuda:0 with gloo for the barriers / reductions, so that a one-GPU box can walk the
+    # whole N > 1 code path of this file (with --gather-backend p2p the gathers are real device copies through HIP IPC)
+    one_gpu = os.environ.get("ISX_BENCH_ONE_GPU", "") == "1"
+    if one_gpu:
+        local = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch %d ranks (python -m torch.distributed.run --nproc-per-node %d ...), "
                          "or run `python bench.py --gpus %d` without WORLD_SIZE set and it starts them itself" % (args.gpus, world, args.gpus, args.gpus, args.gpus))
@@ -360,7 +365,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     lib = imagestitch_amd.load()
     prec = {"i16": _lib.PREC_I16, "f32": _lib.PREC_F32, "f16acc32": _lib.PREC_F16ACC32}[args.precision]
 
