@@ -300,8 +300,9 @@ def test_config4_per_rank_step_at_4k_with_chunked_gathers(gpu):
     assert ret.get(0), dict(ret)
 
 
-@pytest.mark.parametrize("backend,gather", [("p2p", "chunk"), ("p2p", "single"), ("torch", "chunk"), ("torch", "single")])
-def test_bench_walks_its_n2_path_on_one_gpu(gpu, tmp_path, backend, gather):
+@pytest.mark.parametrize("backend,gather,shard", [("p2p", "chunk", "pairs"), ("p2p", "single", "pairs"), ("torch", "chunk", "pairs"), ("torch", "single", "pairs"),
+                                                  ("p2p", "single", "strips")])
+def test_bench_walks_its_n2_path_on_one_gpu(gpu, tmp_path, backend, gather, shard):
     """bench.py's whole N > 1 branch (rank / world indexing, the send blocks, chunk offsets and events, the three timed legs, the reduction of
     the timings, rank 0's JSON line) at world size 2 on ONE GPU: both ranks on cuda:0 (ISX_BENCH_ONE_GPU=1: gloo for barriers and
     reductions), the gathers real device copies through HIP IPC (--gather-backend p2p) or torch.distributed's all-gather over gloo (the
@@ -317,11 +318,13 @@ def test_bench_walks_its_n2_path_on_one_gpu(gpu, tmp_path, backend, gather):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--pairs", "2", "--width", "1280", "--height", "720", "--focal", "1000",
            "--gather-backend", backend, "--gather", gather, "--no-cpu-baseline", "--no-dropin", "--no-live-traffic"]
+    if shard == "strips":      # ONE panorama of 6 tiles per step, cut into two column strips (strong scaling)
+        cmd += ["--shard", "strips", "--tiles", "6", "--yaw", "0.275"]
     out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 alone prints
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["pairs_per_gpu"] == 2
+    assert d["n_gpus"] == 2 and d["scaling"] == ("weak" if shard == "pairs" else "strong") and d["value"] > 0 and d["config"]["pairs_per_gpu"] == 2
     mg = d["multi_gpu"]
     assert mg["gather_backend"] == backend and mg["gather"] == gather and mg["send_bytes_per_rank"] > 0 and mg["gather_bus_GBs"] > 0 and mg["without_gather_Mpix_s"] > 0
