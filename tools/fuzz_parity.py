@@ -307,6 +307,48 @@ def case_strip(rng):
     assert np.array_equal(m[:, :xe - x0], om[:, x0:xe]) and np.array_equal(d[:, :xe - x0], od[:, x0:xe]), (n, bands, prec, x0, x1, act)
 
 
+def case_batch(rng):
+    """isx_blender_blend_batch: 2-7 blenders of one rig family (same bands / precision / input type, different tiles, sizes and corners;
+    now and then one that cannot share the chain: eager, windowed, or other bands) blended in ONE call - every result against the ORACLE's."""
+    from imagestitch_amd.blender import blend_batch
+    nb = int(rng.integers(2, 8))
+    bands, prec = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+    as_u8 = bool(rng.integers(0, 2))
+    out_f32 = prec != 0 and bool(rng.integers(0, 2))
+    blenders, expect, dsts, dmasks = [], [], [], []
+    for b in range(nb):
+        odd = int(rng.integers(0, 8)) == 0                     # a blender that does not qualify for the shared chain
+        n = int(rng.integers(1, 4))
+        sizes = [(int(rng.integers(40, 220)), int(rng.integers(8, 90))) for _ in range(n)]
+        x, corners = int(rng.integers(-50, 50)), []
+        for w, _ in sizes:
+            corners.append((x, int(rng.integers(-12, 12))))
+            x += int(rng.integers(max(w // 4, 1), w + 20))
+        bb = bands if not (odd and rng.integers(0, 2)) else int(rng.integers(1, 6))
+        imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for w, h in sizes]
+        masks = [(rng.random((h, w)) > 0.15).astype(np.uint8) * 255 for w, h in sizes]
+        ob = O.MultiBand(bb, prec)
+        ob.prepare(corners, sizes)
+        for im, m, c in zip(imgs, masks, corners):
+            ob.feed(im.astype(np.int16), m, c)
+        expect.append(ob.blend(out_f32))
+        mb = G.MultiBandBlender(False, bb, prec)
+        mb.set_deferred_level0(not (odd and bb == bands))      # the odd one with the family's bands runs the eager cycle
+        mb.prepare(corners, sizes)
+        for im, m, c in zip(imgs, masks, corners):
+            if as_u8:
+                mb.feed_u8(im, m, c)
+            else:
+                mb.feed(im.astype(np.int16), m, c)
+        blenders.append(mb)
+        w, h = mb.result_size()
+        dsts.append(np.full((h, w, 3), -5, np.float32 if out_f32 else np.int16))
+        dmasks.append(np.full((h, w), 7, np.uint8))
+    blend_batch(blenders, dsts, dmasks)
+    for b in range(nb):
+        assert np.array_equal(dmasks[b], expect[b][1]) and np.array_equal(dsts[b], expect[b][0]), (nb, b, bands, prec, as_u8, out_f32)
+
+
 def case_strip_feather(rng):
     """One column strip of a FeatherBlender mosaic against the oracle's whole blend; only the tiles that overlap the strip are fed."""
     n = int(rng.integers(1, 7))
@@ -348,7 +390,7 @@ def case_strip_feather(rng):
 
 
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair, case_strip, case_strip_feather]
+         case_linear_pair, case_strip, case_strip_feather, case_batch]
 
 
 def run(budget, seed0, verbose=True):
