@@ -178,8 +178,8 @@ struct Finder {
             const int ie = row_start[y], je = row_start[y + 1];
             while (i < ie && j < je) {
                 if (runs[i].cls == runs[j].cls && runs[i].x0 < runs[j].x1 && runs[j].x0 < runs[i].x1) {
-                    const int ra = find(i), rb = find(j);
-                    if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+                    const int pi = find(i), pj = find(j);
+                    if (pi != pj) parent[std::max(pi, pj)] = std::min(pi, pj);
                 }
                 if (runs[i].x1 <= runs[j].x1) ++i; else ++j;
             }
