@@ -871,7 +871,7 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
-    if (blockIdx.x * PD_OW >= dst.cols || blockIdx.y * PD_TY >= dst.rows || (int)blockIdx.x < ts.bx_lo[t] || (int)blockIdx.x >= ts.bx_hi[t]) return;
+    if ((int)blockIdx.x * PD_OW >= dst.cols || (int)blockIdx.y * PD_TY >= dst.rows || (int)blockIdx.x < ts.bx_lo[t] || (int)blockIdx.x >= ts.bx_hi[t]) return;
     __shared__ Px<M> hb[PD_NR][WAVE];
     pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y, hb);
 }
