@@ -566,8 +566,10 @@ def main():
     # would be charged to whichever kernel it overlaps.
     # It is the SECOND warm-up step (the first creates the plans), so that the remaining warm-up steps run at full rate
     # right before the timed region: the serialised step leaves the GPU mostly idle, and a 20-step region is only 5 ms long.
+    # W = 1: the one warm-up step is a planned step (it creates the plans) and the serialised step comes on top of it; W = 0: no
+    # planned step runs before the timed region (the serialised one still does: it picks the dominant kernel).
     gc.collect()
-    if args.warmup > 1:
+    if args.warmup >= 1:
         step()
     fence()
     lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_reset()
@@ -597,7 +599,7 @@ def main():
     # The collection itself ran before the warm-up: any idle stretch in front of the region starts it on a colder clock
     # (tools/probes/region_probe.py: 20 steps right after 5 ms of idle GPU run 3 % slower per step than after none).
     gc.disable()
-    for _ in range(max(args.warmup - 2, 0)):   # the rest of the W warm-up steps, exactly as the timed ones
+    for _ in range(max(args.warmup - 2, 1 if args.warmup >= 1 else 0)):   # the rest of the W warm-up steps, exactly as the timed ones (at least one: right behind the serialised step the GPU is idle)
         step()
     fence()
     t0 = time.perf_counter()
