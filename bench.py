@@ -156,40 +156,60 @@ def host_cpu():
     return {"cpu_model": model, "logical_cpus": os.cpu_count() or 1}
 
 def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
-    """The workload as a drop-in caller of the reference's interface gets it, timed AFTER the headline region:
-    every warp returns its corner to the host (W:160: one host round trip per tile, no ROI memo), feed() consumes its
-    inputs (W:305-308: isx_blender_set_deferred_level0 = 2 takes private copies of device mats; host mats are staged by
-    the library), blend() to CV_16SC3 + mask (W:313).  `device`: mats resident in HBM (zero copy).  `host`: every mat
-    is a host array as a cv::Mat is (pageable numpy memory; `host_pinned`: page-locked), i.e. PCIe-inclusive —
-    sources in, warped tiles + masks out, warped tiles + seam masks in again, mosaic + mask out."""
+    """The workload as a drop-in caller of the reference's interface gets it, timed AFTER the headline region.
+    `literal_*`: call for call what include/imagestitch_cv.hpp issues for the reference's main() - per tile warp(img, LINEAR, REFLECT)
+    (W:229) and warp(all-255 mask, NEAREST, CONSTANT) (W:232), EACH one isx_warper_roi (detectResultRoi, a host round trip, no ROI memo)
+    + one isx_warper_warp_roi; convertTo(CV_16S) (W:294); prepare (W:281); feed(CV_16SC3, mask, corner) (W:302) with the inputs
+    consumed (isx_blender_set_deferred_level0 = 2: private copies of device mats; host mats are staged); blend -> CV_16SC3 + mask
+    (W:313).  `fused_*`: the library's own re-expression of that sequence - warp_with_mask (one map evaluation and one ROI per tile)
+    and feed_u8 (the convertTo fused) - same results.  `device`: mats resident in HBM.  `host`: every mat a host array as a cv::Mat is
+    (pageable numpy memory; `host_pinned`: page-locked), i.e. PCIe-inclusive."""
     import numpy as np
     import torch
     import imagestitch_amd as I
-    from imagestitch_amd import synth
+    from imagestitch_amd import _lib as L
     from imagestitch_amd.pipeline import PairStitcher
     W, H, F = args.width, args.height, args.focal
     mpix = len(host_imgs) * W * H / 1e6
     steps = max(args.steps, 5)
-    out = {"sequence": "per tile warp(image)+warp(mask) with the corner returned to the host (no ROI memo); prepare; feed x n "
-                       "(inputs consumed: private copies); blend -> CV_16SC3 + mask", "steps": steps}
-    for pname in ("f32", "i16"):
-        prec = prec_map[pname]
-        ps = PairStitcher([torch.from_numpy(h).to(dev) for h in host_imgs], K, Rs, F, args.kind, args.bands, prec, dev.index, None, "int16", deferred="copy")
+    out = {"literal": "per tile isx_warper_roi + isx_warper_warp_roi(img, LINEAR, REFLECT), isx_warper_roi + isx_warper_warp_roi(all-255 mask, NEAREST, "
+                      "CONSTANT); isx_convert_to(CV_16S); prepare; isx_blender_feed(CV_16SC3) x n, inputs consumed; blend -> CV_16SC3 + mask "
+                      "(the calls of include/imagestitch_cv.hpp, W:229,232,294,281,302,313)",
+           "fused": "per tile isx_warper_warp_with_mask (one ROI, one map evaluation, corner returned to the host); prepare; isx_blender_feed_u8 x n, "
+                    "inputs consumed; blend -> CV_16SC3 + mask", "steps": steps}
+
+    def timed(fn, n):
         for _ in range(2):
-            ps.step_sync()
+            fn()
         torch.cuda.synchronize()
         gc.collect(); gc.disable()      # as in the headline region: a generation-2 collection costs more than the whole loop
         t0 = time.perf_counter()
-        for _ in range(steps):
-            ps.step_sync()
+        for _ in range(n):
+            fn()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        dt = (time.perf_counter() - t0) / n
         gc.enable()
-        out["device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1)}
+        return dt
+
+    for pname in ("f32", "i16"):
+        prec = prec_map[pname]
+        ps = PairStitcher([torch.from_numpy(h).to(dev) for h in host_imgs], K, Rs, F, args.kind, args.bands, prec, dev.index, None, "int16", deferred="copy")
+        dt = timed(ps.step_sync, steps)
+        out["fused_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1)}
+        ref_out, ref_mask = ps.out.clone(), ps.out_mask.clone()
+        dt = timed(ps.step_literal, steps)
+        same = bool(torch.equal(ps.out, ref_out) and torch.equal(ps.out_mask, ref_mask))
+        out["literal_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1), "equals_fused": same}
+        ps.warper.set_roi_cache(True)       # the adapter's fixed_rig option: detectResultRoi of an unchanged (K, R, size) is remembered
+        dt = timed(ps.step_literal, steps)
+        ps.warper.set_roi_cache(False)
+        out["literal_device_" + pname]["fixed_rig_ms_per_pair"] = round(dt * 1e3, 4)
+        out["literal_device_" + pname]["fixed_rig_Mpix_s"] = round(mpix / dt, 1)
+        del ref_out, ref_mask
         seam_host = [m.cpu().numpy() for m in ps.seam]
         corners, sizes, shape_out = ps.corners, ps.sizes, tuple(ps.out.shape)
         del ps
-        for mem in ("host", "host_pinned"):
+        for mem in (("host", "host_pinned") if pname == "f32" else ("host",)):
             def alloc(shape, dtype):
                 if mem == "host":
                     return np.empty(shape, dtype)
@@ -217,20 +237,41 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
                     blender.feed_u8(wimg[i], seam[i], cs[i])
                 blender.blend(res, res_mask)
             n_host = max(3, steps // 4)
-            host_step()
-            gc.collect(); gc.disable()
-            t0 = time.perf_counter()
-            for _ in range(n_host):
-                host_step()
-            dt = (time.perf_counter() - t0) / n_host
-            gc.enable()
+            dt = timed(host_step, n_host)
             h2d = sum(a.nbytes for a in src) + sum(a.nbytes for a in wimg) + sum(a.nbytes for a in seam)
             d2h = sum(a.nbytes for a in wimg) + sum(a.nbytes for a in wmsk) + res.nbytes + res_mask.nbytes
-            out["%s_%s" % (mem, pname)] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),
-                                           "d2h_MB": round(d2h / 1e6, 1), "pcie_GBs": round((h2d + d2h) / dt / 1e9, 1), "steps": n_host}
+            out["fused_%s_%s" % (mem, pname)] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),
+                                                 "d2h_MB": round(d2h / 1e6, 1), "pcie_GBs": round((h2d + d2h) / dt / 1e9, 1), "steps": n_host}
+            if mem == "host":
+                # the literal calls on host mats: the source masks (W:213-214) and the CV_16SC3 tiles (W:294, the caller's own convertTo on the
+                # host - numpy's here, OpenCV's in the reference) are host mats too
+                smask = [np.full(h.shape[:2], 255, np.uint8) for h in host_imgs]
+                w16 = [np.empty((h, w, 3), np.int16) for (w, h) in sizes]
+                res2, res_mask2 = np.empty(shape_out, np.int16), np.empty(shape_out[:2], np.uint8)
+
+                def host_literal():
+                    cs = []
+                    for i in range(len(src)):
+                        size = (src[i].shape[1], src[i].shape[0])
+                        roi = warper.warpRoi(size, K, Rs[i])
+                        warper.warp_roi(src[i], K, Rs[i], L.INTER_LINEAR, L.BORDER_REFLECT, roi, wimg[i])
+                        roi = warper.warpRoi(size, K, Rs[i])
+                        warper.warp_roi(smask[i], K, Rs[i], L.INTER_NEAREST, L.BORDER_CONSTANT, roi, wmsk[i])
+                        cs.append((roi[0], roi[1]))
+                        np.copyto(w16[i], wimg[i])                         # images_warped.convertTo(images_warped_s, CV_16S)  W:294
+                    blender.prepare(cs, sizes)
+                    for i in range(len(src)):
+                        blender.feed(w16[i], seam[i], cs[i])
+                    blender.blend(res2, res_mask2)
+                dt = timed(host_literal, n_host)
+                h2d = sum(a.nbytes for a in src) + sum(a.nbytes for a in smask) + sum(a.nbytes for a in w16) + sum(a.nbytes for a in seam)
+                out["literal_host_" + pname] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),
+                                                "d2h_MB": round(d2h / 1e6, 1), "pcie_GBs": round((h2d + d2h) / dt / 1e9, 1), "steps": n_host,
+                                                "equals_fused": bool(np.array_equal(res, res2) and np.array_equal(res_mask, res_mask2)),
+                                                "note": "includes the caller's convertTo(CV_16S) on the host (numpy here)"}
             del warper, blender
     # the link alone, one direction at a time (pageable host memory, as a cv::Mat is): what the host legs above are made of
-    nb = int(max(v["h2d_MB"] for k, v in out.items() if k.startswith("host_")) * 1e6 / 2)
+    nb = int(out["fused_host_f32"]["h2d_MB"] * 1e6 / 2)
     hbuf, dbuf = np.empty(nb, np.uint8), torch.empty(nb, dtype=torch.uint8, device=dev)
     ht = torch.from_numpy(hbuf)
     rates = {}
@@ -241,11 +282,14 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
             fn()
         torch.cuda.synchronize()
         rates[name] = round(5 * nb / (time.perf_counter() - t0) / 1e9, 1)
-    hl = out.get("host_f32")
+    for leg in ("fused_host_f32", "literal_host_f32"):
+        hl = out.get(leg)
+        if hl:
+            rates["serial_bound_ms_" + leg.split("_")[0]] = round(hl["h2d_MB"] / rates["h2d_GBs"] + hl["d2h_MB"] / rates["d2h_GBs"], 3)
+    hl = out.get("fused_host_f32")
     if hl:
-        rates["serial_bound_ms"] = round(hl["h2d_MB"] / rates["h2d_GBs"] + hl["d2h_MB"] / rates["d2h_GBs"], 3)
         rates["overlap"] = ("none: every cv::Mat call returns with its outputs delivered and its inputs consumed, so copies of different calls cannot "
-                            "overlap; measured / serial bound = %.2f" % (hl["ms_per_pair"] / max(rates["serial_bound_ms"], 1e-9)))
+                            "overlap; measured / serial bound = %.2f (fused)" % (hl["ms_per_pair"] / max(rates["serial_bound_ms_fused"], 1e-9)))
     out["link"] = rates
     torch.cuda.empty_cache()
     return out

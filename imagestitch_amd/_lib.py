@@ -14,7 +14,6 @@ ISX_8UC1, ISX_8UC3, ISX_16SC3, ISX_32FC1, ISX_32FC3 = 0, 16, 19, 5, 21
 ISX_32SC1 = 4
 INTER_NEAREST, INTER_LINEAR = 0, 1
 INTER_TIES_EVEN = 0x100   # OR to INTER_LINEAR: OpenCV's OpenCL (UMat) remap rounding, half to even
-INTER_TIES_EVEN = 0x100   # OR to INTER_LINEAR: OpenCV's OpenCL remap rounding (half to even)
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
 WARP_CYLINDRICAL, WARP_SPHERICAL = 0, 1
 BLEND_NO, BLEND_FEATHER, BLEND_MULTI_BAND = 0, 1, 2
@@ -79,6 +78,7 @@ _SIGS = {
     "isx_blender_set_sharpness": [C.c_void_p, C.c_float],
     "isx_mask_dilate_and": [_MP, _MP, C.c_int, C.c_int, _MP, C.c_int, C.c_void_p],
     "isx_gain_apply": [_MP, C.c_double, C.c_int, C.c_void_p],
+    "isx_convert_to": [_MP, _MP, C.c_int, C.c_void_p],
     "isx_seam_estimate": [_MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _MP, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                           C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p],
     "isx_dp_seam_find": [C.c_int, _MP, C.POINTER(C.c_int), _MP, C.c_int, C.c_void_p],

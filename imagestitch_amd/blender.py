@@ -205,6 +205,36 @@ def gain_apply(image, gain, device=0, stream=None):
     return image
 
 
+class NoBlender(MultiBandBlender):
+    """cv::detail::Blender itself, what Blender::createDefault(Blender::NO, false) returns (W:276): feed() copies the tile's pixels
+    under its mask into the CV_16SC3 accumulator, blend() zeroes what no mask covered."""
+
+    def __init__(self, try_gpu=False, device=0, stream=None):
+        del try_gpu
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.isx_blender_create(_lib.BLEND_NO, 0, PREC_I16, int(device), C.byref(self._h)))
+        self.precision = PREC_I16
+        self._like = None
+        self._stream_obj = None
+        self._deferred_refs = False
+        self._fed = []
+        if stream is not None:
+            self.set_stream(stream)
+
+
+def convert_to(src, dtype, dst=None, device=0, stream=None):
+    """src.convertTo(dst, depth) with alpha = 1, beta = 0 between uint8 / int16 / float32 (W:261, W:294, W:315's input): isx_convert_to.
+    dtype: numpy dtype (or its name).  Returns dst (same kind as src: numpy array or torch tensor)."""
+    dt = np.dtype(dtype)
+    if dst is None:
+        dst = _empty_like_kind(src, tuple(src.shape), dt)
+    ms, md = as_mat(src), as_mat(dst)
+    ptr = getattr(stream, "cuda_stream", stream)
+    check(_lib.load().isx_convert_to(C.byref(ms), C.byref(md), int(device), C.c_void_p(ptr or 0)))
+    return dst
+
+
 class Blender:
     """cv::detail::Blender factory (W:271,276,278)."""
     NO, FEATHER, MULTI_BAND = 0, 1, 2
@@ -213,6 +243,8 @@ class Blender:
     def createDefault(blend_type, try_gpu=False, **kw):
         if blend_type == Blender.FEATHER:
             return FeatherBlender(try_gpu, **kw)
+        if blend_type == Blender.NO:
+            return NoBlender(try_gpu, **kw)
         if blend_type != Blender.MULTI_BAND:
-            raise IsxError(6, "Blender::createDefault: MULTI_BAND and FEATHER are implemented on this path (got %d)" % blend_type)
+            raise IsxError(1, "Blender::createDefault: NO (0), FEATHER (1) or MULTI_BAND (2), got %d" % blend_type)
         return MultiBandBlender(try_gpu, **kw)

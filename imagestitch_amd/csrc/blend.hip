@@ -1218,12 +1218,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 #include "collapse_roll.inc"
 #include "pyrdown_l0.inc"
 
-// level 0 -> 1 of every recorded tile: CV_8UC3 tiles through k_pyr_down0_u8 (ISX_PD0=0: the general kernel, for A/B runs)
+// level 0 -> 1 of every recorded tile: CV_8UC3 and CV_16SC3 tiles through k_pyr_down0 (ISX_PD0=0: the general kernel, for A/B runs)
 template <int M, int SK>
 int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st) {
     static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
-    if constexpr (SK == SK_U8) {
-        if (fast) { ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down0_u8<M>), grid, dim3(512), 0, ts); return ISX_OK; }
+    if constexpr (SK == SK_U8 || SK == SK_S16) {
+        if (fast) { ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down0<M, SK>), grid, dim3(512), 0, ts); return ISX_OK; }
     }
     ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
     return ISX_OK;
@@ -1451,6 +1451,47 @@ __global__ __launch_bounds__(256) void k_feather_gather(FeatherSet fs, OutMat ou
     }
     normalise<M_I16>(d);
     write_final<M_I16>(out, x, y, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blender::NO (W:276 `Blender::createDefault(Blender::NO, false)`; OpenCV 3.4.2 blenders.cpp, the base class):
+//   prepare: dst_ (CV_16SC3) and dst_mask_ (CV_8U) of dst_roi's size, both zeroed
+//   feed   : where mask != 0: dst_(dy + y, dx + x) = img(y, x); everywhere: dst_mask_(dy + y, dx + x) |= mask(y, x)
+//   blend  : dst_.setTo(0, dst_mask_ == 0); dst = dst_; dst_mask = dst_mask_
+// dst_ is dense short3, dst_mask_ dense bytes, pitch = the ROI's width.
+// ------------------------------------------------------------------------------------------------
+template <int SK>
+__global__ __launch_bounds__(256) void k_no_feed(const unsigned char* img, size_t istep, const unsigned char* mask, size_t mstep, int rows, int cols,
+                                                 short* dst, unsigned char* dmask, int dpitch, int dx, int dy) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const unsigned m = mask[(size_t)y * mstep + x];
+    const size_t o = (size_t)(dy + y) * dpitch + (dx + x);
+    if (m) {
+        int c0, c1, c2;
+        if constexpr (SK == SK_U8) { const unsigned char* q = img + (size_t)y * istep + (size_t)x * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+        else { const short* q = (const short*)(img + (size_t)y * istep) + (size_t)x * 3; c0 = q[0]; c1 = q[1]; c2 = q[2]; }
+        short* d = dst + o * 3;
+        d[0] = (short)c0; d[1] = (short)c1; d[2] = (short)c2;
+        dmask[o] |= (unsigned char)m;
+    }
+}
+__global__ __launch_bounds__(256) void k_no_blend(const short* dst, const unsigned char* dmask, int dpitch, OutMat out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= out.cols || y >= out.rows) return;
+    const size_t o = (size_t)y * dpitch + x;
+    const unsigned m = dmask[o];
+    const short* d = dst + o * 3;
+    int c0 = d[0], c1 = d[1], c2 = d[2];
+    if (m == 0) { c0 = 0; c1 = 0; c2 = 0; }      // dst_.setTo(Scalar::all(0), dst_mask_ == 0)
+    if (out.mask) out.mask[(size_t)y * out.mask_step + x] = (unsigned char)m;
+    if (out.img_f32 == 2) {                       // + result.convertTo(CV_8U)
+        unsigned char* q = out.img + (size_t)y * out.img_step + (size_t)x * 3;
+        q[0] = (unsigned char)sat_u8(c0); q[1] = (unsigned char)sat_u8(c1); q[2] = (unsigned char)sat_u8(c2);
+    } else {
+        short* q = (short*)(out.img + (size_t)y * out.img_step) + (size_t)x * 3;
+        q[0] = (short)c0; q[1] = (short)c1; q[2] = (short)c2;
+    }
 }
 
 // zero every pixel of a level that no fed tile covers (only needed when more than MAX_COVER tiles are
@@ -1774,10 +1815,10 @@ int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, cons
     static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
     static const int rsel = [] { const char* e = getenv("ISX_ROLL_R"); return e ? atoi(e) : 2; }();      // rows per wave (tuning runs only)
     *done = false;
-    if constexpr (SK == SK_U8) {
+    if constexpr (SK == SK_U8 || SK == SK_S16) {
         if (!mode || coarse.cols < 2 || (unsigned long long)coarse.rows * coarse.cols * 16ull >= (1ull << 32)) return ISX_OK;
         for (int t = 0; t < ts.n; ++t)
-            if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].rows < 2 || ts.s0[t].iend == 0u ||      // iend != 0: CV_8UC3 below 2 GiB, 32-bit offsets
+            if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].rows < 2 || ts.s0[t].iend == 0u ||      // iend != 0: a CV_8UC3 / CV_16SC3 tile below 2 GiB, 32-bit offsets
                 (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return ISX_OK;
         // two rows per wave while at most two tiles reach a strip (a pair, a row of tiles with narrow overlaps); one row and a third slot
         // for panoramas whose tiles overlap their second neighbours (BASELINE config 5); k_collapse_gather beyond that
@@ -2050,7 +2091,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
         }
         if (k == 1 && k != L) {      // the last step: the rolling kernel when every mosaic qualifies (launch_collapse_roll's conditions)
             static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
-            bool ok = mode != 0 && SK == SK_U8;
+            bool ok = mode != 0 && (SK == SK_U8 || SK == SK_S16);
             unsigned nblk = 0;
             for (int m = 0; m < nb && ok; ++m) {
                 const LevelBuf& c = d[m][1];
@@ -2072,7 +2113,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
                     nblk = std::max(nblk, xcd_band_blocks(grp, nsx, nby));
                 }
             }
-            if constexpr (SK == SK_U8) {
+            if constexpr (SK == SK_U8 || SK == SK_S16) {
                 if (ok) {
                     ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll_batch<M, SK, 2, 2>), dim3(nblk, 1, nb), dim3(64 * ROLL_WAVES), 0, ts, bo, 0);
                     continue;
@@ -2113,6 +2154,16 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     ISX_CHECK_ARG(width > 0 && height > 0, ISX_ERR_INVALID, "prepare: empty destination ROI %d x %d", width, height);
     ISX_HIP(hipSetDevice(b->device));
     b->fw = width; b->fh = height;
+    if (b->type == ISX_BLEND_NO) {      // Blender::prepare(Rect): dst_.create(size, CV_16SC3), dst_mask_.create(size, CV_8U), both setTo(0)
+        ISX_CHECK_ARG((unsigned long long)width * height < (1ull << 31), ISX_ERR_UNSUPPORTED, "prepare: destination ROI %d x %d exceeds 2^31 pixels", width, height);
+        const size_t n = (size_t)width * height, img_bytes = (n * 6 + 255) & ~(size_t)255;
+        ISX_TRY(b->dst_arena.reserve(img_bytes + n));
+        ISX_HIP(hipMemsetAsync(b->dst_arena.p, 0, img_bytes + n, b->stream));
+        b->rx = x; b->ry = y; b->rw = width; b->rh = height; b->num_bands = 0;
+        b->fed.clear(); b->cleared = false; b->tiles.clear(); b->ftiles.clear(); b->level0_pending = false;
+        b->prepared = true;
+        return ISX_OK;
+    }
     // num_bands_ = min(actual_num_bands_, (int)ceil(log(max_len) / log(2.0)))
     double max_len = (double)(width > height ? width : height);
     int cl = (int)std::ceil(std::log(max_len) / std::log(2.0));
@@ -2257,9 +2308,39 @@ int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int
     return feather_accumulate(b, r);
 }
 
+// Blender::feed of the base class (Blender::NO): a masked copy into dst_, dst_mask_ |= mask
+int do_feed_no(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
+    ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released dst_)");
+    ISX_TRY(check_mat(img, "feed: img"));
+    ISX_TRY(check_mat(mask, "feed: mask"));
+    if (u8_entry) ISX_CHECK_ARG(img->type == ISX_8UC3, ISX_ERR_TYPE, "feed_u8: img must be CV_8UC3, got %s", type_name(img->type));
+    else ISX_CHECK_ARG(img->type == ISX_16SC3, ISX_ERR_TYPE, "Blender::feed: img must be CV_16SC3, got %s", type_name(img->type));
+    ISX_CHECK_ARG(mask->type == ISX_8UC1, ISX_ERR_TYPE, "feed: mask must be CV_8U, got %s", type_name(mask->type));
+    ISX_CHECK_ARG(mask->rows == img->rows && mask->cols == img->cols, ISX_ERR_SIZE, "feed: mask %dx%d does not match img %dx%d",
+                  mask->cols, mask->rows, img->cols, img->rows);
+    const int dx = tl_x - b->rx, dy = tl_y - b->ry;
+    ISX_CHECK_ARG(dx >= 0 && dy >= 0 && dx + img->cols <= b->rw && dy + img->rows <= b->rh, ISX_ERR_INVALID,
+                  "feed: tile at (%d,%d) %dx%d lies outside the prepared ROI", tl_x, tl_y, img->cols, img->rows);
+    ISX_HIP(hipSetDevice(b->device));
+    hipStream_t st = b->stream;
+    ISX_TRY(b->st_img.use_in(img, st, "feed: img"));
+    ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
+    const size_t n = (size_t)b->rw * b->rh, img_bytes = (n * 6 + 255) & ~(size_t)255;
+    short* dst = (short*)b->dst_arena.p;
+    unsigned char* dmask = (unsigned char*)b->dst_arena.p + img_bytes;
+    const dim3 grid(cdiv(img->cols, 64), cdiv(img->rows, 4));
+    const double bytes = (double)img->rows * img->cols * ((u8_entry ? 3.0 : 6.0) + 1.0 + 7.0);
+    if (u8_entry) ISX_LAUNCH("no_feed", bytes, st, (k_no_feed<SK_U8>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step,
+                             (const unsigned char*)b->st_mask.d.data, b->st_mask.d.step, img->rows, img->cols, dst, dmask, b->rw, dx, dy);
+    else ISX_LAUNCH("no_feed", bytes, st, (k_no_feed<SK_S16>), grid, dim3(256), 0, (const unsigned char*)b->st_img.d.data, b->st_img.d.step,
+                    (const unsigned char*)b->st_mask.d.data, b->st_mask.d.step, img->rows, img->cols, dst, dmask, b->rw, dx, dy);
+    return ISX_OK;      // (the shared staging buffers are reused by the next feed on the same stream: ordered)
+}
+
 int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "feed: null blender");
     if (b->type == ISX_BLEND_FEATHER) return do_feed_feather(b, img, mask, tl_x, tl_y, u8_entry);
+    if (b->type == ISX_BLEND_NO) return do_feed_no(b, img, mask, tl_x, tl_y, u8_entry);
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "feed: null blender");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released the pyramids)");
     ISX_TRY(check_mat(img, "feed: img"));
@@ -2330,9 +2411,9 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     s0.imis = (unsigned)((uintptr_t)s0.img & 3); s0.mmis = (unsigned)((uintptr_t)s0.mask & 3);
     s0.img_al = s0.img - s0.imis; s0.mask_al = s0.mask - s0.mmis;
     s0.iend = 0; s0.mend = 0;
-    if (img->type == ISX_8UC3 && (unsigned long long)di.step * img->rows < (1ull << 31) && (unsigned long long)dm.step * img->rows < (1ull << 31) &&
-        di.step < (1u << 24) && dm.step < (1u << 24)) {
-        s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * 3) + s0.imis;
+    if ((img->type == ISX_8UC3 || img->type == ISX_16SC3) && (unsigned long long)di.step * img->rows < (1ull << 31) &&
+        (unsigned long long)dm.step * img->rows < (1ull << 31) && di.step < (1u << 24) && dm.step < (1u << 24)) {
+        s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * (img->type == ISX_8UC3 ? 3 : 6)) + s0.imis;
         s0.mend = (unsigned)((size_t)(img->rows - 1) * dm.step + (size_t)img->cols) + s0.mmis;
     }
 
@@ -2398,9 +2479,9 @@ int isx_blender_create(int type, int num_bands, int precision, int device, isx_b
     clear_error();
     ISX_CHECK_ARG(out != nullptr, ISX_ERR_INVALID, "isx_blender_create: null out pointer");
     *out = nullptr;
-    ISX_CHECK_ARG(type == ISX_BLEND_MULTI_BAND || type == ISX_BLEND_FEATHER, ISX_ERR_UNSUPPORTED,
-                  "isx_blender_create: Blender::MULTI_BAND (2) and Blender::FEATHER (1) are implemented, got %d", type);
-    if (type == ISX_BLEND_FEATHER) { num_bands = 0; precision = ISX_PREC_I16; }   // CV_16SC3 accumulator + CV_32F weights, one level
+    ISX_CHECK_ARG(type == ISX_BLEND_MULTI_BAND || type == ISX_BLEND_FEATHER || type == ISX_BLEND_NO, ISX_ERR_INVALID,
+                  "isx_blender_create: Blender::NO (0), Blender::FEATHER (1) or Blender::MULTI_BAND (2), got %d", type);
+    if (type != ISX_BLEND_MULTI_BAND) { num_bands = 0; precision = ISX_PREC_I16; }   // CV_16SC3 accumulator (+ CV_32F weights: FEATHER), one level
     ISX_CHECK_ARG(num_bands >= 0 && num_bands < MAX_LEVELS - 1, ISX_ERR_INVALID, "isx_blender_create: num_bands %d out of range", num_bands);
     ISX_CHECK_ARG(precision >= ISX_PREC_I16 && precision <= ISX_PREC_F16ACC32, ISX_ERR_INVALID, "isx_blender_create: bad precision %d", precision);
     int n = 0;
@@ -2535,6 +2616,7 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
     ISX_CHECK_ARG(b != nullptr && rows != nullptr && cols != nullptr, ISX_ERR_INVALID, "debug_level: null argument");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "debug_level: prepare() has not been called");
     ISX_CHECK_ARG(level >= 0 && level <= b->num_bands, ISX_ERR_INVALID, "debug_level: level %d of %d", level, b->num_bands);
+    ISX_CHECK_ARG(b->type != ISX_BLEND_NO, ISX_ERR_UNSUPPORTED, "debug_level: Blender::NO keeps no pyramid");
     ISX_HIP(hipSetDevice(b->device));
     const LevelBuf& d = b->dst[level];
     *rows = d.rows; *cols = d.cols;
@@ -2638,7 +2720,11 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     ISX_TRY(blend_begin(b, dst, dst_mask, &o));
     const bool windowed = b->win_x1 > b->win_x0;
     int rc = ISX_OK;
-    if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend
+    if (b->type == ISX_BLEND_NO) {        // Blender::blend of the base class
+        const size_t n = (size_t)b->rw * b->rh, img_bytes = (n * 6 + 255) & ~(size_t)255;
+        ISX_LAUNCH("no_blend", (double)n * (7.0 + (o.img_f32 == 2 ? 4.0 : 7.0)), b->stream, k_no_blend, dim3(cdiv(b->rw, 64), cdiv(b->rh, 4)), dim3(256), 0,
+                   (const short*)b->dst_arena.p, (const unsigned char*)b->dst_arena.p + img_bytes, b->rw, o);
+    } else if (b->type == ISX_BLEND_FEATHER) {   // FeatherBlender::blend: normalizeUsingWeightMap, compare(w > WEIGHT_EPS), Blender::blend
         dim3 grid(cdiv(b->dst[0].cols, 64), cdiv(b->dst[0].rows, 4));
         if (!b->ftiles.empty()) {   // deferred cycle: gather over the recorded tiles
             if (windowed) {         // a pixel of the result depends on the tiles that cover it and on nothing else: the window's block columns

@@ -219,6 +219,17 @@ int isx_gather_p2p_alloc(isx_gather* g, size_t bytes, void** ptr, unsigned char 
     return ISX_OK;
 }
 
+// undo a partly completed isx_gather_p2p_open: close the peers' mappings opened so far, destroy the streams / events created so far and
+// leave the gather as it was before the call, so that the call can be repeated
+static void p2p_rollback(isx_gather* g) {
+    for (int r = 0; r < (int)g->peer.size(); ++r)
+        if (r != g->rank && g->peer[r]) (void)hipIpcCloseMemHandle(g->peer[r]);
+    g->peer.clear();
+    for (hipStream_t st : g->pstream) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : g->pdone) (void)hipEventDestroy(ev);
+    g->pstream.clear(); g->pdone.clear();
+}
+
 int isx_gather_p2p_open(isx_gather* g, const unsigned char* handles /* world x 64 bytes, by rank */) {
     clear_error();
     ISX_CHECK_ARG(g != nullptr && handles != nullptr, ISX_ERR_INVALID, "isx_gather_p2p_open: bad argument");
@@ -226,18 +237,26 @@ int isx_gather_p2p_open(isx_gather* g, const unsigned char* handles /* world x 6
     ISX_CHECK_ARG(g->peer.empty(), ISX_ERR_STATE, "isx_gather_p2p_open: already open");
     ISX_HIP(hipSetDevice(g->device));
     g->peer.assign((size_t)g->world, nullptr);
+    // a failure part of the way leaves nothing behind (no half-filled peer table that a later chunk would dereference, no "already open")
+#define P2P_OPEN_HIP(expr)                                                                                                       \
+    do {                                                                                                                         \
+        hipError_t e__ = (expr);                                                                                                 \
+        if (e__ != hipSuccess) { p2p_rollback(g); return fail(ISX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); } \
+    } while (0)
     for (int r = 0; r < g->world; ++r) {
         if (r == g->rank) { g->peer[r] = g->p2p_local; continue; }
         hipIpcMemHandle_t h;
         std::memcpy(&h, handles + (size_t)r * 64, 64);
-        ISX_HIP(hipIpcOpenMemHandle(&g->peer[r], h, hipIpcMemLazyEnablePeerAccess));
+        P2P_OPEN_HIP(hipIpcOpenMemHandle(&g->peer[r], h, hipIpcMemLazyEnablePeerAccess));
     }
     for (int r = 0; r < g->world; ++r) {
-        hipStream_t st; hipEvent_t ev;
-        ISX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        ISX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        g->pstream.push_back(st); g->pdone.push_back(ev);
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        P2P_OPEN_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        g->pstream.push_back(st);
+        P2P_OPEN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->pdone.push_back(ev);
     }
+#undef P2P_OPEN_HIP
     return ISX_OK;
 }
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 using namespace isx;
@@ -32,6 +33,7 @@ struct Jpeg {
     std::vector<unsigned char> data;
     size_t pos = 0;
     int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1;
+    int mcux = 0, mcuy = 0;               // MCUs per row / column of the frame (set with the frame header)
     Comp comp[4];
     unsigned short qt[4][64];
     bool have_qt[4] = {false, false, false, false};
@@ -217,6 +219,7 @@ int parse(Jpeg& j, const char* path, bool header_only) {
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {     // SOFn
             ISX_CHECK_ARG(m == 0xC0 || m == 0xC1, ISX_ERR_UNSUPPORTED, "imread: %s: only baseline / extended sequential Huffman JPEG is decoded (SOF%u)", path, m - 0xC0);
+            ISX_CHECK_ARG(!j.got_sof, ISX_ERR_INVALID, "imread: %s: a second frame header (libjpeg: JERR_SOF_DUPLICATE)", path);
             ISX_CHECK_ARG(len >= 8 && j.data[s] == 8, ISX_ERR_UNSUPPORTED, "imread: %s: %u-bit samples", path, (unsigned)j.data[s]);
             j.height = (int)rd16(j, s + 1); j.width = (int)rd16(j, s + 3); j.ncomp = j.data[s + 5];
             ISX_CHECK_ARG(j.width > 0 && j.height > 0 && (j.ncomp == 1 || j.ncomp == 3) && s + 6 + 3 * (size_t)j.ncomp <= e, ISX_ERR_UNSUPPORTED,
@@ -228,13 +231,32 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                 j.hmax = std::max(j.hmax, k.h); j.vmax = std::max(j.vmax, k.v);
             }
             j.got_sof = true;
-            if (header_only) return ISX_OK;
-        } else if (m == 0xDD) { j.restart = (int)rd16(j, s);
+            // geometry, once and for all scans: blocks per component, padded to whole MCUs.  A frame whose MCUs could not possibly fit the
+            // file (every coded block takes at least two bits: an end-of-block after a zero DC difference) is refused before anything is
+            // allocated, and so is one beyond the size the BMP reader accepts: the header of a few-hundred-byte file must not drive
+            // gigabytes of allocations.
+            j.mcux = (j.width + 8 * j.hmax - 1) / (8 * j.hmax); j.mcuy = (j.height + 8 * j.vmax - 1) / (8 * j.vmax);
+            {
+                unsigned long long blocks = 0;
+                for (int c = 0; c < j.ncomp; ++c) blocks += (unsigned long long)j.mcux * j.comp[c].h * (unsigned long long)j.mcuy * j.comp[c].v;
+                ISX_CHECK_ARG((unsigned long long)j.width * j.height <= (1ull << 30) && blocks / 4 <= (unsigned long long)n, ISX_ERR_INVALID,
+                              "imread: %s: a %d x %d frame cannot be held by a %zu-byte file", path, j.width, j.height, n);
+            }
+            if (header_only) return ISX_OK;      // (isx_jpeg_size: the caller allocates rows x cols from what this returns - after the check above)
+            for (int c = 0; c < j.ncomp; ++c) {
+                Comp& k = j.comp[c];
+                k.wblk = j.mcux * k.h; k.hblk = j.mcuy * k.v;
+                k.coef.assign((size_t)k.wblk * k.hblk * 64, 0);
+            }
+        } else if (m == 0xDD) {
+            ISX_CHECK_ARG(len >= 4, ISX_ERR_INVALID, "imread: %s: truncated DRI segment", path);
+            j.restart = (int)rd16(j, s);
         } else if (m == 0xEE && len >= 14 && memcmp(&j.data[s], "Adobe", 5) == 0) { j.adobe = true; j.adobe_transform = j.data[s + 11];
         } else if (m == 0xDA) {                           // SOS: decode this scan
             ISX_CHECK_ARG(j.got_sof, ISX_ERR_INVALID, "imread: %s: scan before frame header", path);
+            ISX_CHECK_ARG(len >= 3, ISX_ERR_INVALID, "imread: %s: truncated scan header", path);
             const int ns = j.data[s];
-            ISX_CHECK_ARG(ns >= 1 && ns <= j.ncomp && s + 1 + 2 * (size_t)ns + 3 <= e, ISX_ERR_INVALID, "imread: %s: bad scan header", path);
+            ISX_CHECK_ARG(ns >= 1 && ns <= j.ncomp && len >= 6 + 2 * (size_t)ns, ISX_ERR_INVALID, "imread: %s: bad scan header", path);
             Comp* sc[4];
             for (int i = 0; i < ns; ++i) {
                 const int id = j.data[s + 1 + 2 * i];
@@ -245,12 +267,7 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                 ISX_CHECK_ARG(k->td < 4 && k->ta < 4 && j.dc[k->td].present && j.ac[k->ta].present, ISX_ERR_INVALID, "imread: %s: scan uses an undefined Huffman table", path);
                 sc[i] = k;
             }
-            // geometry (once): blocks per component, padded to whole MCUs
-            const int mcux = (j.width + 8 * j.hmax - 1) / (8 * j.hmax), mcuy = (j.height + 8 * j.vmax - 1) / (8 * j.vmax);
-            for (int c = 0; c < j.ncomp; ++c) {
-                Comp& k = j.comp[c];
-                if (k.coef.empty()) { k.wblk = mcux * k.h; k.hblk = mcuy * k.v; k.coef.assign((size_t)k.wblk * k.hblk * 64, 0); }
-            }
+            const int mcux = j.mcux, mcuy = j.mcuy;      // (blocks per component and the coefficient buffers were sized with the frame header)
             j.pos = e; j.bits = 0; j.nbits = 0; j.hit_marker = false;
             for (int c = 0; c < j.ncomp; ++c) j.comp[c].dc_pred = 0;
             int todo = j.restart;
@@ -265,6 +282,7 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                             while (j.pos + 1 < n && !(j.data[j.pos] == 0xFF && j.data[j.pos + 1] >= 0xD0 && j.data[j.pos + 1] <= 0xD7)) ++j.pos;
                             j.pos += 2; j.hit_marker = false; k.dc_pred = 0; todo = j.restart;
                         }
+                        ISX_CHECK_ARG(bx < k.wblk && by < k.hblk, ISX_ERR_INVALID, "imread: %s: scan passes the frame", path);
                         ISX_CHECK_ARG(decode_block(j, k, &k.coef[((size_t)by * k.wblk + bx) * 64]) == 0, ISX_ERR_INVALID, "imread: %s: corrupt entropy-coded data", path);
                         --todo;
                     }
@@ -282,7 +300,7 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                             Comp& k = *sc[i];
                             for (int v = 0; v < k.v; ++v)
                                 for (int h = 0; h < k.h; ++h)
-                                    ISX_CHECK_ARG(decode_block(j, k, &k.coef[((size_t)(my * k.v + v) * k.wblk + mx * k.h + h) * 64]) == 0, ISX_ERR_INVALID,
+                                    ISX_CHECK_ARG(my * k.v + v < k.hblk && mx * k.h + h < k.wblk && decode_block(j, k, &k.coef[((size_t)(my * k.v + v) * k.wblk + mx * k.h + h) * 64]) == 0, ISX_ERR_INVALID,
                                                   "imread: %s: corrupt entropy-coded data", path);
                         }
                         --todo;
@@ -366,18 +384,33 @@ int load_file(const char* path, std::vector<unsigned char>& buf) {
 
 extern "C" {
 
-int isx_jpeg_size(const char* path, int* rows, int* cols) {
-    clear_error();
-    ISX_CHECK_ARG(path && rows && cols, ISX_ERR_INVALID, "isx_jpeg_size: null argument");
+// no C++ exception crosses the C boundary: an allocation that fails (a damaged header can still ask for a lot) is ISX_ERR_NOMEM
+static int jpeg_size_impl(const char* path, int* rows, int* cols) {
     Jpeg j;
     ISX_TRY(load_file(path, j.data));
     ISX_TRY(parse(j, path, true));
     *rows = j.height; *cols = j.width;
     return ISX_OK;
 }
+static int jpeg_read_impl(const char* path, isx_mat* out);
+
+int isx_jpeg_size(const char* path, int* rows, int* cols) {
+    clear_error();
+    ISX_CHECK_ARG(path && rows && cols, ISX_ERR_INVALID, "isx_jpeg_size: null argument");
+    try { return jpeg_size_impl(path, rows, cols); }
+    catch (const std::bad_alloc&) { return fail(ISX_ERR_NOMEM, "imread: %s: out of host memory", path); }
+    catch (...) { return fail(ISX_ERR_INVALID, "imread: %s: unexpected failure while decoding", path); }
+}
 
 int isx_jpeg_read(const char* path, isx_mat* out) {
     clear_error();
+    ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imread: null path");
+    try { return jpeg_read_impl(path, out); }
+    catch (const std::bad_alloc&) { return fail(ISX_ERR_NOMEM, "imread: %s: out of host memory", path); }
+    catch (...) { return fail(ISX_ERR_INVALID, "imread: %s: unexpected failure while decoding", path); }
+}
+
+static int jpeg_read_impl(const char* path, isx_mat* out) {
     ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imread: null path");
     ISX_TRY(check_mat(out, "imread: out"));
     ISX_CHECK_ARG(out->type == ISX_8UC3, ISX_ERR_TYPE, "imread: out must be CV_8UC3 (IMREAD_COLOR), got %s", type_name(out->type));

@@ -195,6 +195,41 @@ __global__ __launch_bounds__(256) void k_gain_apply(const unsigned char* src, si
     }
 }
 
+
+// A14  the glue conversions of the reference's main(): images_warped[i].convertTo(images_warped_f[i], CV_32F) (W:261),
+// images_warped_f[k].convertTo(images_warped_s[k], CV_16S) (W:294), result.convertTo(CV_8U) (imwrite's input, W:315) - Mat::convertTo with
+// alpha = 1, beta = 0: widening is exact, narrowing is saturate_cast (float -> short / uchar: cvRound = round-half-even with cvtss2si's
+// NaN / overflow -> INT_MIN, then the clamp).  One element per thread over the rows' channel values, dword stores where the rows allow.
+template <class S, class D>
+__device__ __forceinline__ D convert_one(S v) {
+    if constexpr (sizeof(D) >= sizeof(S) && !(sizeof(S) == 4 && sizeof(D) == 4)) return (D)v;               // u8 -> s16 / f32, s16 -> f32: exact
+    else if constexpr (sizeof(S) == 4 && sizeof(D) == 2) return (D)isxd::sat_s16(isxd::cvround_x86(v));       // f32 -> s16
+    else if constexpr (sizeof(S) == 4 && sizeof(D) == 1) return (D)isxd::sat_u8(isxd::cvround_x86(v));        // f32 -> u8
+    else return (D)isxd::sat_u8((int)v);                                                                        // s16 -> u8
+}
+template <class S, class D, bool VEC>
+__global__ __launch_bounds__(256) void k_convert(const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep, int rows, int n) {
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= rows) return;
+    const S* s = (const S*)(src + (size_t)y * sstep);
+    D* d = (D*)(dst + (size_t)y * dstep);
+    if constexpr (VEC) {        // four values per thread: source and destination rows 4-value aligned
+        const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+        if (x >= n) return;
+        if (x + 4 <= n) {
+            typedef S sv4 __attribute__((ext_vector_type(4)));
+            typedef D dv4 __attribute__((ext_vector_type(4)));
+            const sv4 v = *(const sv4*)(s + x);
+            dv4 o;
+            o.x = convert_one<S, D>(v.x); o.y = convert_one<S, D>(v.y); o.z = convert_one<S, D>(v.z); o.w = convert_one<S, D>(v.w);
+            *(dv4*)(d + x) = o;
+        } else for (int k = x; k < n; ++k) d[k] = convert_one<S, D>(s[k]);
+    } else {
+        const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+        if (x < n) d[x] = convert_one<S, D>(s[x]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -256,6 +291,43 @@ int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream) {
                     (const unsigned char*)si.d.data, si.d.step, (unsigned char*)so.d.data, so.d.step, rows, row_bytes, gain);
     ISX_TRY(so.finish_out(st));
     if (image->device < 0) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
+    return ISX_OK;
+}
+
+int isx_convert_to(const isx_mat* src, isx_mat* dst, int device, void* hip_stream) {
+    clear_error();
+    ISX_TRY(check_mat(src, "convertTo: src"));
+    ISX_TRY(check_mat(dst, "convertTo: dst"));
+    ISX_CHECK_ARG(dst->rows == src->rows && dst->cols == src->cols && mat_cn(dst->type) == mat_cn(src->type), ISX_ERR_SIZE,
+                  "convertTo: dst %dx%dx%d does not match src %dx%dx%d", dst->cols, dst->rows, mat_cn(dst->type), src->cols, src->rows, mat_cn(src->type));
+    const int sd = mat_depth(src->type), dd = mat_depth(dst->type);      // CV_8U 0, CV_16S 3, CV_32F 5
+    ISX_CHECK_ARG((sd == 0 || sd == 3 || sd == 5) && (dd == 0 || dd == 3 || dd == 5) && sd != dd, ISX_ERR_TYPE,
+                  "convertTo: %s -> %s (CV_8U, CV_16S and CV_32F depths, different ones)", type_name(src->type), type_name(dst->type));
+    ISX_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    MatStage si, so;
+    ISX_TRY(si.use_in(src, st, "convertTo: src"));
+    ISX_TRY(so.use_out(dst, st, "convertTo: dst"));
+    const int rows = src->rows, n = src->cols * mat_cn(src->type);
+    const size_t ss = sd == 0 ? 1 : (sd == 3 ? 2 : 4), ds = dd == 0 ? 1 : (dd == 3 ? 2 : 4);
+    const bool vec = ((uintptr_t)si.d.data % (4 * ss) == 0) && (si.d.step % (4 * ss) == 0) && ((uintptr_t)so.d.data % (4 * ds) == 0) && (so.d.step % (4 * ds) == 0);
+    const double bytes = (double)rows * n * (double)(ss + ds);
+    const unsigned char* sp = (const unsigned char*)si.d.data;
+    unsigned char* dp = (unsigned char*)so.d.data;
+#define ISX_CVT(S, D)                                                                                                                       \
+    do {                                                                                                                                    \
+        if (vec) ISX_LAUNCH("convert_to", bytes, st, (k_convert<S, D, true>), dim3(cdiv(cdiv(n, 4), 64), cdiv(rows, 4)), dim3(256), 0, sp, si.d.step, dp, so.d.step, rows, n); \
+        else ISX_LAUNCH("convert_to", bytes, st, (k_convert<S, D, false>), dim3(cdiv(n, 64), cdiv(rows, 4)), dim3(256), 0, sp, si.d.step, dp, so.d.step, rows, n);             \
+    } while (0)
+    if (sd == 0 && dd == 3) ISX_CVT(unsigned char, short);
+    else if (sd == 0 && dd == 5) ISX_CVT(unsigned char, float);
+    else if (sd == 3 && dd == 5) ISX_CVT(short, float);
+    else if (sd == 5 && dd == 3) ISX_CVT(float, short);
+    else if (sd == 5 && dd == 0) ISX_CVT(float, unsigned char);
+    else ISX_CVT(short, unsigned char);
+#undef ISX_CVT
+    ISX_TRY(so.finish_out(st));
+    if (src->device < 0 || dst->device < 0) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
     return ISX_OK;
 }
 

@@ -406,7 +406,7 @@ __device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t,
         if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
         // masks[i].setTo(255) (W:213-214) warped NEAREST / CONSTANT: 255 iff cvRound(x) in [0, cols) and cvRound(y) in [0, rows)
         const int nx = clamp_short(cvround_x86(mx)), ny = clamp_short(cvround_x86(my));
-        d->mask[(size_t)dy * d->mask_step + dx] = ((unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows) ? 255 : 0;
+        if (d->mask) d->mask[(size_t)dy * d->mask_step + dx] = ((unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows) ? 255 : 0;
 #pragma unroll 1
         for (int c = 0; c < 3; ++c) {
             const int v = sat_u8((r0[c0 + c] * w0 + r0[c1 + c] * w1 + r1[c0 + c] * w2 + r1[c1 + c] * w3 + (1 << 14)) >> 15);
@@ -463,7 +463,9 @@ __device__ __forceinline__ int reflect_once(int p, int n2m1) {
 #ifndef WARP_WPE
 #define WARP_WPE 7
 #endif
-template <int KIND, bool OUT16, bool VEC>
+// MASK = false: the image alone - RotationWarper::warp(img, K, R, INTER_LINEAR, BORDER_REFLECT) as the reference calls it (W:229), the
+// mask being a call of its own (W:232, k_warp_mask_tile); d.mask is then null
+template <int KIND, bool OUT16, bool VEC, bool MASK = true>
 __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu(WARP_WPE))) void k_warp_tile(WarpTileArgs a) {
     const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
     // A wave is 64 pixels wide and 4 rows tall (16 lanes x 4 pixels per row), a block 64 x 16: the band of border pixels along the
@@ -638,8 +640,10 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
             if (WARP_ABL & 8) { __builtin_nontemporal_store(q0, q); __builtin_nontemporal_store(q1, q + 1); __builtin_nontemporal_store(q2, q + 2); }
             else { q[0] = q0; q[1] = q1; q[2] = q2; }
         }
-        if (WARP_ABL & 8) __builtin_nontemporal_store(m4, (unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)));
-        else *(unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
+        if constexpr (MASK) {
+            if (WARP_ABL & 8) __builtin_nontemporal_store(m4, (unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)));
+            else *(unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
+        }
     } else {    // the partial group at the right edge, or destination rows that are not dword aligned: per-pixel stores
 #pragma unroll 1
         for (int k = 0; k < 4 && dx0 + k < d.w; ++k) {
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
                 unsigned char* q = d.img + (size_t)dy * d.img_step + (size_t)(dx0 + k) * 3;
                 q[0] = (unsigned char)v; q[1] = (unsigned char)(v >> 8); q[2] = (unsigned char)(v >> 16);
             }
-            d.mask[(size_t)dy * d.mask_step + dx0 + k] = (unsigned char)(m4 >> (8 * k));
+            if constexpr (MASK) d.mask[(size_t)dy * d.mask_step + dx0 + k] = (unsigned char)(m4 >> (8 * k));
         }
     }
     // ---- the rare rest (z out of the guarded range incl. the z <= 0 sentinel, more than one reflection, sources too small for a
@@ -660,6 +664,91 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
         const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
         warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_warp_mask_tile: RotationWarper::warp(mask, K, R, INTER_NEAREST, BORDER_CONSTANT) of a CV_8U mask (W:232) as a call of its own - what
+// the reference's main() and the cv adapter (include/imagestitch_cv.hpp) issue after the image's warp.  The source mask is read, whatever
+// it holds: dst = mask(cvRound(y), cvRound(x)) inside, 0 outside (cv::remap NEAREST / BORDER_CONSTANT, coordinates saturated to short).
+// One thread = 4 consecutive destination columns: the transform of k_warp_tile (hoisted separable products, shared-reciprocal division, the
+// bits of W:56-60) without the factor 32, cvRound as the magic-number add after a clamp to +-2^21 (NaN goes to the lower bound: outside,
+// as cvRound's INT_MIN saturated to -32768 is), four byte gathers, one dword store.  z outside the division's guarded range (z <= 0,
+// W:61, included): map_backward + sample_nearest for the thread's pixels.
+// ------------------------------------------------------------------------------------------------
+struct WarpMaskArgs { Proj p; MapTabs t; SrcView src; unsigned char* dst; unsigned dst_step; int w, h; };
+
+template <int KIND, bool VEC>
+__global__ __launch_bounds__(256) void k_warp_mask_tile(WarpMaskArgs a) {
+    const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& src = a.src;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dx0 = (blockIdx.x * 16 + (lane & 15)) * 4;
+    const int dy = blockIdx.y * 16 + wv * 4 + (lane >> 4);
+    if (dy >= a.h || dx0 >= a.w) return;
+    const float4 cs4 = *(const float4*)(t.col_s + dx0), cc4 = *(const float4*)(t.col_c + dx0);   // tables are padded to 4 floats
+    const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
+    f32x2 X[2], Y[2], Z[2];
+    if constexpr (KIND == ISX_WARP_CYLINDRICAL) {
+        const float ra = t.row_a[dy];
+        const f32x2 qx = splat2(p.k_rinv[1] * ra), qy = splat2(p.k_rinv[4] * ra), qz = splat2(p.k_rinv[7] * ra);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            X[h] = (splat2(p.k_rinv[0]) * cs[h] + qx) + splat2(p.k_rinv[2]) * cc[h];             // W:56
+            Y[h] = (splat2(p.k_rinv[3]) * cs[h] + qy) + splat2(p.k_rinv[5]) * cc[h];             // W:57
+            Z[h] = (splat2(p.k_rinv[6]) * cs[h] + qz) + splat2(p.k_rinv[8]) * cc[h];             // W:58
+        }
+    } else {
+        const float ra = t.row_a[dy], rb = t.row_b[dy];
+        const f32x2 qx = splat2(p.k_rinv[1] * rb), qy = splat2(p.k_rinv[4] * rb), qz = splat2(p.k_rinv[7] * rb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 x_ = splat2(ra) * cs[h], z_ = splat2(ra) * cc[h];
+            X[h] = (splat2(p.k_rinv[0]) * x_ + qx) + splat2(p.k_rinv[2]) * z_;
+            Y[h] = (splat2(p.k_rinv[3]) * x_ + qy) + splat2(p.k_rinv[5]) * z_;
+            Z[h] = (splat2(p.k_rinv[6]) * x_ + qz) + splat2(p.k_rinv[8]) * z_;
+        }
+    }
+    float tx[4], ty[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 r0 = {__builtin_amdgcn_rcpf(Z[h].x), __builtin_amdgcn_rcpf(Z[h].y)};
+        const f32x2 r1 = refine_rcp(Z[h], r0);
+        const f32x2 ax = div_by_refined(X[h], Z[h], r1), ay = div_by_refined(Y[h], Z[h], r1);    // W:60
+        tx[2 * h] = ax.x; tx[2 * h + 1] = ax.y; ty[2 * h] = ay.x; ty[2 * h + 1] = ay.y;
+    }
+    const float zmin = fminf(fminf(Z[0].x, Z[0].y), fminf(Z[1].x, Z[1].y)), zmax = fmaxf(fmaxf(Z[0].x, Z[0].y), fmaxf(Z[1].x, Z[1].y));
+    const int rows = src.rows, cols = src.cols;
+    const unsigned step = (unsigned)src.step;
+    unsigned m4 = 0u;
+    if ((zmin >= DIV_Z_LO) & (zmax <= DIV_Z_HI)) {
+        const float big = 2097152.f;            // 2^21: beyond any source (cols, rows <= 32767), the magic-number rounding exact inside
+        unsigned off[4];
+        bool in[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float cx = __builtin_amdgcn_fmed3f(tx[k], -big, big), cy = __builtin_amdgcn_fmed3f(ty[k], -big, big);
+            const int ix = (int)(__float_as_uint(cx + RNE_MAGIC) - 0x4B400000u), iy = (int)(__float_as_uint(cy + RNE_MAGIC) - 0x4B400000u);   // cvRound
+            in[k] = ((unsigned)ix < (unsigned)cols) & ((unsigned)iy < (unsigned)rows);
+            off[k] = in[k] ? __umul24((unsigned)iy, step) + (unsigned)ix : 0u;
+        }
+        unsigned v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src.data[off[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m4 |= (in[k] ? v[k] : 0u) << (8 * k);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < 4 && dx0 + k < a.w; ++k) {
+            float mx, my;
+            map_backward(p, t, dx0 + k, dy, mx, my);
+            unsigned char m;
+            sample_nearest<unsigned char, 1>(src, mx, my, ISX_BORDER_CONSTANT, &m);
+            m4 |= (unsigned)m << (8 * k);
+        }
+    }
+    unsigned char* q = a.dst + (__umul24((unsigned)dy, a.dst_step) + (unsigned)dx0);
+    if (VEC && dx0 + 4 <= a.w) *(unsigned*)q = m4;
+    else for (int k = 0; k < 4 && dx0 + k < a.w; ++k) q[k] = (unsigned char)(m4 >> (8 * k));
 }
 
 // the recurrence of k_warp_tile against the compiler's IEEE division on n pseudo-random operand pairs of the guarded range
@@ -972,6 +1061,11 @@ bool cyl_extrema_on_border(const Proj& p, const float k[9], const float rinv[9],
             const float z_ = p.r_kinv[6] * x + p.r_kinv[7] * y + p.r_kinv[8];
             if (!(z_ > 1e-6f)) return false;
         }
+    // sph_poles reproduces OpenCV's SphericalWarper quirk - its south-pole test negates only y - so for rinv[4] < 0 (a camera pitched past
+    // the zenith or rolled by more than a right angle) it tests the mirror image of the axis' true projection about cy, and with an
+    // off-centre principal point a pole inside the image could be reported outside.  The proof below is only used where the quirk cannot
+    // matter; everything else keeps the reference's full scan (W:72-81).
+    if (!(rinv[4] > 0.f)) return false;
     bool north, south;
     sph_poles(k, rinv, sw, sh, &north, &south, 2.f);         // (a pole within two pixels of the border counts as inside)
     return !north && !south;
@@ -1437,6 +1531,28 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         double bytes = (spx + dpx) * mat_elem_size(src->type);
         unsigned char* dp = (unsigned char*)w->st_dst.d.data;
         size_t ds = w->st_dst.d.step;
+        // The two calls the reference makes per tile (W:229 image LINEAR / REFLECT, W:232 mask NEAREST / CONSTANT) take the tile kernels:
+        // k_warp_tile without its mask output, k_warp_mask_tile.  Same limits as the fused entry (32-bit offsets from 24-bit multiplies).
+        static const bool tile_path = [] { const char* e = getenv("ISX_WARP_LITERAL_FAST"); return !(e && e[0] == '0'); }();
+        const bool small = (unsigned long long)w->st_src.d.step * src->rows < (1ull << 31) && w->st_src.d.step < (1u << 24) && src->cols <= 32767 && src->rows <= 32767 &&
+                           ds < (1u << 24) && (unsigned long long)ds * dh < (1ull << 32);
+        if (tile_path && small && src->type == ISX_8UC3 && interp == ISX_INTER_LINEAR && border == ISX_BORDER_REFLECT) {
+            const bool vec = ((uintptr_t)dp % 4 == 0) && (ds % 4 == 0);
+            const dim3 gridt(cdiv(dw, 64), cdiv(dh, 4 * WARP_WAVES));
+            const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0}};
+#define ISX_WARP_IMG(KD, V) ISX_LAUNCH("warp_tile_img", bytes, st, (k_warp_tile<KD, false, V, false>), gridt, dim3(64 * WARP_WAVES), 0, wta)
+            if (w->kind == ISX_WARP_CYLINDRICAL) { if (vec) ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, true); else ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, false); }
+            else { if (vec) ISX_WARP_IMG(ISX_WARP_SPHERICAL, true); else ISX_WARP_IMG(ISX_WARP_SPHERICAL, false); }
+#undef ISX_WARP_IMG
+        } else if (tile_path && small && src->type == ISX_8UC1 && interp == ISX_INTER_NEAREST && border == ISX_BORDER_CONSTANT) {
+            const bool vec = ((uintptr_t)dp % 4 == 0) && (ds % 4 == 0);
+            const WarpMaskArgs wma{w->proj, t, sv, dp, (unsigned)ds, dw, dh};
+            const dim3 gridm(cdiv(dw, 64), cdiv(dh, 16));
+#define ISX_WARP_MSK(KD, V) ISX_LAUNCH("warp_tile_mask", bytes, st, (k_warp_mask_tile<KD, V>), gridm, dim3(256), 0, wma)
+            if (w->kind == ISX_WARP_CYLINDRICAL) { if (vec) ISX_WARP_MSK(ISX_WARP_CYLINDRICAL, true); else ISX_WARP_MSK(ISX_WARP_CYLINDRICAL, false); }
+            else { if (vec) ISX_WARP_MSK(ISX_WARP_SPHERICAL, true); else ISX_WARP_MSK(ISX_WARP_SPHERICAL, false); }
+#undef ISX_WARP_MSK
+        } else
         switch (src->type) {
             case ISX_8UC3: ISX_LAUNCH("warp", bytes, st, (k_warp<unsigned char, 3>), grid, dim3(256), 0, w->proj, t, sv, dp, ds, dw, dh, interp, border); break;
             case ISX_8UC1: ISX_LAUNCH("warp", bytes, st, (k_warp<unsigned char, 1>), grid, dim3(256), 0, w->proj, t, sv, dp, ds, dw, dh, interp, border); break;

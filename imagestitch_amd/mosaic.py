@@ -205,11 +205,18 @@ class IsxGather:
         self._h = C.c_void_p()
         self._check(self._lib.isx_gather_create(self.world, self.rank, ident[0], int(device), C.byref(self._h)))
 
-    def __del__(self):
+    def close(self):
+        """Releases the handle.  With a p2p receive buffer (p2p_setup) the tensor view of it is dropped first - it aliases memory that
+        isx_gather_destroy frees - and every rank must have finished its copies INTO this rank's buffer: barrier across the ranks before
+        close(), as after any one-sided put (the peers' copies are not this rank's stream work, nothing here can wait for them)."""
+        self.p2p_buf = None
         h = getattr(self, "_h", None)
         if h:
             self._lib.isx_gather_destroy(h)
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     def all(self, send, out, stream=None):
         """ONE all-gather of the whole block on `stream` (default: the current torch stream)."""
@@ -237,7 +244,8 @@ class IsxGather:
     def p2p_setup(self, block_bytes, group=None):
         """Allocates this rank's receive buffer (world x block_bytes, the library's own hipMalloc: an IPC handle names a whole
         allocation), exchanges the 64-byte HIP IPC handles and maps every peer's buffer.  Returns the buffer as a torch uint8 tensor
-        (a view of the library's memory: it lives as long as this object)."""
+        (a view of the library's memory: valid until close() / the end of this object - do not keep it beyond; close() drops the
+        object's own reference first)."""
         import torch
         import torch.distributed as dist
         C = self._C

@@ -284,6 +284,34 @@ class PairStitcher:
         self.blender.blend(self.out, self.out_mask)
         return self.out, self.out_mask
 
+    def step_literal(self):
+        """Call for call what a caller written against cv::detail::RotationWarper / cv::detail::Blender issues - the reference's main()
+        through include/imagestitch_cv.hpp: per tile warp(img, K, R, INTER_LINEAR, BORDER_REFLECT) (W:229) and warp(mask, K, R, INTER_NEAREST,
+        BORDER_CONSTANT) (W:232) of the all-255 source mask (W:213-214), EACH with its own detectResultRoi (isx_warper_roi, one host round
+        trip) + isx_warper_warp_roi; convertTo(CV_16S) (W:294); prepare (W:281); feed(CV_16SC3, mask, corner) (W:302: construct with
+        deferred="copy" so that feed() consumes its inputs); blend -> CV_16SC3 + mask (W:313).  Nothing fused, nothing planned."""
+        from . import _lib as L
+        from .blender import convert_to
+        torch = self.torch
+        if not hasattr(self, "src_masks"):
+            self.src_masks = [None if im is None else torch.full(im.shape[:2], 255, dtype=torch.uint8, device=im.device) for im in self.imgs]   # W:213-214
+            self.warped16 = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.int16, device=wi.device) for wi in self.warped]
+        cs = list(self.corners)
+        for i in self.active:
+            im = self.imgs[i]
+            size = (im.shape[1], im.shape[0])
+            roi = self.warper.warpRoi(size, self.K, self.Rs[i])                                                                      # W:126 inside W:229
+            self.warper.warp_roi(im, self.K, self.Rs[i], L.INTER_LINEAR, L.BORDER_REFLECT, roi, self.warped[i])
+            roi = self.warper.warpRoi(size, self.K, self.Rs[i])                                                                      # W:126 inside W:232
+            self.warper.warp_roi(self.src_masks[i], self.K, self.Rs[i], L.INTER_NEAREST, L.BORDER_CONSTANT, roi, self.wmasks[i])
+            cs[i] = (roi[0], roi[1])
+            convert_to(self.warped[i], np.int16, dst=self.warped16[i], device=self.device, stream=self.blender._stream_obj)            # W:294
+        self.blender.prepare(cs, self.sizes)                                                                                         # W:281
+        for i in self.active:
+            self.blender.feed(self.warped16[i], self.seam[i], cs[i])                                                                 # W:302
+        self.blender.blend(self.out, self.out_mask)                                                                                  # W:313
+        return self.out, self.out_mask
+
     def bytes_model(self):
         src_px = [self.imgs[i].shape[0] * self.imgs[i].shape[1] for i in self.active]
         warped_px = [self.sizes[i][0] * self.sizes[i][1] for i in self.active]

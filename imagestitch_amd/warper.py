@@ -114,6 +114,15 @@ class RotationWarper:
         check(self._lib.isx_warper_warp(self._h, C.byref(ms), kp, rp, int(interp_mode), int(border_mode), C.byref(md), corner))
         return (corner[0], corner[1]), dst
 
+    def warp_roi(self, src, K, R, interp_mode, border_mode, roi, dst):
+        """The second half of a RotationWarper::warp as include/imagestitch_cv.hpp issues it: isx_warper_warp_roi with the ROI that
+        isx_warper_roi (warpRoi) just returned, into the caller's dst of (roi height + 1) x (roi width + 1) (W:150, W:157)."""
+        ms, md = as_mat(src), as_mat(dst)
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        check(self._lib.isx_warper_warp_roi(self._h, C.byref(ms), kp, rp, int(interp_mode), int(border_mode), (C.c_int * 4)(*[int(v) for v in roi]), C.byref(md)))
+        return dst
+
     def warp_with_mask(self, img, K, R, mask=None, out16=False, dst_img=None, dst_mask=None):
         """W:229 + W:232 (+ W:294 when out16) in one pass -> (corner, warped_img, warped_mask)."""
         mi = as_mat(img)

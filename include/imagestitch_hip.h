@@ -191,8 +191,9 @@ int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int 
 
 /* ---- blender: replaces Blender::createDefault + MultiBandBlender (W:271-281,302,313) ---- */
 /* Blender::createDefault(type, try_gpu) (W:271,276,278) + setNumBands (W:273).
- * type: ISX_BLEND_MULTI_BAND (num_bands default in OpenCV: 5) or ISX_BLEND_FEATHER (the blender every
- * reference demo actually runs, W:278-280; num_bands / precision are ignored, sharpness 0.02).     */
+ * type: ISX_BLEND_MULTI_BAND (num_bands default in OpenCV: 5), ISX_BLEND_FEATHER (the blender every
+ * reference demo actually runs, W:278-280; num_bands / precision are ignored, sharpness 0.02) or ISX_BLEND_NO
+ * (W:276: the base class - feed() is a masked copy, blend() zeroes what no mask covered).            */
 int isx_blender_create(int type, int num_bands, int precision, int device, isx_blender** out);
 int isx_blender_destroy(isx_blender* b);
 int isx_blender_set_stream(isx_blender* b, void* hip_stream);
@@ -282,6 +283,13 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
  * computed by compensator->feed (a small linear solve on the host, not part of this library).              */
 int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream);
 
+/* ---- the glue conversions of the reference's main() ---------------------------------- */
+/* src.convertTo(dst, dst.type()) with alpha = 1, beta = 0 between the CV_8U, CV_16S and CV_32F depths, same channel count:
+ * images_warped[i].convertTo(images_warped_f[i], CV_32F) (W:261), images_warped_f[k].convertTo(images_warped_s[k], CV_16S) (W:294; CV_8U ->
+ * CV_16S is the two composed, exact) and result.convertTo(CV_8U) (W:315's input).  Widening is exact; narrowing is OpenCV's
+ * saturate_cast (float: cvRound = round-half-even, NaN / overflow -> INT_MIN, then the clamp).  dst is caller-allocated.      */
+int isx_convert_to(const isx_mat* src, isx_mat* dst, int device, void* hip_stream);
+
 /* ---- DP seam finder, its data-parallel part (S = 动态规划法寻找最佳缝合线.cpp) ------------------------- */
 /* estimateSeam(image1, image2, tl1, tl2, comp, p1, p2, seam, isHorizontal) S:806-957 incl. computeCosts S:733-803
  * (costFunc_ COLOR, what `new DpSeamFinder(DpSeamFinder::COLOR)` W:253 / S:71-72 runs): the cost maps and the dynamic
@@ -360,6 +368,8 @@ int isx_blend_pair_linear_release(void);
 typedef struct isx_gather isx_gather;
 int isx_gather_unique_id(unsigned char id[128]);
 int isx_gather_create(int world, int rank, const unsigned char id[128], int device, isx_gather** out);
+/* isx_gather_destroy frees the p2p receive buffer (isx_gather_p2p_alloc) and unmaps the peers': no other rank may still be copying into
+ * this rank's buffer - barrier across the ranks first, as after any one-sided put - and no view of the buffer may be used afterwards. */
 int isx_gather_destroy(isx_gather* g);
 int isx_gather_info(const isx_gather* g, int* world, int* rank);
 int isx_gather_all(isx_gather* g, const void* send, size_t bytes, void* recv, void* hip_stream);
@@ -374,6 +384,7 @@ int isx_gather_synchronize(isx_gather* g);
  *   isx_gather_p2p_alloc : this rank's receive buffer (world x block bytes, its own hipMalloc) and its 64-byte HIP IPC handle, which
  *                          travels to the other ranks by whatever the caller has (as the unique id does);
  *   isx_gather_p2p_open  : maps every rank's buffer (handles: world x 64 bytes, in rank order), creates the per-destination streams;
+ *                          a failure part of the way is rolled back (mappings closed, streams destroyed): the call can be repeated;
  *   isx_gather_p2p_chunk : bytes [offset, offset + bytes) of the send block copied into every rank's buffer (this rank's own
  *                          included) behind `ready_event`, same layout as isx_gather_chunk (isx_gather_chunk_ptr applies);
  *   isx_gather_p2p_wait  : makes `hip_stream` wait for this rank's copies enqueued so far (its send block may then be rewritten);

@@ -300,6 +300,48 @@ class Feather:
         return dst, m
 
 
+class NoBlend:
+    """orc_nb_*: cv::detail::Blender itself (Blender::NO, W:276) restated."""
+
+    def __init__(self):
+        lib().orc_nb_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_nb_create())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_nb_destroy(self.h)
+            self.h = None
+
+    def prepare(self, corners, sizes):
+        c = _c(np.asarray(corners).reshape(-1), np.int32)
+        s = _c(np.asarray(sizes).reshape(-1), np.int32)
+        lib().orc_nb_prepare(self.h, len(c) // 2, _p(c), _p(s))
+
+    def result_size(self):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_nb_result_size(self.h, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def feed(self, img, mask, tl):
+        img, mask = _c(img, np.int16), _c(mask, np.uint8)
+        lib().orc_nb_feed(self.h, _p(img), _p(mask), img.shape[0], img.shape[1], int(tl[0]), int(tl[1]))
+
+    def blend(self):
+        w, h = self.result_size()
+        dst, m = np.empty((h, w, 3), np.int16), np.empty((h, w), np.uint8)
+        lib().orc_nb_blend(self.h, _p(dst), _p(m))
+        return dst, m
+
+
+def convert_f32(src, dtype):
+    """src.convertTo(dst, CV_16S / CV_8U) of a float image: saturate_cast = clamp(cvRound(v))  (W:294, W:315's input)."""
+    src = _c(src, np.float32)
+    dst = np.empty(src.shape, np.dtype(dtype))
+    fn = lib().orc_convert_f32_s16 if dst.dtype == np.int16 else lib().orc_convert_f32_u8
+    fn(_p(src), C.c_size_t(src.size), _p(dst))
+    return dst
+
+
 # ---------------------------------------------------------------- A13
 def blend_pair_linear(img1, img2, tl1, tl2):
     img1, img2 = _c(img1, np.float32), _c(img2, np.float32)

@@ -960,6 +960,51 @@ void orc_fb_blend(orc_fb* b, int16_t* dst, uint8_t* dst_mask) {
     }
 }
 
+/* ---- Blender::NO: cv::detail::Blender itself, what Blender::createDefault(Blender::NO, false) returns (W:276).
+ * OpenCV 3.4.2 modules/stitching/src/blenders.cpp (absent here; restated from the published source):
+ *   prepare(Rect): dst_.create(size, CV_16SC3); dst_.setTo(0); dst_mask_.create(size, CV_8U); dst_mask_.setTo(0)
+ *   feed(img CV_16SC3, mask CV_8U, tl): for every pixel: if (mask) dst_(dy + y, dx + x) = img(y, x); dst_mask_(dy + y, dx + x) |= mask
+ *   blend(dst, dst_mask): dst_.setTo(0, dst_mask_ == 0); dst = dst_; dst_mask = dst_mask_                                   */
+struct orc_nb { int rx, ry, rw, rh; int16_t* dst; uint8_t* mask; };
+orc_nb* orc_nb_create(void) { return (orc_nb*)calloc(1, sizeof(orc_nb)); }
+void orc_nb_destroy(orc_nb* b) { if (b) { free(b->dst); free(b->mask); free(b); } }
+void orc_nb_prepare(orc_nb* b, int n, const int* c, const int* s) {
+    int tlx = INT_MAX, tly = INT_MAX, brx = INT_MIN, bry = INT_MIN;
+    for (int i = 0; i < n; ++i) {      /* resultRoi(corners, sizes) */
+        if (c[2 * i] < tlx) tlx = c[2 * i];
+        if (c[2 * i + 1] < tly) tly = c[2 * i + 1];
+        if (c[2 * i] + s[2 * i] > brx) brx = c[2 * i] + s[2 * i];
+        if (c[2 * i + 1] + s[2 * i + 1] > bry) bry = c[2 * i + 1] + s[2 * i + 1];
+    }
+    free(b->dst); free(b->mask);
+    b->rx = tlx; b->ry = tly; b->rw = brx - tlx; b->rh = bry - tly;
+    b->dst = (int16_t*)calloc((size_t)b->rw * b->rh * 3, sizeof(int16_t));
+    b->mask = (uint8_t*)calloc((size_t)b->rw * b->rh, 1);
+}
+void orc_nb_result_size(const orc_nb* b, int* w, int* h) { *w = b->rw; *h = b->rh; }
+void orc_nb_feed(orc_nb* b, const int16_t* img, const uint8_t* mask, int rows, int cols, int tl_x, int tl_y) {
+    int dx = tl_x - b->rx, dy = tl_y - b->ry;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            size_t di = (size_t)(dy + y) * b->rw + dx + x, si = (size_t)y * cols + x;
+            if (mask[si]) for (int c = 0; c < 3; ++c) b->dst[di * 3 + c] = img[si * 3 + c];
+            b->mask[di] |= mask[si];
+        }
+}
+void orc_nb_blend(orc_nb* b, int16_t* dst, uint8_t* dst_mask) {
+    size_t n = (size_t)b->rw * b->rh;
+    for (size_t k = 0; k < n; ++k) {
+        for (int c = 0; c < 3; ++c) dst[k * 3 + c] = b->mask[k] ? b->dst[k * 3 + c] : 0;
+        if (dst_mask) dst_mask[k] = b->mask[k];
+    }
+}
+
+/* ---- A14: Mat::convertTo (alpha 1, beta 0) where it narrows: saturate_cast<short / uchar>(float) = clamp(cvRound(v)), W:294, W:315 */
+void orc_convert_f32_s16(const float* src, size_t n, int16_t* dst) { for (size_t i = 0; i < n; ++i) dst[i] = sat_s16(orc_cvround(src[i])); }
+void orc_convert_f32_u8(const float* src, size_t n, uint8_t* dst) {
+    for (size_t i = 0; i < n; ++i) { int v = orc_cvround(src[i]); dst[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* N1  DP seam finder, the data-parallel part: computeCosts S:733-803, estimateSeam S:806-957     */
 /* ------------------------------------------------------------------------------------------ */

@@ -123,6 +123,19 @@ void    orc_fb_result_size(const orc_fb* b, int* w, int* h);
 void    orc_fb_feed(orc_fb* b, const int16_t* img, const uint8_t* mask, int rows, int cols, int tl_x, int tl_y);
 void    orc_fb_blend(orc_fb* b, int16_t* dst, uint8_t* dst_mask);
 
+/* Blender::NO = cv::detail::Blender itself (W:276) */
+typedef struct orc_nb orc_nb;
+orc_nb* orc_nb_create(void);
+void    orc_nb_destroy(orc_nb* b);
+void    orc_nb_prepare(orc_nb* b, int n, const int* corners_xy, const int* sizes_wh);
+void    orc_nb_result_size(const orc_nb* b, int* w, int* h);
+void    orc_nb_feed(orc_nb* b, const int16_t* img, const uint8_t* mask, int rows, int cols, int tl_x, int tl_y);
+void    orc_nb_blend(orc_nb* b, int16_t* dst, uint8_t* dst_mask);
+
+/* Mat::convertTo where it narrows (W:294: CV_32F -> CV_16S; W:315's input: -> CV_8U) */
+void orc_convert_f32_s16(const float* src, size_t n, int16_t* dst);
+void orc_convert_f32_u8(const float* src, size_t n, uint8_t* dst);
+
 /* N1, the data-parallel part of the in-tree DP seam finder (S = 动态规划法寻找最佳缝合线.cpp):
  * computeCosts S:733-803 (costFunc_ COLOR) and estimateSeam S:806-957.  Images are HWC 3-channel float (is_u8 == 0)
  * or uint8 (is_u8 == 1), contiguous; labels is the union-sized int32 label image (labels_), label = comp + 1,

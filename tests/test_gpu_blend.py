@@ -132,7 +132,7 @@ def test_blender_errors(gpu):
         mb.blend()
     assert e.value.code == 3  # blend() released the pyramids
     with pytest.raises(gpu.IsxError):
-        gpu.Blender.createDefault(gpu.Blender.NO)
+        gpu.Blender.createDefault(3)     # NO (0), FEATHER (1), MULTI_BAND (2) exist (Blender::NO: tests/test_gpu_s16_tiles.py)
 
 
 @pytest.mark.parametrize("dy", [3, -5, 0])

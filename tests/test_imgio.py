@@ -256,3 +256,67 @@ def test_jpeg_read_survives_corrupted_files(isx, tmp_path):
         except IsxError:
             refused += 1
     assert decoded > 50 and refused > 50
+
+
+def _jpeg_segments(data):
+    """Split a baseline JPEG into (marker, payload-with-length) segments up to and including SOS + its entropy-coded data."""
+    segs, p = [], 2
+    while p < len(data):
+        assert data[p] == 0xFF
+        m = data[p + 1]
+        n = (data[p + 2] << 8) | data[p + 3]
+        if m == 0xDA:
+            segs.append((m, bytes(data[p:])))      # scan header + entropy-coded data + EOI
+            break
+        segs.append((m, bytes(data[p:p + 2 + n])))
+        p += 2 + n
+    return segs
+
+
+def test_jpeg_read_refuses_structurally_hostile_files(isx, tmp_path):
+    """Structures byte-level mutation cannot produce: a second frame header that enlarges the image after the coefficient
+    buffers were sized; DRI / SOS segments that end before their payload, at the very end of the file; a few-hundred-byte file that
+    declares 65535 x 65535 pixels.  Each is refused with an error (the first used to write past the heap, the last to throw bad_alloc)."""
+    import io
+    from imagestitch_amd._lib import IsxError
+    rng = np.random.default_rng(2)
+
+    def jpeg(w, h):
+        b = io.BytesIO()
+        PIL.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(b, "JPEG", quality=80, subsampling=0)
+        return b.getvalue()
+    small, big = jpeg(8, 8), jpeg(512, 512)
+    path = str(tmp_path / "hostile.jpg")
+
+    def refused(data, what):
+        with open(path, "wb") as f:
+            f.write(data)
+        with pytest.raises(IsxError):
+            isx.imread(path)
+        # the C entry point itself, with an output mat of the size the FIRST header declares (the caller of a C-ABI sizes its own buffer)
+        import ctypes as C
+        from imagestitch_amd import _lib
+        out = np.zeros((8, 8, 3), np.uint8)
+        m = _lib.as_mat(out)
+        assert _lib.load().isx_jpeg_read(path.encode(), C.byref(m)) != 0, what
+
+    s_small, s_big = _jpeg_segments(small), _jpeg_segments(big)
+    sof_big = [seg for mk, seg in s_big if mk == 0xC0][0]
+    sos_big = [seg for mk, seg in s_big if mk == 0xDA][0]
+    # 1. 8 x 8 frame + its scan, then a 512 x 512 SOF + scan
+    body = b"".join(seg for _, seg in s_small)
+    assert body.endswith(b"\xff\xd9")
+    refused(b"\xff\xd8" + body[:-2] + sof_big + sos_big, "second SOF")
+    # 2. a marker segment of length 2 that ends the file: DRI, SOS
+    head = b"".join(seg for mk, seg in s_small if mk != 0xDA)
+    refused(b"\xff\xd8" + head + b"\xff\xdd\x00\x02", "DRI without payload")
+    refused(b"\xff\xd8" + head + b"\xff\xda\x00\x02", "SOS without payload")
+    # 3. huge declared size in a tiny file
+    sof = bytearray([seg for mk, seg in s_small if mk == 0xC0][0])
+    sof[5:9] = b"\xff\xff\xff\xff"
+    parts = [bytes(sof) if mk == 0xC0 else seg for mk, seg in s_small]
+    refused(b"\xff\xd8" + b"".join(parts), "65535 x 65535 in a few hundred bytes")
+    # the untouched files still decode
+    with open(path, "wb") as f:
+        f.write(big)
+    assert isx.imread(path).shape == (512, 512, 3)

@@ -247,3 +247,32 @@ def test_seam_estimate_known_answers(oracle):
     lab2 = lab.copy(); lab2[20, :] = 2
     seam, _ = oracle.seam_estimate(a, a, (0, 0), (0, 0), (0, 0), lab2, 1, (0, 0, w, h), (10, 0), (10, h - 1))
     assert len(seam) == 0
+
+
+def test_blender_no_known_answers(oracle):
+    """cv::detail::Blender (Blender::NO, W:276): feed copies under the mask and ORs the mask, blend zeroes what no mask covered."""
+    nb = oracle.NoBlend()
+    nb.prepare([(0, 0), (2, 1)], [(4, 3), (4, 3)])
+    assert nb.result_size() == (6, 4)
+    a = np.full((3, 4, 3), 100, np.int16)
+    b = np.full((3, 4, 3), -7, np.int16)
+    ma = np.array([[255, 255, 0, 0]] * 3, np.uint8)
+    mb = np.array([[0, 4, 9, 0]] * 3, np.uint8)
+    nb.feed(a, ma, (0, 0))
+    nb.feed(b, mb, (2, 1))
+    d, m = nb.blend()
+    want_m = np.zeros((4, 6), np.uint8)
+    want_m[0:3, 0:2] = 255
+    want_m[1:4, 3] |= 4
+    want_m[1:4, 4] |= 9
+    assert np.array_equal(m, want_m)
+    assert np.all(d[m == 0] == 0)
+    assert np.all(d[0:3, 0:2] == 100) and np.all(d[1:4, 3:5] == -7)
+
+
+def test_convert_known_answers(oracle):
+    """Mat::convertTo(CV_16S / CV_8U) of floats (W:294, W:315's input): saturate_cast<T>(cvRound(v)), ties to even, cvtss2si's indefinite."""
+    f = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 32767.4, 32767.5, 40000.0, -32768.5, -40000.0, 1e20, -1e20, np.nan, np.inf], np.float32)
+    assert oracle.convert_f32(f, np.int16).tolist() == [0, 2, 2, 0, -2, 32767, 32767, 32767, -32768, -32768, -32768, -32768, -32768, -32768]
+    g = np.array([0.5, 1.5, 254.5, 255.5, 300.0, -3.0, np.nan, 1e20], np.float32)
+    assert oracle.convert_f32(g, np.uint8).tolist() == [0, 2, 254, 255, 255, 0, 0, 0]

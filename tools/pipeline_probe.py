@@ -14,10 +14,10 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 imgs = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generator=g) for _ in range(2)]
 from imagestitch_amd.pipeline import PairStitcher
-ps = PairStitcher(imgs, K, Rs, F, "cylindrical", bands, prec, 0, None, "int16")
-print("corners", ps.corners, "sizes", ps.sizes)
 mode = sys.argv[3] if len(sys.argv) > 3 else "planned"
-step = ps.step_sync if mode == "sync" else ps.step
+ps = PairStitcher(imgs, K, Rs, F, "cylindrical", bands, prec, 0, None, "int16", deferred="copy" if mode in ("sync", "literal") else True)
+print("corners", ps.corners, "sizes", ps.sizes)
+step = ps.step_sync if mode == "sync" else (ps.step_literal if mode == "literal" else ps.step)
 if mode == "graph":
     ps.capture()
     step = ps.replay

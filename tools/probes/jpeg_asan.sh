@@ -43,6 +43,27 @@ for it in range(4000):
     else:
         for _ in range(3): data[int(rng.integers(2, min(len(data), 200)))] = int(rng.integers(0, 256))
     open("c/%04d.jpg" % it, "wb").write(bytes(data))
+# structures no byte-level mutation produces: a second, larger frame header after a scan; DRI / SOS segments that end before
+# their payload at the end of the file; 65535 x 65535 declared by a few hundred bytes; every pair of originals spliced header-to-scan
+def segs(d):
+    out, p = [], 2
+    while p < len(d):
+        m = d[p + 1]; n = (d[p + 2] << 8) | d[p + 3]
+        if m == 0xDA: out.append((m, bytes(d[p:]))); break
+        out.append((m, bytes(d[p:p + 2 + n]))); p += 2 + n
+    return out
+k = 0
+for a in base[:9]:
+    sa = segs(a)
+    head = b"".join(s for m, s in sa if m != 0xDA); body = b"".join(s for m, s in sa)
+    for tail in (b"\xff\xdd\x00\x02", b"\xff\xda\x00\x02", b"\xff\xc4\x00\x02", b"\xff\xdb\x00\x02", b"\xff\xc0\x00\x02"):
+        open("c/s%04d.jpg" % k, "wb").write(b"\xff\xd8" + head + tail); k += 1
+    for b2 in base[:9]:
+        sb = segs(b2)
+        extra = b"".join(s for m, s in sb if m in (0xC0, 0xDA))
+        open("c/s%04d.jpg" % k, "wb").write(b"\xff\xd8" + body[:-2] + extra); k += 1
+    sof = bytearray([s for m, s in sa if m == 0xC0][0]); sof[5:9] = b"\xff\xff\xff\xff"
+    open("c/s%04d.jpg" % k, "wb").write(b"\xff\xd8" + b"".join(bytes(sof) if m == 0xC0 else s for m, s in sa)); k += 1
 PY
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer --offload-arch=gfx950 -Wno-option-ignored -I"$R/include" -I"$R/imagestitch_amd/csrc" \
     harness.cpp "$R/imagestitch_amd/csrc/jpegdec.cpp" "$R/imagestitch_amd/csrc/isx_core.cpp" -o harness
