@@ -40,7 +40,7 @@ def measured_traffic(kernel, args, live=True):
     import subprocess
     import tempfile
     extra = ["--precision", args.precision, "--bands", str(args.bands), "--width", str(args.width), "--height", str(args.height),
-             "--focal", str(args.focal), "--kind", args.kind, "--tiles", str(args.tiles), "--cycle", args.cycle]
+             "--focal", str(args.focal), "--kind", args.kind, "--tiles", str(args.tiles), "--cycle", args.cycle, "--tile-type", args.tile_type]
     if live and shutil.which("rocprofv3"):
         try:
             with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -57,7 +57,7 @@ def measured_traffic(kernel, args, live=True):
     try:
         path = os.path.join(ROOT, "profiles", "round3_traffic.json")
         d = json.load(open(path))
-        if d.get("bench_args", []) != [] or args.precision != "f32" or args.bands != 5 or args.tiles != 2 or args.width != 3840 or args.kind != "cylindrical":
+        if d.get("bench_args", []) != [] or args.precision != "f32" or args.bands != 5 or args.tiles != 2 or args.width != 3840 or args.kind != "cylindrical" or args.tile_type != "u8":
             return None, "no PMC measurement of this command"
         return d["kernels"][kernel]["traffic_bytes"], ("profiles/round3_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
                                                       "rocprofv3 was not usable in this run)")
@@ -198,7 +198,7 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
         out["fused_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1)}
         ref_out, ref_mask = ps.out.clone(), ps.out_mask.clone()
         dt = timed(ps.step_literal, steps)
-        same = bool(torch.equal(ps.out, ref_out) and torch.equal(ps.out_mask, ref_mask))
+        same = bool(torch.equal(ps.lit_out, ref_out) and torch.equal(ps.lit_out_mask, ref_mask))
         out["literal_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1), "equals_fused": same}
         ps.warper.set_roi_cache(True)       # the adapter's fixed_rig option: detectResultRoi of an unchanged (K, R, size) is remembered
         dt = timed(ps.step_literal, steps)
@@ -362,6 +362,9 @@ def main():
     ap.add_argument("--cycle", default="deferred", choices=["deferred", "copy", "eager"],
                     help="blender cycle: deferred on the stitcher's own buffers (default), deferred with private copies of the fed mats "
                          "(OpenCV's feed contract, isx_blender_set_deferred_level0 = 2), or the eager destination-pyramid cycle")
+    ap.add_argument("--tile-type", default="u8", choices=["u8", "s16"],
+                    help="type of the warped tiles: u8 = CV_8UC3 through feed_u8 (the convertTo(CV_16S) of W:294 fused into feed), s16 = CV_16SC3 (the warp "
+                         "writes them so; feed() receives what the reference's feed() receives, W:302)")
     ap.add_argument("--roi-cache", action="store_true", help="with --sync-roi: isx_warper_set_roi_cache (the ROI of a fixed rig is computed once)")
     ap.add_argument("--sync-roi", action="store_true", help="return every warp's corner to the host (one stream sync per tile) instead of the planned, device-checked ROI")
     args = ap.parse_args()
@@ -457,7 +460,7 @@ def main():
         if p == 0 and rank == 0:
             host_imgs0 = [im.cpu().numpy() for im in imgs]
         pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, pstreams[p % len(pstreams)], "uint8" if (world > 1 or args.force_dist) else "int16",
-                                  deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle], window=window))
+                                  deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle], window=window, tile_type=args.tile_type))
         del yy, xx
     if args.roi_cache:
         for p in pairs:
@@ -748,7 +751,7 @@ def main():
                 "tiles_per_mosaic": NT,
                 **({"shard": "strips", "strip": "%d/%d" % (strip_rank, strip_world), "window": list(window), "panorama_cols": fw_all,
                     "tiles_this_rank": pairs[0].active} if strips else {}),
-                "pairs_per_gpu": args.pairs, "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "pairs_per_gpu": args.pairs, "tile_type": args.tile_type, "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
             # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them
@@ -776,7 +779,7 @@ def main():
             # timed region above the kernels run alone, which is what `roofline` needs.
             s2 = torch.cuda.Stream(device=dev)
             p2 = PairStitcher(pairs[0].imgs, K, Rs, F, args.kind, args.bands, prec, local, s2, "int16",
-                              deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle])
+                              deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle], tile_type=args.tile_type)
             both = [pairs[0], p2]
             for i in range(4):
                 both[i % 2].step_sync() if args.sync_roi else both[i % 2].step()

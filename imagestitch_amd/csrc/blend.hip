@@ -2218,11 +2218,14 @@ int flush_feather(isx_blender* b) {
 // feed() consumes its inputs - the reference releases the fed mats before blend(), W:305-308): take a private copy, one
 // device-to-device pass on the blender's stream (4 B/px for a CV_8UC3 tile + its mask).  A copy kernel, not
 // hipMemcpy2DAsync: the runtime's pitched D2D copy moved the 59 MB of a 4K pair at 0.46 TB/s (127 us).
-template <class V>
-__global__ __launch_bounds__(256) void k_copy_rows(const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep, unsigned row_bytes, int rows) {
-    // units of sizeof(V) bytes; a row's last unit may overhang the row (never the source's pitch, checked by the host) except
-    // in the last row, whose overhanging unit is copied byte by byte
-    const unsigned u = blockIdx.x * 256 + threadIdx.x, off = u * (unsigned)sizeof(V);
+// 16-byte units per thread: loads from the caller's mat at whatever alignment its rows have (a dense cv::Mat row of 3425 CV_16SC3 pixels
+// starts on a 2-byte boundary; unaligned global access is legal on this part and costs nothing at a regular stride), stores to the
+// private buffer aligned.  A unit that overhangs the row reads into the next row (inside the mat) and writes into the copy's own pitch;
+// the last row's overhanging unit is copied byte by byte.
+typedef unsigned u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+__global__ __launch_bounds__(256) void k_copy_rows(const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep, unsigned long long row_bytes, int rows) {
+    const unsigned long long off = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16ull;
     const int y0 = blockIdx.y * 8;
     if (off >= row_bytes) return;
 #pragma unroll
@@ -2231,27 +2234,21 @@ __global__ __launch_bounds__(256) void k_copy_rows(const unsigned char* src, siz
         if (y >= rows) break;
         const unsigned char* sp = src + (size_t)y * sstep + off;
         unsigned char* dp = dst + (size_t)y * dstep + off;
-        if (y < rows - 1 || off + (unsigned)sizeof(V) <= row_bytes) *(V*)dp = *(const V*)sp;
+        if (y < rows - 1 || off + 16ull <= row_bytes) *(u32x4_a16*)dp = *(const u32x4_a1*)sp;
         else for (unsigned b = 0; off + b < row_bytes; ++b) dp[b] = sp[b];
     }
 }
 
 int private_copy(isx_mat& d, DevBuf& buf, hipStream_t st) {
     const size_t row_bytes = (size_t)d.cols * mat_elem_size(d.type);
+    const unsigned char* src = (const unsigned char*)d.data;
+    const double bytes = 2.0 * (double)row_bytes * d.rows;
+    // the copy's rows start on 64-byte boundaries whatever the caller's do: the level-0 kernels read a CV_16SC3 pair as one 12-byte load,
+    // and against a continuous copy of 20 550-byte rows (2-byte aligned starts) the last collapse step ran 85 us instead of 58
     const size_t pitch = (row_bytes + 63) & ~(size_t)63;
     ISX_TRY(buf.reserve(pitch * (size_t)d.rows + 64));
-    const unsigned char* src = (const unsigned char*)d.data;
-    unsigned char* dst = (unsigned char*)buf.p;
-    const double bytes = 2.0 * (double)row_bytes * d.rows;
-    const auto fits = [&](size_t unit) { return ((uintptr_t)src & (unit - 1)) == 0 && (d.step & (unit - 1)) == 0 && ((row_bytes + unit - 1) & ~(unit - 1)) <= d.step; };
-    const dim3 block(256);
-    if (fits(16)) {
-        ISX_LAUNCH("feed_copy", bytes, st, (k_copy_rows<uint4>), dim3(cdiv((int)cdiv((int)row_bytes, 16), 256), cdiv(d.rows, 8)), block, 0, src, d.step, dst, pitch, (unsigned)row_bytes, d.rows);
-    } else if (fits(4)) {
-        ISX_LAUNCH("feed_copy", bytes, st, (k_copy_rows<unsigned>), dim3(cdiv((int)cdiv((int)row_bytes, 4), 256), cdiv(d.rows, 8)), block, 0, src, d.step, dst, pitch, (unsigned)row_bytes, d.rows);
-    } else {
-        ISX_LAUNCH("feed_copy", bytes, st, (k_copy_rows<unsigned char>), dim3(cdiv((int)row_bytes, 256), cdiv(d.rows, 8)), block, 0, src, d.step, dst, pitch, (unsigned)row_bytes, d.rows);
-    }
+    ISX_LAUNCH("feed_copy", bytes, st, k_copy_rows, dim3(cdiv((int)cdiv((int)row_bytes, 16), 256), cdiv(d.rows, 8)), dim3(256), 0, src, d.step, (unsigned char*)buf.p, pitch,
+               (unsigned long long)row_bytes, d.rows);
     d.data = buf.p; d.step = pitch;
     return ISX_OK;
 }

@@ -207,27 +207,25 @@ __device__ __forceinline__ D convert_one(S v) {
     else if constexpr (sizeof(S) == 4 && sizeof(D) == 1) return (D)isxd::sat_u8(isxd::cvround_x86(v));        // f32 -> u8
     else return (D)isxd::sat_u8((int)v);                                                                        // s16 -> u8
 }
-template <class S, class D, bool VEC>
+// N values per thread as ONE vector load and ONE vector store, at whatever alignment the rows have (a dense cv::Mat row of 3425 CV_16SC3
+// pixels starts on a 2-byte boundary; unaligned global access is legal on this part).  The row's last, partial group goes value by value.
+template <class S, class D, int N>
 __global__ __launch_bounds__(256) void k_convert(const unsigned char* src, size_t sstep, unsigned char* dst, size_t dstep, int rows, int n) {
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (y >= rows) return;
     const S* s = (const S*)(src + (size_t)y * sstep);
     D* d = (D*)(dst + (size_t)y * dstep);
-    if constexpr (VEC) {        // four values per thread: source and destination rows 4-value aligned
-        const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-        if (x >= n) return;
-        if (x + 4 <= n) {
-            typedef S sv4 __attribute__((ext_vector_type(4)));
-            typedef D dv4 __attribute__((ext_vector_type(4)));
-            const sv4 v = *(const sv4*)(s + x);
-            dv4 o;
-            o.x = convert_one<S, D>(v.x); o.y = convert_one<S, D>(v.y); o.z = convert_one<S, D>(v.z); o.w = convert_one<S, D>(v.w);
-            *(dv4*)(d + x) = o;
-        } else for (int k = x; k < n; ++k) d[k] = convert_one<S, D>(s[k]);
-    } else {
-        const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-        if (x < n) d[x] = convert_one<S, D>(s[x]);
-    }
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * N;
+    if (x >= n) return;
+    if (x + N <= n) {
+        typedef S svn __attribute__((ext_vector_type(N), aligned(1)));
+        typedef D dvn __attribute__((ext_vector_type(N), aligned(1)));
+        const svn v = *(const svn*)(s + x);
+        dvn o;
+#pragma unroll
+        for (int k = 0; k < N; ++k) o[k] = convert_one<S, D>(v[k]);
+        *(dvn*)(d + x) = o;
+    } else for (int k = x; k < n; ++k) d[k] = convert_one<S, D>(s[k]);
 }
 
 }  // namespace
@@ -310,21 +308,17 @@ int isx_convert_to(const isx_mat* src, isx_mat* dst, int device, void* hip_strea
     ISX_TRY(so.use_out(dst, st, "convertTo: dst"));
     const int rows = src->rows, n = src->cols * mat_cn(src->type);
     const size_t ss = sd == 0 ? 1 : (sd == 3 ? 2 : 4), ds = dd == 0 ? 1 : (dd == 3 ? 2 : 4);
-    const bool vec = ((uintptr_t)si.d.data % (4 * ss) == 0) && (si.d.step % (4 * ss) == 0) && ((uintptr_t)so.d.data % (4 * ds) == 0) && (so.d.step % (4 * ds) == 0);
     const double bytes = (double)rows * n * (double)(ss + ds);
     const unsigned char* sp = (const unsigned char*)si.d.data;
     unsigned char* dp = (unsigned char*)so.d.data;
-#define ISX_CVT(S, D)                                                                                                                       \
-    do {                                                                                                                                    \
-        if (vec) ISX_LAUNCH("convert_to", bytes, st, (k_convert<S, D, true>), dim3(cdiv(cdiv(n, 4), 64), cdiv(rows, 4)), dim3(256), 0, sp, si.d.step, dp, so.d.step, rows, n); \
-        else ISX_LAUNCH("convert_to", bytes, st, (k_convert<S, D, false>), dim3(cdiv(n, 64), cdiv(rows, 4)), dim3(256), 0, sp, si.d.step, dp, so.d.step, rows, n);             \
-    } while (0)
-    if (sd == 0 && dd == 3) ISX_CVT(unsigned char, short);
-    else if (sd == 0 && dd == 5) ISX_CVT(unsigned char, float);
-    else if (sd == 3 && dd == 5) ISX_CVT(short, float);
-    else if (sd == 5 && dd == 3) ISX_CVT(float, short);
-    else if (sd == 5 && dd == 0) ISX_CVT(float, unsigned char);
-    else ISX_CVT(short, unsigned char);
+    // values per thread: 16 bytes of the wider side (8 where the wider side is 2 bytes)
+#define ISX_CVT(S, D, N) ISX_LAUNCH("convert_to", bytes, st, (k_convert<S, D, N>), dim3(cdiv(cdiv(n, N), 64), cdiv(rows, 4)), dim3(256), 0, sp, si.d.step, dp, so.d.step, rows, n)
+    if (sd == 0 && dd == 3) ISX_CVT(unsigned char, short, 8);
+    else if (sd == 0 && dd == 5) ISX_CVT(unsigned char, float, 4);
+    else if (sd == 3 && dd == 5) ISX_CVT(short, float, 4);
+    else if (sd == 5 && dd == 3) ISX_CVT(float, short, 4);
+    else if (sd == 5 && dd == 0) ISX_CVT(float, unsigned char, 4);
+    else ISX_CVT(short, unsigned char, 8);
 #undef ISX_CVT
     ISX_TRY(so.finish_out(st));
     if (src->device < 0 || dst->device < 0) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return

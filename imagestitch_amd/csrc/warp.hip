@@ -14,6 +14,7 @@
 #include "isx_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -422,6 +423,8 @@ __device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t,
 __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
 
 struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; };
+typedef unsigned WV3 __attribute__((ext_vector_type(3), aligned(1)));      // a 12-byte run of a destination row, any alignment
+typedef unsigned WV1 __attribute__((aligned(1)));
 
 // one pixel of the fixed-point bilinear from its two 12-byte windows: window pixel 0 weighs wA, pixel 1 weighs wB (wA + wB = 32),
 // the upper row gy, the lower fy (gy + fy = 32): (sum of the BilinearTab_i products + 2^14) >> 15 == (S + 512) >> 10 with the
@@ -623,26 +626,26 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
     // ---- stores ------------------------------------------------------------------------------------------------------------
     if ((WARP_ABL & 1) && d.w > -3) { if (px[0] + px[1] + px[2] + px[3] + m4 == 0x12345u) d.mask[0] = 1; return; }
     if (whole) {
+        // one vector store per run, typed for ANY alignment (WV3 / WV1: aligned(1)): a dense cv::Mat row of 3425 CV_8UC3 pixels starts on
+        // an odd byte, unaligned global access is legal on this part and a wave's runs are contiguous either way
         if constexpr (OUT16) {
-            unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 6u));
+            unsigned char* q = d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 6u);
 #pragma unroll
             for (int k = 0; k < 4; k += 2) {   // 2 pixels = 6 shorts = 3 dwords
                 const unsigned a0 = px[k], b2 = px[k + 1];
-                q[3 * (k / 2)] = (a0 & 255) | (((a0 >> 8) & 255) << 16);
-                q[3 * (k / 2) + 1] = ((a0 >> 16) & 255) | ((b2 & 255) << 16);
-                q[3 * (k / 2) + 2] = ((b2 >> 8) & 255) | (((b2 >> 16) & 255) << 16);
+                *(WV3*)(q + 12 * (k / 2)) = WV3{(a0 & 255) | (((a0 >> 8) & 255) << 16), ((a0 >> 16) & 255) | ((b2 & 255) << 16), ((b2 >> 8) & 255) | (((b2 >> 16) & 255) << 16)};
             }
         } else {
-            unsigned* q = (unsigned*)(d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 3u));
+            unsigned char* q = d.img + (__umul24((unsigned)dy, d.img_step) + (unsigned)dx0 * 3u);
             const unsigned q0 = px[0] | (px[1] << 24);                                   // b0 g0 r0 b1
             const unsigned q1 = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);        // g1 r1 b2 g2
             const unsigned q2 = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);        // r2 b3 g3 r3
-            if (WARP_ABL & 8) { __builtin_nontemporal_store(q0, q); __builtin_nontemporal_store(q1, q + 1); __builtin_nontemporal_store(q2, q + 2); }
-            else { q[0] = q0; q[1] = q1; q[2] = q2; }
+            if (WARP_ABL & 8) __builtin_nontemporal_store(WV3{q0, q1, q2}, (WV3*)q);
+            else *(WV3*)q = WV3{q0, q1, q2};
         }
         if constexpr (MASK) {
-            if (WARP_ABL & 8) __builtin_nontemporal_store(m4, (unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)));
-            else *(unsigned*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
+            if (WARP_ABL & 8) __builtin_nontemporal_store(m4, (WV1*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)));
+            else *(WV1*)(d.mask + (__umul24((unsigned)dy, d.mask_step) + (unsigned)dx0)) = m4;
         }
     } else {    // the partial group at the right edge, or destination rows that are not dword aligned: per-pixel stores
 #pragma unroll 1
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256) void k_warp_mask_tile(WarpMaskArgs a) {
         }
     }
     unsigned char* q = a.dst + (__umul24((unsigned)dy, a.dst_step) + (unsigned)dx0);
-    if (VEC && dx0 + 4 <= a.w) *(unsigned*)q = m4;
+    if (VEC && dx0 + 4 <= a.w) *(WV1*)q = m4;
     else for (int k = 0; k < 4 && dx0 + k < a.w; ++k) q[k] = (unsigned char)(m4 >> (8 * k));
 }
 
@@ -970,6 +973,92 @@ __global__ void k_roi_check_rearm(unsigned* keys, RoiBounds b, int* mismatches) 
     keys[0] = 0xffffffffu; keys[1] = 0xffffffffu; keys[2] = 0u; keys[3] = 0u; keys[4] = 0u;
 }
 
+// The synchronous border scan with its answer delivered straight into pinned host memory: detectResultRoi has to hand the corner to the
+// host (W:160), and the round trip - kernel, copy of {count, candidates}, a kernel that re-arms the device-side keys, a stream
+// synchronisation - cost the caller's thread 45 us per call, four times per pair in the reference's own call sequence (W:229, W:232 each
+// run detectResultRoi).  Here ONE workgroup ranks the 2 (W + H) border pixels (stand-ins kept in registers between the two passes while
+// they fit: 16 per thread), counts the candidates in LDS, writes them and the count into the caller's pinned block and publishes a
+// sequence number with a system-scope release store; the host polls that word (detect_roi) - no copy, no second kernel, no
+// hipStreamSynchronize.  Candidates beyond the pinned block's CAND_FIRST also go to the device buffer (the host fetches them: rare).
+constexpr int PIN_CAND = 1024;      // == CAND_FIRST (checked where that is defined)
+struct RoiPin { int seq, count, pad[14]; int cand[2 * PIN_CAND]; };
+__global__ __launch_bounds__(1024) void k_roi_border_pin(Proj p, int sw, int sh, RoiPin* pin, int seq, int* cand_dev, int cap) {
+    __shared__ float red[4][16];
+    __shared__ int s_count;
+    constexpr int PER = 16;
+    const int n = 2 * sw + 2 * sh;
+    const bool fits = n <= PER * 1024;
+    float dv[PER], qv[PER];
+    float dmin = 3.402823466e+38f, qmin = 3.402823466e+38f, dmax = -3.402823466e+38f, qmax = -3.402823466e+38f;
+    if (threadIdx.x == 0) s_count = 0;
+    auto proxy = [&](int i, float& d, float& q) {
+        int x, y;
+        border_point(i, sw, sh, x, y);
+        if (p.kind == ISX_WARP_SPHERICAL) forward_proxy_sph(p, (float)x, (float)y, d, q); else forward_proxy(p, (float)x, (float)y, d, q);
+    };
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 1024 * k;
+            float d = 0.f, q = 0.f;
+            if (i < n) {
+                proxy(i, d, q);
+                dmin = (d < dmin) ? d : dmin; qmin = (q < qmin) ? q : qmin; dmax = (dmax < d) ? d : dmax; qmax = (qmax < q) ? q : qmax;
+            }
+            dv[k] = d; qv[k] = q;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            float d, q;
+            proxy(i, d, q);
+            dmin = (d < dmin) ? d : dmin; qmin = (q < qmin) ? q : qmin; dmax = (dmax < d) ? d : dmax; qmax = (qmax < q) ? q : qmax;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = fminf(dmin, __shfl_xor(dmin, o)); qmin = fminf(qmin, __shfl_xor(qmin, o));
+        dmax = fmaxf(dmax, __shfl_xor(dmax, o)); qmax = fmaxf(qmax, __shfl_xor(qmax, o));
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = dmin; red[1][wv] = qmin; red[2][wv] = dmax; red[3][wv] = qmax; }
+    __syncthreads();
+    dmin = red[0][0]; qmin = red[1][0]; dmax = red[2][0]; qmax = red[3][0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { dmin = fminf(dmin, red[0][k]); qmin = fminf(qmin, red[1][k]); dmax = fmaxf(dmax, red[2][k]); qmax = fmaxf(qmax, red[3][k]); }
+    const float tol_d = 7.62939453125e-06f;                                   // as k_roi_candidates
+    const float tol_q = 4e-6f * fmaxf(fabsf(qmin), fabsf(qmax)) + 1e-9f;
+    bool wrote = false;
+    auto take = [&](int i, float d, float q) {
+        if (d <= dmin + tol_d || d >= dmax - tol_d || q <= qmin + tol_q || q >= qmax - tol_q) {
+            int x, y;
+            border_point(i, sw, sh, x, y);
+            const int j = atomicAdd(&s_count, 1);
+            if (j < PIN_CAND) { pin->cand[2 * j] = x; pin->cand[2 * j + 1] = y; wrote = true; }
+            if (j < cap) { cand_dev[2 * j] = x; cand_dev[2 * j + 1] = y; }
+        }
+    };
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 1024 * k;
+            if (i < n) take(i, dv[k], qv[k]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            float d, q;
+            proxy(i, d, q);
+            take(i, d, q);
+        }
+    }
+    if (wrote) __threadfence_system();          // the candidates are in host memory before the sequence number is
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pin->count = s_count;
+        __threadfence_system();
+        __hip_atomic_store(&pin->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ void k_roi_rearm(unsigned* keys) {
     keys[0] = 0xffffffffu; keys[1] = 0xffffffffu; keys[2] = 0u; keys[3] = 0u; keys[4] = 0u;
 }
@@ -1095,6 +1184,8 @@ struct isx_warper {
     DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
     DevBuf scan_blk;         // the synchronous scan's per-block extrema (k_roi_scan -> k_roi_candidates)
     void* pin = nullptr;     // pinned host landing zone of detectResultRoi's {keys, count, first candidates}
+    RoiPin* pin2 = nullptr;  // pinned block the border scan writes its answer into (k_roi_border_pin); pin_seq: the call number it publishes
+    int pin_seq = 0;
     // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
     // queued scans behind the main stream's position AT THAT CALL (e.g. after the last warp of a step, so
     // that they run under the memory-bound pyramid kernels instead of under the next tile's warp)
@@ -1126,6 +1217,7 @@ namespace {
 
 constexpr int CAND_CAP = 1 << 16;
 constexpr int CAND_FIRST = 1024;   // candidates that travel with the count in the one copy of detectResultRoi
+static_assert(CAND_FIRST == PIN_CAND, "k_roi_border_pin's pinned block holds CAND_FIRST candidates");
 
 int set_camera(isx_warper* w, const float K[9], const float R[9]) {
     ISX_CHECK_ARG(K != nullptr && R != nullptr, ISX_ERR_INVALID, "setCameraParams: K and R must be 3x3 CV_32F (got null)");  // W:94-95
@@ -1243,10 +1335,59 @@ int roi_stream_of(isx_warper* w, hipStream_t* out) {
         static hipStream_t shared[64] = {};
         std::lock_guard<std::mutex> lk(mu);
         const int d = w->device >= 0 && w->device < 64 ? w->device : 0;
-        if (!shared[d]) ISX_HIP(hipStreamCreateWithFlags(&shared[d], hipStreamNonBlocking));
+        if (!shared[d]) ISX_HIP(hipStreamCreateWithFlags(&shared[d], hipStreamNonBlocking));      // (a high-priority stream changes nothing here: a resident wave is not preempted; measured 40 us per call beside a saturating kernel either way)
         w->roi_stream = shared[d];
     }
     *out = w->roi_stream;
+    return ISX_OK;
+}
+
+// The synchronous border scan (k_roi_border_pin) on the ROI stream, its candidates in w->host_cand when this returns: one launch, then the
+// caller's thread polls the sequence number the kernel publishes in pinned memory (ISX_ROI_POLL=0: the round-3 form - kernel, copy, re-arm
+// kernel, hipStreamSynchronize - for A/B runs).
+int border_scan_sync(isx_warper* w, int sw, int sh, hipStream_t st, const char* label, int* n_out) {
+    static const bool poll = [] { const char* e = getenv("ISX_ROI_POLL"); return !(e && e[0] == '0'); }();
+    unsigned* keys = (unsigned*)w->scan.p;
+    int* count = (int*)(keys + 4);
+    int* cand = (int*)((char*)w->scan.p + 64);
+    int n = 0;
+    const int* first = nullptr;
+    if (poll) {
+        if (!w->pin2) {
+            ISX_HIP(hipHostMalloc((void**)&w->pin2, sizeof(RoiPin), hipHostMallocCoherent | hipHostMallocMapped));
+            memset(w->pin2, 0, sizeof(RoiPin));
+        }
+        const int seq = ++w->pin_seq;
+        ISX_LAUNCH(label, 0.0, st, k_roi_border_pin, dim3(1), dim3(1024), 0, w->proj, sw, sh, w->pin2, seq, cand, CAND_CAP);
+        (void)hipStreamQuery(st);           // the dispatch is on its way before the polling starts
+        const auto t0 = std::chrono::steady_clock::now();
+        bool synced = false;
+        while (__atomic_load_n(&w->pin2->seq, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if (!synced && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {   // a busy GPU: wait the ordinary way (and report its errors)
+                ISX_HIP(hipStreamSynchronize(st));
+                synced = true;
+                ISX_CHECK_ARG(__atomic_load_n(&w->pin2->seq, __ATOMIC_ACQUIRE) == seq, ISX_ERR_HIP, "detectResultRoi: the border scan finished without publishing its result");
+            }
+        }
+        n = w->pin2->count;
+        first = w->pin2->cand;
+    } else {
+        ISX_LAUNCH(label, 0.0, st, k_roi_border_sph, dim3(1), dim3(1024), 0, w->proj, sw, sh, (unsigned*)nullptr, cand, CAND_CAP, count);
+        if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
+        ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
+        ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
+        ISX_HIP(hipStreamSynchronize(st));
+        n = ((const int*)w->pin)[4];
+        first = (const int*)((const char*)w->pin + 64);
+    }
+    ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
+    ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the border of the %d x %d source (bad K / R / scale?)", sw, sh);
+    w->host_cand.resize((size_t)n * 2);
+    std::memcpy(w->host_cand.data(), first, (size_t)std::min(n, CAND_FIRST) * 8);
+    if (n > CAND_FIRST)     // rare: more candidates than the pinned block carries
+        ISX_HIP(hipMemcpy(w->host_cand.data() + 2 * (size_t)CAND_FIRST, cand + 2 * (size_t)CAND_FIRST, (size_t)(n - CAND_FIRST) * 8, hipMemcpyDeviceToHost));
+    *n_out = n;
     return ISX_OK;
 }
 
@@ -1272,18 +1413,8 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         // detectResultRoiByBorder: the border pixels ranked on the device, the candidates for the four extrema evaluated here with the
         // host's libm (exactly the values the host-only scan of round 2 took its minima / maxima over), then OpenCV's two pole tests
         ISX_TRY(roi_stream_of(w, &st));
-        ISX_LAUNCH("roi_border_sph", 0.0, st, k_roi_border_sph, dim3(1), dim3(1024), 0, w->proj, sw, sh, (unsigned*)nullptr, cand, CAND_CAP, count);
-        if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
-        ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
-        ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
-        ISX_HIP(hipStreamSynchronize(st));
-        const int n = ((const int*)w->pin)[4];
-        ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
-        ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the border of the %d x %d source (bad K / R / scale?)", sw, sh);
-        w->host_cand.resize((size_t)n * 2);
-        std::memcpy(w->host_cand.data(), (const char*)w->pin + 64, (size_t)std::min(n, CAND_FIRST) * 8);
-        if (n > CAND_FIRST)
-            ISX_HIP(hipMemcpy(w->host_cand.data() + 2 * (size_t)CAND_FIRST, cand + 2 * (size_t)CAND_FIRST, (size_t)(n - CAND_FIRST) * 8, hipMemcpyDeviceToHost));
+        int n = 0;
+        ISX_TRY(border_scan_sync(w, sw, sh, st, "roi_border_sph", &n));
         float tl_u = std::numeric_limits<float>::max(), tl_v = tl_u, br_u = -tl_u, br_v = -tl_u, u, v;
         for (int i = 0; i < n; ++i) {
             map_forward_host(w->proj, (float)w->host_cand[2 * i], (float)w->host_cand[2 * i + 1], u, v);
@@ -1335,8 +1466,9 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     const bool border_only = !full_always && cyl_extrema_on_border(w->proj, w->k, w->rinv, sw, sh);
     dim3 grid(cdiv(sw, 256), cdiv(sh, SYNC_ROWS));
     float4* blk = nullptr;
+    int n = 0;
     if (border_only) {
-        ISX_LAUNCH("roi_border", 0.0, st, k_roi_border_sph, dim3(1), dim3(1024), 0, w->proj, sw, sh, (unsigned*)nullptr, cand, CAND_CAP, count);
+        ISX_TRY(border_scan_sync(w, sw, sh, st, "roi_border", &n));
     } else {
     ISX_TRY(w->scan_blk.reserve((size_t)grid.x * grid.y * sizeof(float4)));
     blk = (float4*)w->scan_blk.p;
@@ -1349,18 +1481,18 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     static_assert(SYNC_ROWS % CAND_ROWS == 0, "a candidate block lies inside one scan block");
     ISX_LAUNCH("roi_candidates", 0.0, st, k_roi_candidates, dim3(grid.x, cdiv(sh, CAND_ROWS)), dim3(256), 0, w->proj, sw, sh, cand, CAND_CAP, count, CAND_ROWS,
                (const float4*)blk, SYNC_ROWS, (int)grid.y);
-    }
     if (!w->pin) ISX_HIP(hipHostMalloc(&w->pin, 64 + (size_t)CAND_FIRST * 8, hipHostMallocDefault));
     ISX_HIP(hipMemcpyAsync(w->pin, w->scan.p, 64 + (size_t)CAND_FIRST * 8, hipMemcpyDeviceToHost, st));
     ISX_LAUNCH("roi_rearm", 0.0, st, k_roi_rearm, dim3(1), dim3(1), 0, keys);
     ISX_HIP(hipStreamSynchronize(st));
-    const int n = ((const int*)w->pin)[4];
+    n = ((const int*)w->pin)[4];
     ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
     ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the %d x %d source (bad K / R / scale?)", sw, sh);
     w->host_cand.resize((size_t)n * 2);
     std::memcpy(w->host_cand.data(), (const char*)w->pin + 64, (size_t)std::min(n, CAND_FIRST) * 8);
     if (n > CAND_FIRST)   // rare: more candidates than the first copy carried
         ISX_HIP(hipMemcpy(w->host_cand.data() + 2 * (size_t)CAND_FIRST, cand + 2 * (size_t)CAND_FIRST, (size_t)(n - CAND_FIRST) * 8, hipMemcpyDeviceToHost));
+    }
     float tl_uf = std::numeric_limits<float>::max(), tl_vf = tl_uf, br_uf = -tl_uf, br_vf = -tl_uf;     // W:66-69
     for (int i = 0; i < n; ++i) {
         float u, v;
@@ -1482,7 +1614,11 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         // row length is not a multiple of 4 bytes takes the per-pixel store path)
         const isx_mat& dd = w->st_dst.d;
         const isx_mat& dm = w->st_dmask.d;
-        const bool vec = ((uintptr_t)dd.data % 4 == 0) && (dd.step % 4 == 0) && ((uintptr_t)dm.data % 4 == 0) && (dm.step % 4 == 0);
+        // k_warp_tile stores 12-byte runs at any alignment (a dense cv::Mat row need not start on a dword); the caller-mask kernel keeps its
+        // dword stores for aligned rows.  ISX_WARP_VEC=0: per-pixel stores (A/B runs)
+        static const bool vec_any = [] { const char* e = getenv("ISX_WARP_VEC"); return !(e && e[0] == '0'); }();
+        const bool vec_al = ((uintptr_t)dd.data % 4 == 0) && (dd.step % 4 == 0) && ((uintptr_t)dm.data % 4 == 0) && (dm.step % 4 == 0);
+        const bool vec = src_mask ? vec_al : vec_any;
         ISX_CHECK_ARG(dd.step < (1u << 24) && dm.step < (1u << 24) && (unsigned long long)dd.step * dh < (1ull << 32), ISX_ERR_UNSUPPORTED,
                       "warp_with_mask: destination larger than 4 GiB or 16 MiB per row");
         dim3 grid4(cdiv(dw, 256), cdiv(dh, 4));
@@ -1537,7 +1673,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         const bool small = (unsigned long long)w->st_src.d.step * src->rows < (1ull << 31) && w->st_src.d.step < (1u << 24) && src->cols <= 32767 && src->rows <= 32767 &&
                            ds < (1u << 24) && (unsigned long long)ds * dh < (1ull << 32);
         if (tile_path && small && src->type == ISX_8UC3 && interp == ISX_INTER_LINEAR && border == ISX_BORDER_REFLECT) {
-            const bool vec = ((uintptr_t)dp % 4 == 0) && (ds % 4 == 0);
+            static const bool vec = [] { const char* e = getenv("ISX_WARP_VEC"); return !(e && e[0] == '0'); }();
             const dim3 gridt(cdiv(dw, 64), cdiv(dh, 4 * WARP_WAVES));
             const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0}};
 #define ISX_WARP_IMG(KD, V) ISX_LAUNCH("warp_tile_img", bytes, st, (k_warp_tile<KD, false, V, false>), gridt, dim3(64 * WARP_WAVES), 0, wta)
@@ -1545,7 +1681,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             else { if (vec) ISX_WARP_IMG(ISX_WARP_SPHERICAL, true); else ISX_WARP_IMG(ISX_WARP_SPHERICAL, false); }
 #undef ISX_WARP_IMG
         } else if (tile_path && small && src->type == ISX_8UC1 && interp == ISX_INTER_NEAREST && border == ISX_BORDER_CONSTANT) {
-            const bool vec = ((uintptr_t)dp % 4 == 0) && (ds % 4 == 0);
+            static const bool vec = [] { const char* e = getenv("ISX_WARP_VEC"); return !(e && e[0] == '0'); }();
             const WarpMaskArgs wma{w->proj, t, sv, dp, (unsigned)ds, dw, dh};
             const dim3 gridm(cdiv(dw, 64), cdiv(dh, 16));
 #define ISX_WARP_MSK(KD, V) ISX_LAUNCH("warp_tile_mask", bytes, st, (k_warp_mask_tile<KD, V>), gridm, dim3(256), 0, wma)
@@ -1592,6 +1728,7 @@ int isx_warper_destroy(isx_warper* w) {
     (void)hipStreamSynchronize(w->stream);
     if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipEventDestroy(w->ev_warp); (void)hipEventDestroy(w->ev_scan); }   // the side stream is shared per device
     if (w->pin) (void)hipHostFree(w->pin);
+    if (w->pin2) (void)hipHostFree(w->pin2);
     delete w;
     return ISX_OK;
 }

@@ -72,7 +72,7 @@ class PairStitcher:
     tensors).  At most 20 tiles stay on the deferred blender cycle (isx_blender_set_deferred_level0)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
-                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1, window=None):
+                 device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1, window=None, tile_type="u8"):
         """window = (x0, x1): this object produces only the columns [x0, x1) of the mosaic (x0 a multiple of _lib.WINDOW_GRANULE,
         counted from the mosaic's left edge) - one strip of a panorama cut across GPUs (mosaic.strip_windows).  It then warps and
         feeds only the tiles that can reach those columns (self.active; `imgs` may hold None for the others), prepare() still gets
@@ -81,6 +81,9 @@ class PairStitcher:
         self.torch = torch
         self.imgs, self.K, self.Rs = imgs, K, Rs
         self.device = device
+        # tile_type "s16": the warped tiles are CV_16SC3 - the warp writes them so (the convertTo(CV_16S) of W:294 folded into its store) and
+        # feed() receives what the reference's feed() receives (W:302); "u8": CV_8UC3 tiles through feed_u8 (the conversion fused into feed)
+        self.tile_type = tile_type
         creator = CylindricalWarper if kind == "cylindrical" else SphericalWarper
         self.warper = creator(device, stream).create(scale)
         self.warper.set_deferred_verify(True)   # both ROI scans start after the last warp of a step (see step())
@@ -113,7 +116,13 @@ class PairStitcher:
             pitch = (row_bytes + 63) // 64 * 64
             return torch.empty((h * pitch,), dtype=torch.uint8, device=dev).as_strided(shape, (pitch,) + strides)
         act = set(self.active)
-        self.warped = [pitched(h, w * 3, (h, w, 3), (3, 1)) if i in act else None for i, (w, h) in enumerate(self.sizes)]
+        if tile_type == "s16":
+            def pitched16(h, w):
+                pitch = (w * 6 + 63) // 64 * 64
+                return torch.empty((h * pitch // 2,), dtype=torch.int16, device=dev).as_strided((h, w, 3), (pitch // 2, 3, 1))
+            self.warped = [pitched16(h, w) if i in act else None for i, (w, h) in enumerate(self.sizes)]
+        else:
+            self.warped = [pitched(h, w * 3, (h, w, 3), (3, 1)) if i in act else None for i, (w, h) in enumerate(self.sizes)]
         self.wmasks = [pitched(h, w, (h, w), (1,)) if i in act else None for i, (w, h) in enumerate(self.sizes)]
         for i in self.active:
             self.warper.warp_with_mask(imgs[i], K, Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
@@ -148,6 +157,12 @@ class PairStitcher:
         self.out = torch.empty((fh * opitch // es,), dtype=odt, device=dev).as_strided((fh, fw, 3), (opitch // es, 3, 1))
         self.out_mask = pitched(fh, fw, (fh, fw), (1,))
 
+    def _feed(self, i, corner):
+        if self.tile_type == "s16":
+            self.blender.feed(self.warped[i], self.seam[i], corner)
+        else:
+            self.blender.feed_u8(self.warped[i], self.seam[i], corner)
+
     def step(self):
         """Steady-state step without host round trips: the ROI scan (detectResultRoi) still runs on the
         GPU for every warp and is compared ON THE DEVICE with the ROI planned in __init__; a mismatch
@@ -156,7 +171,7 @@ class PairStitcher:
             self.blender.prepare(self.corners, self.sizes)
             for i in self.active:
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
-                self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+                self._feed(i, self.corners[i])
         else:
             for i in self.active:
                 if self.tile_cols is not None:
@@ -168,7 +183,7 @@ class PairStitcher:
                 self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
             for i in self.active:
-                self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+                self._feed(i, self.corners[i])
         self.blender.blend(self.out, self.out_mask)
         if self.mark is not None and not self.interleave:
             self.warper.verify_after(self.mark)   # blend() recorded the mark behind its level-`verify_at` pyrDown
@@ -186,7 +201,7 @@ class PairStitcher:
             self.warper.verify()
         self.blender.prepare(self.corners, self.sizes)
         for i in self.active:
-            self.blender.feed_u8(self.warped[i], self.seam[i], self.corners[i])
+            self._feed(i, self.corners[i])
 
     @staticmethod
     def step_batch(stitchers):
@@ -280,7 +295,7 @@ class PairStitcher:
             self.warper.set_dst_columns(0, 0)
         self.blender.prepare(cs, self.sizes)
         for i in self.active:
-            self.blender.feed_u8(self.warped[i], self.seam[i], cs[i])
+            self._feed(i, cs[i])
         self.blender.blend(self.out, self.out_mask)
         return self.out, self.out_mask
 
@@ -293,24 +308,31 @@ class PairStitcher:
         from . import _lib as L
         from .blender import convert_to
         torch = self.torch
+        if self.tile_type != "u8":
+            raise ValueError("step_literal: the reference warps CV_8UC3 tiles (construct with tile_type='u8')")
         if not hasattr(self, "src_masks"):
+            # every mat as Mat::create makes it: continuous, rows back to back (a 3425-pixel CV_8UC3 row starts on an odd byte)
             self.src_masks = [None if im is None else torch.full(im.shape[:2], 255, dtype=torch.uint8, device=im.device) for im in self.imgs]   # W:213-214
+            self.lit_warped = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.uint8, device=wi.device) for wi in self.warped]
+            self.lit_wmasks = [None if wm is None else torch.empty(tuple(wm.shape), dtype=torch.uint8, device=wm.device) for wm in self.wmasks]
             self.warped16 = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.int16, device=wi.device) for wi in self.warped]
+            self.lit_out = torch.empty(tuple(self.out.shape), dtype=self.out.dtype, device=self.out.device)
+            self.lit_out_mask = torch.empty(tuple(self.out_mask.shape), dtype=torch.uint8, device=self.out.device)
         cs = list(self.corners)
         for i in self.active:
             im = self.imgs[i]
             size = (im.shape[1], im.shape[0])
             roi = self.warper.warpRoi(size, self.K, self.Rs[i])                                                                      # W:126 inside W:229
-            self.warper.warp_roi(im, self.K, self.Rs[i], L.INTER_LINEAR, L.BORDER_REFLECT, roi, self.warped[i])
+            self.warper.warp_roi(im, self.K, self.Rs[i], L.INTER_LINEAR, L.BORDER_REFLECT, roi, self.lit_warped[i])
             roi = self.warper.warpRoi(size, self.K, self.Rs[i])                                                                      # W:126 inside W:232
-            self.warper.warp_roi(self.src_masks[i], self.K, self.Rs[i], L.INTER_NEAREST, L.BORDER_CONSTANT, roi, self.wmasks[i])
+            self.warper.warp_roi(self.src_masks[i], self.K, self.Rs[i], L.INTER_NEAREST, L.BORDER_CONSTANT, roi, self.lit_wmasks[i])
             cs[i] = (roi[0], roi[1])
-            convert_to(self.warped[i], np.int16, dst=self.warped16[i], device=self.device, stream=self.blender._stream_obj)            # W:294
+            convert_to(self.lit_warped[i], np.int16, dst=self.warped16[i], device=self.device, stream=self.blender._stream_obj)        # W:294
         self.blender.prepare(cs, self.sizes)                                                                                         # W:281
         for i in self.active:
             self.blender.feed(self.warped16[i], self.seam[i], cs[i])                                                                 # W:302
-        self.blender.blend(self.out, self.out_mask)                                                                                  # W:313
-        return self.out, self.out_mask
+        self.blender.blend(self.lit_out, self.lit_out_mask)                                                                          # W:313
+        return self.lit_out, self.lit_out_mask
 
     def bytes_model(self):
         src_px = [self.imgs[i].shape[0] * self.imgs[i].shape[1] for i in self.active]
