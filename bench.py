@@ -34,7 +34,7 @@ def measured_traffic(kernel, args, live=True):
     """HBM (fabric) bytes per launch of `kernel` from rocprofv3's PMC counters, (2 x FETCH_SIZE + WRITE_SIZE) KiB with FETCH and WRITE in
     separate passes (tools/measure_traffic.py; the factor 2 is calibrated for the kernels' access shapes, profiles/round2_fetch_calib.txt).
     live: collected NOW, by two short child runs of this command under `rocprofv3 --kernel-trace --pmc X` (about 30 s); when rocprofv3 is
-    missing or a pass fails, the committed measurement of the same command (profiles/round3_traffic.json) is returned instead.
+    missing or a pass fails, the committed measurement of the same command (profiles/round4_traffic.json) is returned instead.
     Returns (bytes or None, source)."""
     import shutil
     import subprocess
@@ -55,11 +55,11 @@ def measured_traffic(kernel, args, live=True):
         except Exception:
             pass
     try:
-        path = os.path.join(ROOT, "profiles", "round3_traffic.json")
+        path = os.path.join(ROOT, "profiles", "round4_traffic.json")
         d = json.load(open(path))
         if d.get("bench_args", []) != [] or args.precision != "f32" or args.bands != 5 or args.tiles != 2 or args.width != 3840 or args.kind != "cylindrical" or args.tile_type != "u8":
             return None, "no PMC measurement of this command"
-        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round3_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
+        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round4_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
                                                       "rocprofv3 was not usable in this run)")
     except Exception:
         return None, "no PMC measurement of this command"
@@ -111,14 +111,18 @@ def cpu_baseline(width, height, focal, bands, precision, kind="cylindrical", til
     one = cpu_pair_seconds(width, height, focal, bands, precision, kind, tiles, yaw)
     px = float(tiles) * width * height
     rate1 = px / (one[0] + one[1]) / 1e6
-    cores = os.cpu_count() or 1
+    # all host cores.  One single-threaded worker per PHYSICAL core (a second hardware thread of a core adds little to this
+    # memory- and FPU-bound code and doubles the memory the legs hold at once), bounded by memory; both counts are stated in the line.
+    logical = os.cpu_count() or 1
+    cores = logical
     try:
         import psutil
+        physical = psutil.cpu_count(logical=False) or logical
         per_worker = 0.5e9 * tiles * (width * height) / (3840.0 * 2160.0) + 0.2e9
-        cores = int(max(1, min(cores, psutil.virtual_memory().available * 0.25 // per_worker)))
+        cores = int(max(1, min(physical, psutil.virtual_memory().available * 0.5 // per_worker)))
     except Exception:
+        physical = None
         cores = min(cores, 8)
-    cores = min(cores, 64)
     out = {"value": round(rate1, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
            "sample": "1 mosaic of %d %dx%d tiles (oracle/oracle.c, %s, warp %.2fs + blend %.2fs)" % (tiles, width, height, flags, one[0], one[1])}
     if cores > 1:
@@ -139,6 +143,7 @@ def cpu_baseline(width, height, focal, bands, precision, kind="cylindrical", til
                    "sample": "%d concurrent worker processes, one mosaic of %d %dx%d tiles each (oracle/oracle.c: single-threaded C, %s, "
                              "no FMA contraction); one worker alone: warp %.2fs + blend %.2fs" % (cores, tiles, width, height, flags, one[0], one[1])}
     out["host"] = host_cpu()
+    out["host"]["physical_cores"] = physical
     return out
 
 
@@ -727,8 +732,6 @@ def main():
             tr, unmeasured = 0.0, []
             for name, v in ent_step.items():
                 per = allk.get(name) or allk.get("k_" + name)
-                if per is None and name == "warp_img_mask":
-                    per = allk.get("warp_img_mask")
                 if per is not None:
                     tr += per * v["launches"] / max(len(pairs), 1)
                 else:       # no counter figure under this launch name: its algorithmic bytes stand in, and the line says so
@@ -751,7 +754,9 @@ def main():
                 "tiles_per_mosaic": NT,
                 **({"shard": "strips", "strip": "%d/%d" % (strip_rank, strip_world), "window": list(window), "panorama_cols": fw_all,
                     "tiles_this_rank": pairs[0].active} if strips else {}),
-                "pairs_per_gpu": args.pairs, "tile_type": args.tile_type, "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "pairs_per_gpu": args.pairs, "tile_type": args.tile_type,
+                # which side of the fast kernels' limits this run was on (isx_blender_last_path): deferred | eager cycle, the kernel of the last collapse step
+                "path": pairs[0].blender.last_path(), "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
             # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them
@@ -765,6 +770,10 @@ def main():
         if split:
             dt_c, dt_g, nsend = split
             out["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),
+                                # the N = 1 reference of THIS workload (config 4's per-GPU share: --pairs P on min(P, 4) streams, u8 mosaics, no gather) - the default N = 1
+                                # line is config 2 (one pair per step, CV_16SC3 result), so a ratio against it would mix two workloads: this is one
+                                # rank's share of the no-gather leg above (the slowest rank's time, divided by the world size)
+                                "n1_same_workload_Mpix_s": round(mpix_step * args.steps / dt_c / world, 1),
                                 "gather_alone_ms": round(dt_g / args.steps * 1e3, 4), "send_bytes_per_rank": nsend,
                                 # bytes every rank RECEIVES from its peers / gather time; with one rank nothing crosses a link: the local copy's rate instead
                                 **({"gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1)} if world > 1 else

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--blend", default="feather", choices=["feather", "multiband"])
     ap.add_argument("--gains", type=float, nargs=2, default=[1.0, 1.0])
     ap.add_argument("--out", default="pano.bmp")
+    ap.add_argument("--separate", action="store_true",
+                    help="gain apply and mask preparation as passes of their own (isx_gain_apply, isx_mask_dilate_and) instead of folded into the warp's "
+                         "store (isx_warper_set_gain) and into the feed (isx_blender_feed_dilated): same panorama, two passes per tile more")
     a = ap.parse_args()
     if a.images:
         imgs = [isx.imread(p) for p in a.images[:2]]                       # W:166
@@ -40,8 +43,12 @@ def main():
     warper = isx.CylindricalWarper().create(F)                              # W:217-222
     corners, warped, wmasks = [], [], []
     for i in range(2):
-        c, wi, wm = warper.warp_with_mask(imgs[i], K, Rs[i])               # W:229, W:232
-        isx.gain_apply(wi, a.gains[i])                                      # W:241-244
+        if a.separate:
+            c, wi, wm = warper.warp_with_mask(imgs[i], K, Rs[i])           # W:229, W:232
+            isx.gain_apply(wi, a.gains[i])                                  # W:241-244
+        else:                                                               # W:241-244 folded into the warp's store (gains known: a fixed rig)
+            warper.set_gain(a.gains[i])
+            c, wi, wm = warper.warp_with_mask(imgs[i], K, Rs[i])           # W:229, W:232
         corners.append(tuple(c)); warped.append(wi); wmasks.append(wm)
     seam = [m.copy() for m in wmasks]                                       # W:247-249
     isx.DpSeamFinder().find([w.astype(np.float32) for w in warped], corners, seam)   # W:259-262
@@ -52,8 +59,11 @@ def main():
         blender = isx.MultiBandBlender(False, 4, isx.PREC_I16)              # W:271-273
     blender.prepare(corners, sizes)                                         # W:281
     for i in range(2):
-        mk = isx.dilate_and(seam[i], 20, 20, other=wmasks[i])               # W:295-301
-        blender.feed(warped[i].astype(np.int16), mk, corners[i])            # W:294, W:302
+        if a.separate:
+            mk = isx.dilate_and(seam[i], 20, 20, other=wmasks[i])           # W:295-301
+            blender.feed(warped[i].astype(np.int16), mk, corners[i])        # W:294, W:302
+        else:                                                               # W:294-302 in one call
+            blender.feed_dilated(warped[i].astype(np.int16), seam[i], wmasks[i], 20, 20, corners[i])
     result, result_mask = blender.blend(out_u8=True)                        # W:313 + the convertTo(CV_8U) of imwrite
     isx.imwrite(a.out, result)                                              # W:315
     print("corners", corners, "sizes", sizes, "->", a.out, result.shape, "covered %.1f %%" % (100.0 * (result_mask > 0).mean()))

@@ -62,6 +62,8 @@ _SIGS = {
     "isx_warper_set_deferred_verify": [C.c_void_p, C.c_int],
     "isx_remap": [_MP, _MP, _MP, C.c_int, C.c_int, _MP, C.c_int, C.c_void_p],
     "isx_warper_set_roi_cache": [C.c_void_p, C.c_int],
+    "isx_warper_set_gain": [C.c_void_p, C.c_double],
+    "isx_blender_feed_dilated": [C.c_void_p, _MP, _MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int],
     "isx_warper_verify": [C.c_void_p],
     "isx_warper_verify_is_light": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "isx_warper_verify_after": [C.c_void_p, C.c_void_p],
@@ -95,6 +97,7 @@ _SIGS = {
     "isx_blender_feed": [C.c_void_p, _MP, _MP, C.c_int, C.c_int],
     "isx_blender_feed_u8": [C.c_void_p, _MP, _MP, C.c_int, C.c_int],
     "isx_blender_result_size": [C.c_void_p, _IP, _IP],
+    "isx_blender_last_path": [C.c_void_p, _IP, _IP],
     "isx_blender_blend": [C.c_void_p, _MP, _MP],
     "isx_blender_blend_batch": [C.POINTER(C.c_void_p), C.c_int, _MP, _MP],
     "isx_blender_debug_level": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _IP, _IP],

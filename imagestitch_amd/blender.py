@@ -106,10 +106,23 @@ class MultiBandBlender:
         self._keep(img, mask)
         check(self._lib.isx_blender_feed_u8(self._h, C.byref(mi), C.byref(mm), int(tl[0]), int(tl[1])))
 
+    def feed_dilated(self, img, seam_mask, warped_mask, kw, kh, tl):
+        """W:286-302 in one call: feed(img, dilate(seam_mask, MORPH_RECT kw x kh) & warped_mask, tl) (isx_blender_feed_dilated)."""
+        mi, ms, mw = as_mat(img), as_mat(seam_mask), as_mat(warped_mask)
+        self._keep(img, None)
+        check(self._lib.isx_blender_feed_dilated(self._h, C.byref(mi), C.byref(ms), C.byref(mw), int(kw), int(kh), int(tl[0]), int(tl[1])))
+
     def result_size(self):
         w, h = C.c_int(), C.c_int()
         check(self._lib.isx_blender_result_size(self._h, C.byref(w), C.byref(h)))
         return w.value, h.value
+
+    def last_path(self):
+        """isx_blender_last_path: which kernels the last blend() ran - {"cycle": eager | deferred | deferred_batched, "last_step": none |
+        collapse | collapse_gather | collapse_roll}."""
+        c, k = C.c_int(), C.c_int()
+        check(self._lib.isx_blender_last_path(self._h, C.byref(c), C.byref(k)))
+        return {"cycle": ("eager", "deferred", "deferred_batched")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
 
     def level(self, i):
         """Accumulated destination pyramid level i (parity tests): (laplacian HxWx3, weight HxW)."""

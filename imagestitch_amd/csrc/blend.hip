@@ -1223,7 +1223,7 @@ template <int M, int SK>
 int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st) {
     static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
     if constexpr (SK == SK_U8 || SK == SK_S16) {
-        if (fast) { ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down0<M, SK>), grid, dim3(512), 0, ts); return ISX_OK; }
+        if (fast) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK>), grid, dim3(512), 0, ts); return ISX_OK; }
     }
     ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
     return ISX_OK;
@@ -1533,6 +1533,8 @@ struct isx_blender {
     DevBuf dst_arena, tile_arena;
     DevBuf out_arena;                    // I16, deferred cycle: the collapsed levels out_k as 16-byte register records
     MatStage st_img, st_mask, st_out, st_outmask;
+    MatStage st_other;                   // isx_blender_feed_dilated: the warped mask that is AND-ed in (W:299)
+    DevBuf dil_mask;                     // ... the dilated & AND-ed mask of an eager / Feather / NO feed (recorded tiles keep theirs per tile)
     std::vector<unsigned char> host_tmp;
     // level-0 rectangles (x, y, w, h in dst_roi_ coordinates) written by the feeds so far; `cleared`
     // means every level has been zero-filled outside them (only when > MAX_COVER tiles are fed)
@@ -1557,6 +1559,10 @@ struct isx_blender {
     hipEvent_t mark_event = nullptr;   // isx_blender_set_mark_event: recorded inside a deferred blend()
     int mark_level = 0;
     bool overlap = false;
+    // which code path the last blend() took (isx_blender_last_path): the fast kernels have limits, and a caller / a bench line should be
+    // able to say which side of them it ran on.  cycle: 0 eager, 1 deferred, 2 deferred as part of a batched chain; last: the kernel of
+    // the last collapse step - 0 none (a 0-band blend, Feather, NO), 1 k_collapse, 2 k_collapse_gather, 3 k_collapse_roll
+    int path_cycle = 0, path_last = 0;
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_ready, ev_done;
     std::vector<char> chain_on_side;   // per recorded tile: its chain was launched by feed()
@@ -1806,7 +1812,7 @@ int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& co
     o.bx0 = 0; o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx);
     o.band = band_mode ? cdiv(nby, 8) : 0;
     const unsigned nblk = o.band ? xcd_band_blocks(grp, nsx, nby) : xcd_grid_blocks(grp, nsx, nby);
-    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll<M, SK, R, MAXT>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
+    ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll<M, SK, R, MAXT>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
     *done = true;
     return ISX_OK;
 }
@@ -1835,6 +1841,7 @@ template <int M, int SK>
 int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     hipStream_t st = b->stream;
     const int L = b->num_bands, prec = M, n = (int)b->tiles.size();
+    b->path_cycle = 1; b->path_last = 0;
     LevelBuf* d = b->dst;
     // The collapsed levels out_k (k >= 1) only live between two steps of this chain.  The fp32 / fp16 destination levels
     // are float4 records already; for I16 (OpenCV's short4 + weight plane) they go to a private arena in the tile-level
@@ -1948,8 +1955,9 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             if (k != L) {
                 bool done = false;
                 ISX_TRY((launch_collapse_roll<M, SK>(b, st, ts, d[1], out, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, &done)));
-                if (done) continue;
+                if (done) { b->path_last = 3; continue; }
             }
+            b->path_last = 2;
             if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
             else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, false>), grid, dim3(256), 0, ts, d[1], d[0], o);
         } else {
@@ -1975,6 +1983,7 @@ int run_blend(isx_blender* b, const OutMat& out) {
     const int L = b->num_bands, prec = M;
     LevelBuf* d = b->dst;
     if (b->level0_pending) return run_blend_deferred<M>(b, out);
+    b->path_cycle = 0; b->path_last = L >= 1 ? 1 : 0;
     if (L == 0) {
         dim3 grid(cdiv(d[0].cols, 64), cdiv(d[0].rows, 4));
         double px = (double)d[0].rows * d[0].cols;
@@ -2029,6 +2038,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
         ISX_TRY(join_side_streams(b));
     }
     first[nb] = nt;
+    for (int m = 0; m < nb; ++m) { bs[m]->path_cycle = 2; bs[m]->path_last = 2; }
     auto base = [&](int k_fine) {
         TileSet ts;
         memset(&ts, 0, sizeof(ts));
@@ -2115,7 +2125,8 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
             }
             if constexpr (SK == SK_U8 || SK == SK_S16) {
                 if (ok) {
-                    ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_roll_batch<M, SK, 2, 2>), dim3(nblk, 1, nb), dim3(64 * ROLL_WAVES), 0, ts, bo, 0);
+                    ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll_batch<M, SK, 2, 2>), dim3(nblk, 1, nb), dim3(64 * ROLL_WAVES), 0, ts, bo, 0);
+                    for (int m = 0; m < nb; ++m) bs[m]->path_last = 3;
                     continue;
                 }
             }
@@ -2253,7 +2264,25 @@ int private_copy(isx_mat& d, DevBuf& buf, hipStream_t st) {
     return ISX_OK;
 }
 
-int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
+// isx_blender_feed_dilated (W:286-301 fused into the feed): mask = dilate(seam_mask, MORPH_RECT kw x kh) & warped_mask, written straight
+// into a buffer the blender owns - `dst` - so that no mask travels through the caller and, for a recorded tile, the private copy of
+// the mask (OpenCV's feed contract) IS the dilation's output: one pass over the mask less.  On return st_mask.d describes that buffer.
+struct DilateSpec { const isx_mat* other; int kw, kh; };
+int stage_dilated_mask(isx_blender* b, MatStage& st_mask, const isx_mat* seam, const DilateSpec& ds, DevBuf& dst, hipStream_t st) {
+    ISX_TRY(check_mat(ds.other, "feed_dilated: warped mask"));
+    ISX_CHECK_ARG(ds.other->type == ISX_8UC1 && ds.other->rows == seam->rows && ds.other->cols == seam->cols, ISX_ERR_SIZE,
+                  "feed_dilated: the warped mask must be a CV_8U mask of the seam mask's size");
+    ISX_TRY(st_mask.use_in(seam, st, "feed_dilated: seam mask"));
+    ISX_TRY(b->st_other.use_in(ds.other, st, "feed_dilated: warped mask"));
+    const size_t pitch = ((size_t)seam->cols + 63) & ~(size_t)63;
+    ISX_TRY(dst.reserve(pitch * (size_t)seam->rows + 64));
+    ISX_TRY(dilate_and_device((const unsigned char*)st_mask.d.data, st_mask.d.step, (const unsigned char*)b->st_other.d.data, b->st_other.d.step, seam->rows, seam->cols,
+                              ds.kw, ds.kh, (unsigned char*)dst.p, pitch, st));
+    st_mask.d.data = dst.p; st_mask.d.step = pitch; st_mask.d.device = b->device;
+    return ISX_OK;
+}
+
+int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry, const DilateSpec* dil = nullptr) {
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released the accumulators)");
     ISX_TRY(check_mat(img, "feed: img"));
     ISX_TRY(check_mat(mask, "feed: mask"));
@@ -2281,7 +2310,8 @@ int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int
     MatStage& st_img = can_defer ? *b->tile_img[slot] : b->st_img;
     DevBuf& wbuf = can_defer ? *b->tile_arenas[slot] : b->feather_w;
     ISX_TRY(st_img.use_in(img, st, "feed: img"));
-    ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
+    if (dil) ISX_TRY(stage_dilated_mask(b, b->st_mask, mask, *dil, b->dil_mask, st));
+    else ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
     if (can_defer && b->deferred_copy && img->device >= 0) {   // the mask is consumed here (weight map); the image is read by blend()
         if (b->tile_copy_img.size() <= slot) { b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf()); }
         ISX_TRY(private_copy(st_img.d, *b->tile_copy_img[slot], st));
@@ -2306,7 +2336,7 @@ int do_feed_feather(isx_blender* b, const isx_mat* img, const isx_mat* mask, int
 }
 
 // Blender::feed of the base class (Blender::NO): a masked copy into dst_, dst_mask_ |= mask
-int do_feed_no(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
+int do_feed_no(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry, const DilateSpec* dil = nullptr) {
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released dst_)");
     ISX_TRY(check_mat(img, "feed: img"));
     ISX_TRY(check_mat(mask, "feed: mask"));
@@ -2321,7 +2351,8 @@ int do_feed_no(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x
     ISX_HIP(hipSetDevice(b->device));
     hipStream_t st = b->stream;
     ISX_TRY(b->st_img.use_in(img, st, "feed: img"));
-    ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
+    if (dil) ISX_TRY(stage_dilated_mask(b, b->st_mask, mask, *dil, b->dil_mask, st));
+    else ISX_TRY(b->st_mask.use_in(mask, st, "feed: mask"));
     const size_t n = (size_t)b->rw * b->rh, img_bytes = (n * 6 + 255) & ~(size_t)255;
     short* dst = (short*)b->dst_arena.p;
     unsigned char* dmask = (unsigned char*)b->dst_arena.p + img_bytes;
@@ -2334,10 +2365,10 @@ int do_feed_no(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x
     return ISX_OK;      // (the shared staging buffers are reused by the next feed on the same stream: ordered)
 }
 
-int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry) {
+int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y, bool u8_entry, const DilateSpec* dil = nullptr) {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "feed: null blender");
-    if (b->type == ISX_BLEND_FEATHER) return do_feed_feather(b, img, mask, tl_x, tl_y, u8_entry);
-    if (b->type == ISX_BLEND_NO) return do_feed_no(b, img, mask, tl_x, tl_y, u8_entry);
+    if (b->type == ISX_BLEND_FEATHER) return do_feed_feather(b, img, mask, tl_x, tl_y, u8_entry, dil);
+    if (b->type == ISX_BLEND_NO) return do_feed_no(b, img, mask, tl_x, tl_y, u8_entry, dil);
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "feed: null blender");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "feed: prepare() has not been called (or blend() already released the pyramids)");
     ISX_TRY(check_mat(img, "feed: img"));
@@ -2374,11 +2405,12 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     MatStage& st_mask = can_defer ? *b->tile_mask[slot] : b->st_mask;
     DevBuf& arena = can_defer ? *b->tile_arenas[slot] : b->tile_arena;
     ISX_TRY(st_img.use_in(img, b->stream, "feed: img"));
-    ISX_TRY(st_mask.use_in(mask, b->stream, "feed: mask"));
+    if (can_defer && b->tile_copy_img.size() <= slot) { b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf()); }
+    if (dil) ISX_TRY(stage_dilated_mask(b, st_mask, mask, *dil, can_defer ? *b->tile_copy_mask[slot] : b->dil_mask, b->stream));   // the blender's own copy already
+    else ISX_TRY(st_mask.use_in(mask, b->stream, "feed: mask"));
     if (can_defer && b->deferred_copy) {
-        if (b->tile_copy_img.size() <= slot) { b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf()); }
         if (img->device >= 0) ISX_TRY(private_copy(st_img.d, *b->tile_copy_img[slot], b->stream));
-        if (mask->device >= 0) ISX_TRY(private_copy(st_mask.d, *b->tile_copy_mask[slot], b->stream));
+        if (mask->device >= 0 && !dil) ISX_TRY(private_copy(st_mask.d, *b->tile_copy_mask[slot], b->stream));
     }
     const isx_mat& di = st_img.d;
     const isx_mat& dm = st_mask.d;
@@ -2599,6 +2631,23 @@ int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, in
 int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y) {
     clear_error();
     return do_feed(b, img, mask, tl_x, tl_y, true);
+}
+
+int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* seam_mask, const isx_mat* warped_mask, int kw, int kh, int tl_x, int tl_y) {
+    clear_error();
+    ISX_CHECK_ARG(b != nullptr && img != nullptr && seam_mask != nullptr && warped_mask != nullptr, ISX_ERR_INVALID, "feed_dilated: null argument");
+    ISX_TRY(check_mat(seam_mask, "feed_dilated: seam mask"));
+    ISX_CHECK_ARG(seam_mask->type == ISX_8UC1, ISX_ERR_TYPE, "feed_dilated: seam mask must be CV_8U, got %s", type_name(seam_mask->type));
+    ISX_CHECK_ARG(kw >= 1 && kh >= 1, ISX_ERR_INVALID, "feed_dilated: bad structuring element %d x %d", kw, kh);
+    const DilateSpec ds{warped_mask, kw, kh};
+    return do_feed(b, img, seam_mask, tl_x, tl_y, img->type == ISX_8UC3, &ds);
+}
+
+int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_last_path: null blender");
+    if (cycle) *cycle = b->type == ISX_BLEND_MULTI_BAND ? b->path_cycle : 0;
+    if (last_step) *last_step = b->type == ISX_BLEND_MULTI_BAND ? b->path_last : 0;
+    return ISX_OK;
 }
 
 int isx_blender_result_size(isx_blender* b, int* width, int* height) {

@@ -94,6 +94,10 @@ bool profiling_enabled();
             return ::isx::fail(ISX_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(le__)); \
     } while (0)
 
+// prep.hip: dilate(mask, MORPH_RECT kw x kh) [& other] between device buffers (one kernel, elements up to 33 a side)
+int dilate_and_device(const unsigned char* mask, size_t mstep, const unsigned char* other, size_t ostep, int rows, int cols, int kw, int kh,
+                      unsigned char* dst, size_t dstep, hipStream_t st);
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // blocks of a 1-D launch in the XCD-aware order of isx_device.hpp's xcd_block: gy rows in groups of grp, the groups dealt to 8 XCDs
 inline unsigned xcd_magic(int grp, int gx) { return 0xFFFFFFFFu / (unsigned)(grp * gx) + 1u; }

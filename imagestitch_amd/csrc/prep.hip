@@ -230,6 +230,18 @@ __global__ __launch_bounds__(256) void k_convert(const unsigned char* src, size_
 
 }  // namespace
 
+// dilate(mask, MORPH_RECT kw x kh) [& other] between DEVICE buffers with the one-kernel path (elements up to 33 a side): what
+// isx_mask_dilate_and launches, callable from the blender (isx_blender_feed_dilated writes the result straight into the mask it keeps)
+namespace isx {
+int dilate_and_device(const unsigned char* mask, size_t mstep, const unsigned char* other, size_t ostep, int rows, int cols, int kw, int kh,
+                      unsigned char* dst, size_t dstep, hipStream_t st) {
+    ISX_CHECK_ARG(kw >= 1 && kh >= 1 && kw <= DIL_MAXK && kh <= DIL_MAXK, ISX_ERR_UNSUPPORTED, "dilate: a %d x %d element exceeds the fused kernel's %d a side", kw, kh, DIL_MAXK);
+    ISX_LAUNCH("dilate_and", (double)rows * cols * (other ? 3.0 : 2.0), st, k_dilate_and, dim3(cdiv(cols, DIL_TW), cdiv(rows, DIL_TH)), dim3(DIL_NT), 0,
+               mask, mstep, rows, cols, kw, kh, other, other ? ostep : (size_t)0, dst, dstep);
+    return ISX_OK;
+}
+}  // namespace isx
+
 extern "C" {
 
 int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int kh, isx_mat* out, int device, void* hip_stream) {
@@ -252,9 +264,8 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
     ISX_TRY(sd.use_out(out, st, "dilate: out"));
     const int rows = mask->rows, cols = mask->cols;
     if (kw <= DIL_MAXK && kh <= DIL_MAXK) {
-        ISX_LAUNCH("dilate_and", (double)rows * cols * (other ? 3.0 : 2.0), st, k_dilate_and, dim3(cdiv(cols, DIL_TW), cdiv(rows, DIL_TH)), dim3(DIL_NT), 0,
-                   (const unsigned char*)sm.d.data, sm.d.step, rows, cols, kw, kh, other ? (const unsigned char*)so.d.data : nullptr, other ? so.d.step : 0,
-                   (unsigned char*)sd.d.data, sd.d.step);
+        ISX_TRY(dilate_and_device((const unsigned char*)sm.d.data, sm.d.step, other ? (const unsigned char*)so.d.data : nullptr, other ? so.d.step : 0, rows, cols, kw, kh,
+                                  (unsigned char*)sd.d.data, sd.d.step, st));
         ISX_TRY(sd.finish_out(st));
         if (mask->device < 0 || out->device < 0 || (other && other->device < 0)) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
         return ISX_OK;

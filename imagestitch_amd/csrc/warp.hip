@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -386,7 +387,7 @@ __device__ __forceinline__ int reflect_inline(int p, int n) {
 }
 
 template <bool OUT16>
-__device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t, const SrcView* img, const TileDst* d, int dx0, int row0, unsigned slow, int nrows) {
+__device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t, const SrcView* img, const TileDst* d, int dx0, int row0, unsigned slow, int nrows, const unsigned char* lut = nullptr) {
     const unsigned char* data = img->data;
     const size_t step = img->step;
     const int rows = img->rows, cols = img->cols;
@@ -410,7 +411,8 @@ __device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t,
         if (d->mask) d->mask[(size_t)dy * d->mask_step + dx] = ((unsigned)nx < (unsigned)cols && (unsigned)ny < (unsigned)rows) ? 255 : 0;
 #pragma unroll 1
         for (int c = 0; c < 3; ++c) {
-            const int v = sat_u8((r0[c0 + c] * w0 + r0[c1 + c] * w1 + r1[c0 + c] * w2 + r1[c1 + c] * w3 + (1 << 14)) >> 15);
+            int v = sat_u8((r0[c0 + c] * w0 + r0[c1 + c] * w1 + r1[c0 + c] * w2 + r1[c1 + c] * w3 + (1 << 14)) >> 15);
+            if (lut) v = lut[v];
             if constexpr (OUT16) ((short*)(d->img + (size_t)dy * d->img_step))[(size_t)dx * 3 + c] = (short)v;
             else (d->img + (size_t)dy * d->img_step)[(size_t)dx * 3 + c] = (unsigned char)v;
         }
@@ -422,7 +424,11 @@ __device__ __forceinline__ void warp_tile_fixup(const Proj* p, const MapTabs* t,
 // a DOT instruction and a VALU read of its result) and reads a stale register.
 __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
 
-struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; };
+// lut (GAIN kernels): GainCompensator::apply (W:241-244) folded into the warp's store - multiply(image, gain, image) on a CV_8U image is
+// saturate_cast<uchar>(cvRound((double)byte * gain)) per byte, a function of the byte alone: 256 entries computed on the host with the
+// arithmetic of isx_gain_apply (isx_warper_set_gain), applied to the remapped byte (NOT to the source: remap of scaled pixels differs)
+// The table travels in the kernel arguments (256 bytes): changing the gain between two tiles costs no upload and no synchronisation.
+struct WarpTileArgs { Proj p; MapTabs t; SrcView img; TileDst d; unsigned lut[64]; };
 typedef unsigned WV3 __attribute__((ext_vector_type(3), aligned(1)));      // a 12-byte run of a destination row, any alignment
 typedef unsigned WV1 __attribute__((aligned(1)));
 
@@ -468,9 +474,14 @@ __device__ __forceinline__ int reflect_once(int p, int n2m1) {
 #endif
 // MASK = false: the image alone - RotationWarper::warp(img, K, R, INTER_LINEAR, BORDER_REFLECT) as the reference calls it (W:229), the
 // mask being a call of its own (W:232, k_warp_mask_tile); d.mask is then null
-template <int KIND, bool OUT16, bool VEC, bool MASK = true>
+template <int KIND, bool OUT16, bool VEC, bool MASK = true, bool GAIN = false>
 __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu(WARP_WPE))) void k_warp_tile(WarpTileArgs a) {
     const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
+    __shared__ unsigned char s_lut[GAIN ? 256 : 4];
+    if constexpr (GAIN) {      // the 256-entry gain table, once per workgroup (before any thread leaves: everyone reaches the barrier)
+        if (threadIdx.x < 64) ((unsigned*)s_lut)[threadIdx.x] = ((const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr())->lut[threadIdx.x];
+        __syncthreads();
+    }
     // A wave is 64 pixels wide and 4 rows tall (16 lanes x 4 pixels per row), a block 64 x 16: the band of border pixels along the
     // left and right edge of the warped tile is a few dozen pixels wide, so with 256 x 1 waves every row's first and last wave crossed
     // it (tier 2); with 64 x 4 waves a quarter as many do.
@@ -623,6 +634,10 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
             px[k] = sample_windows(w0[k], w1[k], s0, s1, wA, 32u - wA, 32u - fy, fy);
         }
     }
+    if constexpr (GAIN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) px[k] = (unsigned)s_lut[px[k] & 255u] | ((unsigned)s_lut[(px[k] >> 8) & 255u] << 8) | ((unsigned)s_lut[(px[k] >> 16) & 255u] << 16);
+    }
     // ---- stores ------------------------------------------------------------------------------------------------------------
     if ((WARP_ABL & 1) && d.w > -3) { if (px[0] + px[1] + px[2] + px[3] + m4 == 0x12345u) d.mask[0] = 1; return; }
     if (whole) {
@@ -665,7 +680,7 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
     // window, the last columns of the buffer's last row): the whole 4-pixel row of the thread again, by the generic code path
     if (generic) {
         const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1);
+        warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1, GAIN ? (const unsigned char*)ka->lut : nullptr);
     }
 }
 
@@ -1184,6 +1199,8 @@ struct isx_warper {
     DevBuf scan_side;        // {keys[4], count, mismatches} used on the side stream only
     DevBuf scan_blk;         // the synchronous scan's per-block extrema (k_roi_scan -> k_roi_candidates)
     void* pin = nullptr;     // pinned host landing zone of detectResultRoi's {keys, count, first candidates}
+    double gain = 1.0;       // isx_warper_set_gain: folded into the fused tile warp's store (1.0 = off)
+    unsigned char gain_lut[256] = {};   // its 256-entry table (handed to the kernel in its arguments)
     RoiPin* pin2 = nullptr;  // pinned block the border scan writes its answer into (k_roi_border_pin); pin_seq: the call number it publishes
     int pin_seq = 0;
     // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
@@ -1630,7 +1647,8 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
 #define ISX_WARP_FUSED(O16, V)                                                                                                   \
         ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_img_mask<O16, V>), grid4, dim3(256), 0, w->proj, t, sv, mv, src_mask ? 1 : 0, \
                    (unsigned char*)dd.data, dd.step, (unsigned char*)dm.data, dm.step, dw, dh, plan_keys, plan4, plan_mism)
-        // the hot kernel: a tile whose mask is all 255 (W:213-214).  Same launch name: it is the same operation.
+        // the hot kernel: a tile whose mask is all 255 (W:213-214).  Launch names are the kernels' names without the k_ (they can be
+        // found in a rocprofv3 kernel trace as they are)
         // isx_warper_set_dst_columns: only the 64-column blocks that hold columns [col0, col1) of the warped tile are computed; the
         // kernel's right crop is the range's end, its left end the block boundary at or below col0
         int bx0 = 0, wcrop = dw;
@@ -1639,8 +1657,15 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             bytes *= (double)(cdiv(wcrop, 64) - bx0) / cdiv(dw, 64);
         }
         const dim3 gridt(cdiv(wcrop, 64) - bx0, cdiv(dh, 4 * WARP_WAVES));
-        const WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0}};
-#define ISX_WARP_TILE(KD, O16, V) ISX_LAUNCH("warp_img_mask", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(64 * WARP_WAVES), 0, wta)
+        const bool gained = w->gain != 1.0;
+        ISX_CHECK_ARG(!(gained && src_mask), ISX_ERR_UNSUPPORTED, "warp_with_mask: isx_warper_set_gain applies to tiles warped with the all-255 mask (src_mask == NULL)");
+        WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0}, {}};
+        if (gained) memcpy(wta.lut, w->gain_lut, 256);
+#define ISX_WARP_TILE(KD, O16, V)                                                                                                            \
+    do {                                                                                                                                     \
+        if (gained) ISX_LAUNCH("warp_tile", bytes, st, (k_warp_tile<KD, O16, V, true, true>), gridt, dim3(64 * WARP_WAVES), 0, wta);          \
+        else ISX_LAUNCH("warp_tile", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(64 * WARP_WAVES), 0, wta);                              \
+    } while (0)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
         if (!src_mask) {
             if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_TILE_K(true, true); else ISX_WARP_TILE_K(true, false); }
@@ -1675,7 +1700,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         if (tile_path && small && src->type == ISX_8UC3 && interp == ISX_INTER_LINEAR && border == ISX_BORDER_REFLECT) {
             static const bool vec = [] { const char* e = getenv("ISX_WARP_VEC"); return !(e && e[0] == '0'); }();
             const dim3 gridt(cdiv(dw, 64), cdiv(dh, 4 * WARP_WAVES));
-            const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0}};
+            const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0}, {}};
 #define ISX_WARP_IMG(KD, V) ISX_LAUNCH("warp_tile_img", bytes, st, (k_warp_tile<KD, false, V, false>), gridt, dim3(64 * WARP_WAVES), 0, wta)
             if (w->kind == ISX_WARP_CYLINDRICAL) { if (vec) ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, true); else ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, false); }
             else { if (vec) ISX_WARP_IMG(ISX_WARP_SPHERICAL, true); else ISX_WARP_IMG(ISX_WARP_SPHERICAL, false); }
@@ -1736,6 +1761,23 @@ int isx_warper_destroy(isx_warper* w) {
 int isx_warper_set_stream(isx_warper* w, void* hip_stream) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_stream: null warper");
     w->stream = (hipStream_t)hip_stream;
+    return ISX_OK;
+}
+
+int isx_warper_set_gain(isx_warper* w, double gain) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_gain: null warper");
+    if (gain == w->gain) return ISX_OK;
+    if (gain != 1.0) {
+        // saturate_cast<uchar>(cvRound((double)v * gain)) for every byte value, with isx_gain_apply's arithmetic (cvtsd2si: ties to even,
+        // NaN / overflow -> INT_MIN -> 0)
+        for (int v = 0; v < 256; ++v) {
+            const double t = std::nearbyint((double)v * gain);
+            const int iv = (t >= -2147483648.0 && t <= 2147483647.0) ? (int)t : INT_MIN;
+            w->gain_lut[v] = (unsigned char)((unsigned)iv <= 255u ? iv : (iv > 0 ? 255 : 0));
+        }
+    }
+    w->gain = gain;
     return ISX_OK;
 }
 

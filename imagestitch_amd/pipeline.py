@@ -345,3 +345,117 @@ class PairStitcher:
 
 
 MosaicStitcher = PairStitcher   # the same object under the name that fits n > 2 tiles (BASELINE config 5: a row of 8)
+
+
+class SplitStitcher:
+    """ONE mosaic computed as `nsplit` column strips on `nsplit` streams of one GPU, the strips' launch chains staggered: a step of one
+    mosaic is about a dozen dependent launches of which six (pyramid levels 2 and up) are latency-bound and leave the GPU nearly idle
+    (39 of 211 us at 4K); a strip is bit for bit the same columns of the whole blend (isx_blender_set_window: recomputed halos,
+    no exchange), so the strips are independent chains, and strip i + 1 starts when strip i has issued its two full-size pyramid kernels
+    (the event isx_blender_set_mark_event records behind the level-1 pyrDown) - its large kernels then run beside strip i's small ones.
+    Every strip warps only the tile columns it needs and writes its columns of ONE output mat.  Within a step only: the first strip of a
+    step waits for the last strip of the step before."""
+
+    def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32, device=0, out_dtype="int16",
+                 nsplit=2, tile_type="u8", stagger_level=1, chain_steps=False):
+        import torch
+        from . import mosaic
+        self.torch = torch
+        dev = torch.device("cuda", device)
+        creator = CylindricalWarper if kind == "cylindrical" else SphericalWarper
+        wp = creator(device, None).create(scale)
+        src_size = (imgs[0].shape[1], imgs[0].shape[0])
+        rois = [wp.warpRoi(src_size, K, R) for R in Rs]
+        del wp
+        corners = [(r[0], r[1]) for r in rois]
+        sizes = [(r[2] - r[0] + 1, r[3] - r[1] + 1) for r in rois]
+        _, (fw, fh), _ = prepare_geometry(corners, sizes, num_bands)
+        windows, sw = mosaic.strip_windows(fw, nsplit, _lib.WINDOW_GRANULE)
+        windows = [w for w in windows if w[1] > w[0]]
+        self.mosaic_size = (fw, fh)
+        odt = {"int16": torch.int16, "float32": torch.float32, "uint8": torch.uint8}[out_dtype]
+        es = {"int16": 2, "float32": 4, "uint8": 1}[out_dtype]
+        wpad = len(windows) * sw                       # the last strip may reach past the mosaic's right edge: columns nobody writes
+        opitch = (wpad * 3 * es + 127) // 128 * 128
+        self._out_full = torch.empty((fh * opitch // es,), dtype=odt, device=dev).as_strided((fh, wpad, 3), (opitch // es, 3, 1))
+        mpitch = (wpad + 127) // 128 * 128
+        self._mask_full = torch.empty((fh * mpitch,), dtype=torch.uint8, device=dev).as_strided((fh, wpad), (mpitch, 1))
+        self.out, self.out_mask = self._out_full[:, :fw], self._mask_full[:, :fw]
+        self.streams = [torch.cuda.Stream(device=device) for _ in windows]
+        self.parts = []
+        for w, st in zip(windows, self.streams):
+            part = PairStitcher(imgs, K, Rs, scale, kind, num_bands, precision, device, st, out_dtype, deferred=True, window=w, tile_type=tile_type)
+            part.out = self._out_full[:, w[0]:w[1]]
+            part.out_mask = self._mask_full[:, w[0]:w[1]]
+            self.parts.append(part)
+        torch.cuda.synchronize(device)
+        self.corners, self.sizes = self.parts[0].corners, self.parts[0].sizes
+        # the stagger: strip i records `go[i]` behind its level-`stagger_level` pyrDown, strip i + 1's chain starts there.  (A part whose ROI
+        # verification is a full scan already uses the blender's one mark event to place it: that part is then simply not staggered.)
+        self.go = []
+        for part in self.parts[:-1]:
+            ev = None
+            if part.mark is None and part.L >= 1 and stagger_level is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                part.blender.set_mark_event(ev, min(stagger_level, part.L - 1))
+            self.go.append(ev)
+        self.done = [torch.cuda.Event() for _ in self.parts]
+        self.chain_steps = chain_steps
+        self._first = True
+
+    def step(self):
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        for i, (part, st) in enumerate(zip(self.parts, self.streams)):
+            st.wait_stream(main)                                   # whatever produced the sources
+            if i == 0 and not self._first and not self.chain_steps:
+                st.wait_event(self.done[-1])                       # one step at a time: the last strip of the step before has finished
+            elif i > 0 and self.go[i - 1] is not None:
+                pass                                               # (the wait is enqueued below, once strip i - 1's step() has recorded the event)
+            with torch.cuda.stream(st):
+                if i > 0 and self.go[i - 1] is not None:
+                    st.wait_event(self.go[i - 1])
+                part.step()
+                self.done[i].record(st)
+        for ev in self.done:
+            main.wait_event(ev)
+        self._first = False
+        return self.out, self.out_mask
+
+    def capture(self):
+        """The staggered step as ONE hipGraph: the strips' chains become parallel branches (forked from the capture stream, joined at the
+        end), the stagger an edge from strip i's level-1 pyrDown to strip i + 1's first node - one graph launch per step instead of two
+        dozen kernel launches per strip from the host."""
+        torch = self.torch
+        dev = self.parts[0].device
+        self.gstream = torch.cuda.Stream(device=dev)
+        self.gstream.wait_stream(torch.cuda.current_stream(dev))
+
+        def one():
+            root = torch.cuda.current_stream(dev)
+            for i, (part, st) in enumerate(zip(self.parts, self.streams)):
+                st.wait_stream(root)
+                with torch.cuda.stream(st):
+                    if i > 0 and self.go[i - 1] is not None:
+                        st.wait_event(self.go[i - 1])
+                    part.step()
+                    part.warper.join()
+                    self.done[i].record(st)
+            for ev in self.done:
+                root.wait_event(ev)
+        with torch.cuda.stream(self.gstream):
+            one()
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.gstream, capture_error_mode="relaxed"):
+            one()
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
+        return self.out, self.out_mask
+
+    def check_plan(self):
+        return sum(p.check_plan() for p in self.parts)
+

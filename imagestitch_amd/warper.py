@@ -158,6 +158,10 @@ class RotationWarper:
         """Opt-in: remember detectResultRoi per (K, R, scale, source size); repeated calls skip the scan and its host sync."""
         check(self._lib.isx_warper_set_roi_cache(self._h, int(bool(on))))
 
+    def set_gain(self, gain=1.0):
+        """GainCompensator::apply (W:241-244) folded into the fused warps that follow (warp_with_mask*, all-255 mask): isx_warper_set_gain."""
+        check(self._lib.isx_warper_set_gain(self._h, C.c_double(float(gain))))
+
     def set_dst_columns(self, col0=0, col1=0):
         """The fused warps that follow produce only the columns [col0, col1) of the warped tile (isx_warper_set_dst_columns)."""
         check(self._lib.isx_warper_set_dst_columns(self._h, int(col0), int(col1)))

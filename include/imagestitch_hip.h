@@ -115,6 +115,11 @@ int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const 
  * must reach the host before the destination can be sized, W:148-150).  The spherical ROI (host code) is not cached.
  * Off by default: every call then computes its ROI as the reference does.                                           */
 int isx_warper_set_roi_cache(isx_warper* w, int on);
+/* compensator->apply(i, corners[i], images_warped[i], masks_warped[i]) (W:241-244) folded into the fused tile warps that
+ * follow (isx_warper_warp_with_mask / _roi / _planned with src_mask == NULL): every byte of the warped IMAGE becomes
+ * saturate_cast<uchar>(cvRound((double)byte * gain)) - exactly isx_gain_apply on the warped tile, one pass over it less (the gain acts on
+ * the remapped byte, not on the source: remap of scaled pixels is a different number).  gain = 1.0 switches it off.                    */
+int isx_warper_set_gain(isx_warper* w, double gain);
 
 /* buildMaps (W:122-144): xmap,ymap are caller-allocated CV_32FC1 of
  * (roi[3]-roi[1]+1) rows x (roi[2]-roi[0]+1) cols (W:128-129).                               */
@@ -214,6 +219,13 @@ int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, in
 /* images_warped.convertTo(CV_16S) (W:261,294) fused into feed: img is CV_8UC3 and is widened
  * to int16 on load; results are identical to converting first and calling isx_blender_feed.   */
 int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y);
+/* the mask preparation of W:286-301 inside the feed - mask = dilate(seam_mask, getStructuringElement(MORPH_RECT, Size(kw, kh)))
+ * & warped_mask is computed straight into the mask buffer the blender keeps for the tile (its private copy under
+ * isx_blender_set_deferred_level0 = 2), then blender->feed(img, mask, tl) (W:302) as isx_blender_feed does: identical results, no
+ * intermediate mask mat, one pass over the mask less.  Every blender type; elements up to 33 a side (ISX_ERR_UNSUPPORTED beyond:
+ * isx_mask_dilate_and + isx_blender_feed); img CV_16SC3 or CV_8UC3.                                                                */
+int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* seam_mask, const isx_mat* warped_mask, int kw, int kh,
+                             int tl_x, int tl_y);
 
 /* Opt-in: deferred mode.  feed() then only RECORDS the tile and blend() does all the work: the
  * Gaussian chains of all tiles (one launch per level), then a collapse chain whose every step
@@ -252,6 +264,11 @@ int isx_blender_set_window(isx_blender* b, int x0, int x1);
 
 /* size of the result of blend(): dst_roi_final_ (unpadded union of the fed tiles)             */
 int isx_blender_result_size(isx_blender* b, int* width, int* height);
+/* Which code path the last isx_blender_blend / _blend_batch of a multi-band blender took - the fast kernels have limits (tile type, tiles
+ * per place, tile count: DESIGN.md §3) and nothing else says which side of them a blend ran on.  cycle: 0 eager (the destination pyramid),
+ * 1 deferred, 2 deferred inside a batched chain; last_step: the kernel of the last collapse step - 0 none (a 0-band blend), 1 k_collapse,
+ * 2 k_collapse_gather, 3 k_collapse_roll.  Either pointer may be NULL.                                                          */
+int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step);
 /* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast
  * round-half-even), CV_32FC3 (F32/F16ACC32 only) or CV_8UC3 (= blend to CV_16SC3 followed by
  * result.convertTo(CV_8U), what imwrite (W:315) does to the panorama); dst_mask: CV_8UC1.  Releases the pyramids:

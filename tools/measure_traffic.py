@@ -31,17 +31,17 @@ def short(name):
 
 
 # kernel function name -> the launch name bench.py / the library's profiler reports
-ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_warp_tile": "warp_img_mask", "k_roi_scan": "roi_scan",
+ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_warp_tile": "warp_tile", "k_roi_scan": "roi_scan",
          "k_lap_acc_all": "lap_acc_all", "k_pyr_down": None, "k_pyr_down_multi": None, "k_collapse": None}
 
 
 def launch_name(kname, full):
-    if kname == "k_collapse_roll":       # round 3: the last collapse step without LDS
-        return "collapse_gather_final"
+    if kname in ("k_collapse_roll", "k_collapse_roll_batch"):       # the last collapse step without LDS (launch names = kernel names without the k_)
+        return "collapse_roll"
     if kname == "k_collapse_gather":
         return "collapse_gather_final" if re.search(r"k_collapse_gather<\d+, -?\d+, true", full) else "collapse_gather"
-    if kname == "k_pyr_down0_u8":        # round 3: level 0 -> 1 of CV_8UC3 tiles
-        return "pyr_down_l0"
+    if kname == "k_pyr_down0":           # level 0 -> 1 of CV_8UC3 / CV_16SC3 tiles
+        return "pyr_down0"
     if kname in ("k_pyr_down", "k_pyr_down_multi"):
         return "pyr_down" if re.search(r"<\d+, -1>", full) else "pyr_down_l0"
     if kname == "k_collapse":

@@ -51,7 +51,7 @@ if hasattr(p.warper, "set_roi_cache"):
     p.warper.set_roi_cache(True)
     fit(p.step, "planned step, ROI cache (no verify scans)")
     p.warper.set_roi_cache(False)
-lib.isx_profile_enable(1); lib.isx_profile_filter(b"collapse_gather_final"); lib.isx_profile_sample(4)
+lib.isx_profile_enable(1); lib.isx_profile_filter(b"collapse_roll"); lib.isx_profile_sample(4)
 fit(p.step, "planned step, dominant kernel bracketed 1/4")
 lib.isx_profile_enable(0)
 p.capture()
