@@ -562,6 +562,8 @@ def main():
             b = 0                                  # the graphs run on their own streams and always write send[0]
             if args.batch and not use_dist:
                 batch_graph.replay()
+                for p in pairs:
+                    p.verify_beside()       # the plans' verification scans, beside the graph (PairStitcher.capture)
                 return
         if args.batch and not args.graph and not args.sync_roi:
             for g, ps in enumerate(pstreams):           # one batched chain per stream: the pairs created on that stream

@@ -65,6 +65,8 @@ _SIGS = {
     "isx_warper_set_gain": [C.c_void_p, C.c_double],
     "isx_blender_feed_dilated": [C.c_void_p, _MP, _MP, _MP, C.c_int, C.c_int, C.c_int, C.c_int],
     "isx_warper_verify": [C.c_void_p],
+    "isx_warper_discard_pending": [C.c_void_p],
+    "isx_warper_queue_verify": [C.c_void_p, C.c_int, C.c_int, _F9, _F9, _IP],
     "isx_warper_verify_is_light": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "isx_warper_verify_after": [C.c_void_p, C.c_void_p],
     "isx_blender_set_mark_event": [C.c_void_p, C.c_void_p, C.c_int],

@@ -1256,6 +1256,8 @@ int set_camera(isx_warper* w, const float K[9], const float R[9]) {
 // current position.  The scan is VALU-bound like the warp kernel: it should run under memory-bound work.
 int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
     if (w->pending.empty()) return ISX_OK;
+    static const bool never = getenv("ISX_VERIFY_NEVER") != nullptr;      // measurement aid: what the verification scans cost a step (never in a product run)
+    if (never) { w->pending.clear(); return ISX_OK; }
     hipStream_t st = w->stream;
     if (!w->side) {
         // one verification stream per DEVICE, shared by every warper on it (never destroyed): a batch of pairs would otherwise
@@ -1967,6 +1969,32 @@ int isx_warper_verify_after(isx_warper* w, void* hip_event) {
     ISX_CHECK_ARG(w != nullptr && hip_event != nullptr, ISX_ERR_INVALID, "isx_warper_verify_after: null argument");
     ISX_HIP(hipSetDevice(w->device));
     return flush_verify(w, (hipEvent_t)hip_event);
+}
+
+// Verification outside a captured step.  A planned warp queues the scan that checks its plan; inside a hipGraph that scan has to be forked
+// from the captured stream by an event, and the fork cost a replayed step 12 us (0.206 -> 0.218 ms at 4K; the eager step starts the scan on the
+// side stream with no event at all).  A capturing caller therefore drops the queued scans of the captured warps
+// (isx_warper_discard_pending) and, after every replay, queues the same verifications from the rig alone (isx_warper_queue_verify: the scan
+// reads the projection and the source size, never an image) and starts them beside the graph (isx_warper_verify).
+int isx_warper_discard_pending(isx_warper* w) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_discard_pending: null warper");
+    w->pending.clear();
+    return ISX_OK;
+}
+
+int isx_warper_queue_verify(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], const int planned_roi[4]) {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr && K != nullptr && R != nullptr && planned_roi != nullptr, ISX_ERR_INVALID, "isx_warper_queue_verify: null argument");
+    ISX_CHECK_ARG(src_w > 0 && src_h > 0, ISX_ERR_INVALID, "isx_warper_queue_verify: empty source %d x %d", src_w, src_h);
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(set_camera(w, K, R));
+    isx_warper::Pending pd;
+    pd.proj = w->proj; pd.sw = src_w; pd.sh = src_h;
+    std::copy(planned_roi, planned_roi + 4, pd.planned);
+    std::copy(w->k, w->k + 9, pd.k); std::copy(w->rinv, w->rinv + 9, pd.rinv);
+    w->pending.push_back(pd);
+    return ISX_OK;
 }
 
 int isx_warper_join(isx_warper* w) {

@@ -179,7 +179,9 @@ class PairStitcher:
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
             if self.tile_cols is not None:
                 self.warper.set_dst_columns(0, 0)
-            if self.mark is None:
+            if getattr(self, "_verify_outside", False):
+                self.warper.discard_pending()   # a captured step: the verification runs beside the graph (replay)
+            elif self.mark is None:
                 self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
             for i in self.active:
@@ -197,7 +199,9 @@ class PairStitcher:
             self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
         if self.tile_cols is not None:
             self.warper.set_dst_columns(0, 0)
-        if self.mark is None:
+        if getattr(self, "_verify_outside", False):
+            self.warper.discard_pending()
+        elif self.mark is None:
             self.warper.verify()
         self.blender.prepare(self.corners, self.sizes)
         for i in self.active:
@@ -221,13 +225,10 @@ class PairStitcher:
         everything the step enqueues is stream work on resident buffers — no allocation, no host copy,
         no synchronisation — so it is capturable as is; the side-stream ROI scans are re-joined first."""
         torch = self.torch
-        # In a graph the side stream is forked by an event either way; a light verification then goes where the full scan used to go
-        # (behind the level-`verify_at` pyrDown, under the small launches) rather than between the warps and the level-0 pyrDown
-        va = self._verify_at_cfg
-        if self.mark is None and va is not None and va >= 0 and self.L >= 1 and not self.interleave and os.environ.get("ISX_VERIFY_AT", "") == "":
-            self.mark = torch.cuda.Event()
-            self.mark.record()
-            self.blender.set_mark_event(self.mark, min(va, self.L - 1))
+        # A verification that is a border scan (self.mark is None: every tile's is) stays OUT of the graph: forked inside it by an event it cost
+        # a replay 12 us (0.206 -> 0.218 ms at 4K), beside it nothing - replay() queues it from the rig alone and starts it on the
+        # verification stream, as the eager step does.  A full-scan verification keeps its place inside (behind the level-`verify_at` pyrDown).
+        self._verify_outside = self.mark is None and not self.interleave and os.environ.get("ISX_GRAPH_VERIFY_INSIDE", "") == ""
         self.gstream = torch.cuda.Stream(device=self.device)
         self.warper.set_stream(self.gstream)
         self.blender.set_stream(self.gstream)
@@ -239,41 +240,48 @@ class PairStitcher:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.gstream, capture_error_mode="relaxed"):
             self.step()
-            self.warper.join()
+            if not self._verify_outside:
+                self.warper.join()      # (with the verification outside, the captured step never leaves its stream: nothing to join)
         return self.graph
+
+    def verify_beside(self):
+        """The verification of a replayed step, beside the graph (see capture)."""
+        if getattr(self, "_verify_outside", False):
+            for i in self.active:
+                self.warper.queue_verify((self.imgs[i].shape[1], self.imgs[i].shape[0]), self.K, self.Rs[i], self.rois[i])
+            self.warper.verify()
 
     def replay(self):
         self.graph.replay()
+        self.verify_beside()
         return self.out, self.out_mask
 
     @staticmethod
     def capture_batch(stitchers):
         """step_batch of several stitchers captured into ONE hipGraph (BASELINE config 3: a batch of independent pairs as a graph
-        whose every launch spans all of them).  Returns (graph, stream); graph.replay() redoes the step of every stitcher."""
+        whose every launch spans all of them).  Returns (graph, stream); graph.replay() redoes the step of every stitcher, and
+        verify_beside() of every stitcher then starts its plan's verification beside the graph (see capture)."""
         s0 = stitchers[0]
         torch = s0.torch
         gstream = torch.cuda.Stream(device=s0.device)
         for s in stitchers:
-            va = s._verify_at_cfg
-            if s.mark is None and va is not None and va >= 0 and s.L >= 1 and not s.interleave and os.environ.get("ISX_VERIFY_AT", "") == "":
-                s.mark = torch.cuda.Event()
-                s.mark.record()
-                s.blender.set_mark_event(s.mark, min(va, s.L - 1))
+            s._verify_outside = s.mark is None and not s.interleave and os.environ.get("ISX_GRAPH_VERIFY_INSIDE", "") == ""   # see capture()
             s.gstream = gstream
             s.warper.set_stream(gstream)
             s.blender.set_stream(gstream)
         gstream.wait_stream(torch.cuda.current_stream(s0.device))
 
-        def one():
+        def one(join_all):
             PairStitcher.step_batch(stitchers)
             for s in stitchers:
-                s.warper.join()
+                if join_all or not s._verify_outside:
+                    s.warper.join()
         with torch.cuda.stream(gstream):
-            one()
+            one(True)
         torch.cuda.synchronize(s0.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=gstream, capture_error_mode="relaxed"):
-            one()
+            one(False)
         for s in stitchers:
             s.graph = graph
         return graph, gstream

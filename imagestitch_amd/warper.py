@@ -177,6 +177,16 @@ class RotationWarper:
         check(self._lib.isx_warper_verify_is_light(self._h, int(src_size[0]), int(src_size[1]), kp, rp, C.byref(v)))
         return bool(v.value)
 
+    def discard_pending(self):
+        """Drop the verification scans the planned warps since the last verify() queued (a captured step: they are re-queued per replay)."""
+        check(self._lib.isx_warper_discard_pending(self._h))
+
+    def queue_verify(self, src_size, K, R, planned_roi):
+        """Queue the verification of a planned ROI from the rig alone (isx_warper_queue_verify); verify() starts what is queued."""
+        _k, kp = f9(K)
+        _r, rp = f9(R)
+        check(self._lib.isx_warper_queue_verify(self._h, int(src_size[0]), int(src_size[1]), kp, rp, (C.c_int * 4)(*[int(v) for v in planned_roi])))
+
     def verify(self):
         """Enqueue the queued verification scans of planned warps behind the stream's current position."""
         check(self._lib.isx_warper_verify(self._h))

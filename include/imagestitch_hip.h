@@ -178,6 +178,12 @@ int isx_warper_set_deferred_verify(isx_warper* w, int on);
  * panorama (imagestitch_amd/mosaic.py: tile_columns_for_window gives the range).  (0, 0) = the whole tile again.              */
 int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1);
 int isx_warper_verify(isx_warper* w);
+/* Verification beside a hipGraph instead of inside it (a fork of the verification stream inside a captured step costs the replay 12 us at 4K):
+ * isx_warper_discard_pending drops the scans the planned warps of a CAPTURED step queued; after every replay the caller queues the same
+ * verifications from the rig alone - isx_warper_queue_verify(source size, K, R, planned ROI): the scan reads no image - and starts them with
+ * isx_warper_verify.  isx_warper_plan_status reports a stale plan as for any planned warp.                                           */
+int isx_warper_discard_pending(isx_warper* w);
+int isx_warper_queue_verify(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], const int planned_roi[4]);
 /* Scheduling hint (nothing in the reference): is the verification of a planned warp of a src_cols x src_rows source under (K, R) a
  * border scan - one workgroup over the 2 (W + H) border pixels, which starts at once, with no event on the handle's stream - (1), or
  * the full detectResultRoi scan of every source pixel (0), which is worth placing under memory-bound work

@@ -373,6 +373,29 @@ def test_pipeline_variants_agree(gpu):
     torch.cuda.synchronize()
     assert torch.equal(g, ref[0]) and torch.equal(gm, ref[1])
     assert ps.check_plan() == 0
+    # round 4: a border-scan verification runs BESIDE the graph (queued from the rig per replay, isx_warper_queue_verify): it still sees a
+    # plan that no longer fits the rig - here the rig's second camera turns a little after the capture
+    assert ps._verify_outside
+    from imagestitch_amd import synth as _s
+    _, Rs2 = _s.camera_pair(W, H, F, yaw=0.37)
+    ps.Rs = [Rs[0], Rs2[1]]
+    ps.replay()
+    with pytest.raises(gpu.IsxError) as e:
+        ps.check_plan()
+    assert e.value.code == 8       # ISX_ERR_PLAN
+    # ... and the same stitcher with the verification forked inside the graph (the former placement) gives the same mosaic
+    import os
+    os.environ["ISX_GRAPH_VERIFY_INSIDE"] = "1"
+    try:
+        pi = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, gpu.PREC_F32, 0, None, "int16")
+        pi.capture()
+        assert not pi._verify_outside
+        for _ in range(2):
+            g2, gm2 = pi.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g2, ref[0]) and torch.equal(gm2, ref[1]) and pi.check_plan() == 0
+    finally:
+        del os.environ["ISX_GRAPH_VERIFY_INSIDE"]
 
 
 @pytest.mark.parametrize("prec", [I16, F32])
