@@ -389,8 +389,145 @@ def case_strip_feather(rng):
     assert np.array_equal(m[:, :xe - x0], om[:, x0:xe]) and np.array_equal(d[:, :xe - x0], od[:, x0:xe]), (n, x0, x1, act)
 
 
+def case_s16_tiles(rng):
+    """Round 4: CV_16SC3 tiles of the whole int16 range through the deferred cycle (k_pyr_down0 / k_collapse_roll take them), device mats at
+    odd alignments, masks that are not just 0 / 255, two to five tiles over one place, every precision and result type."""
+    import torch
+    n = int(rng.integers(1, 6))
+    big = bool(rng.integers(0, 2))
+    sizes = [(int(rng.integers(2, 420 if big else 120)), int(rng.integers(2, 300 if big else 100))) for _ in range(n)]
+    spread = 260 if big else 70
+    corners = [(int(rng.integers(-spread, spread)), int(rng.integers(-40, 60))) for _ in range(n)]
+    bands, prec = int(rng.integers(1, 7)), int(rng.integers(0, 3))
+    lo, hi = [(-32768, 32767), (0, 255), (-2000, 3000)][int(rng.integers(0, 3))]
+    mode = [True, "copy", False][int(rng.integers(0, 3))]
+    mb = G.MultiBandBlender(False, bands, prec)
+    mb.set_deferred_level0(mode)
+    ob = O.MultiBand(bands, prec)
+    mb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    keep = []
+    dev = bool(rng.integers(0, 2))
+    for (w, h), c in zip(sizes, corners):
+        img = rng.integers(lo, hi + 1, (h, w, 3)).astype(np.int16)
+        mask = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        mask[rng.random((h, w)) < rng.uniform(0, 0.7)] = 0
+        mask[rng.random((h, w)) < rng.uniform(0, 0.7)] = 255
+        ob.feed(img, mask, c)
+        if dev:
+            pad, off = int(rng.integers(0, 9)), int(rng.integers(0, 4))
+            pitch = w * 3 + pad
+            buf = torch.zeros((h * pitch + off + 8,), dtype=torch.int16, device="cuda")
+            ti = buf[off:].as_strided((h, w, 3), (pitch, 3, 1))
+            ti.copy_(torch.from_numpy(img).cuda())
+            tm = torch.from_numpy(mask).cuda()
+            keep.append((buf, ti, tm))
+            mb.feed(ti, tm, c)
+        else:
+            mb.feed(img, mask, c)
+    kind = int(rng.integers(0, 3)) if prec != 0 else int(rng.integers(0, 2)) * 2
+    d, m = mb.blend(out_f32=kind == 1, out_u8=kind == 2)
+    d = d.cpu().numpy() if hasattr(d, "cpu") else d
+    m = m.cpu().numpy() if hasattr(m, "cpu") else m
+    od, om = ob.blend(kind == 1)
+    if kind == 2:
+        od = np.clip(od, 0, 255).astype(np.uint8)
+    assert np.array_equal(m, om)
+    assert np.array_equal(d, od), (bands, prec, mode, n, np.argwhere(d != od)[:3])
+
+
+def case_round4_calls(rng):
+    """Round 4's new entries: Blender::NO, isx_convert_to, the gain folded into the fused warp, the mask preparation folded into the feed, and
+    the two warps of a tile as calls of their own (image-only / mask-only tile kernels) - each against the oracle's separate stages."""
+    which = int(rng.integers(0, 4))
+    if which == 0:      # Blender::NO
+        n = int(rng.integers(1, 5))
+        sizes = [(int(rng.integers(1, 150)), int(rng.integers(1, 120))) for _ in range(n)]
+        corners = [(int(rng.integers(-50, 90)), int(rng.integers(-40, 60))) for _ in range(n)]
+        nb, ob = G.NoBlender(), O.NoBlend()
+        nb.prepare(corners, sizes); ob.prepare(corners, sizes)
+        for (w, h), c in zip(sizes, corners):
+            img = rng.integers(-32768, 32768, (h, w, 3)).astype(np.int16)
+            mask = rng.integers(0, 256, (h, w)).astype(np.uint8) * (rng.random((h, w)) < 0.6)
+            nb.feed(img, mask.astype(np.uint8), c); ob.feed(img, mask.astype(np.uint8), c)
+        d, m = nb.blend(); od, om = ob.blend()
+        assert np.array_equal(m, om) and np.array_equal(d, od)
+    elif which == 1:    # convertTo
+        h, w, cn = int(rng.integers(1, 90)), int(rng.integers(1, 130)), int(rng.choice([1, 3]))
+        f = (rng.standard_normal((h, w, cn) if cn == 3 else (h, w)) * float(rng.choice([3.0, 300.0, 40000.0, 1e12]))).astype(np.float32)
+        f.flat[::17] = np.round(f.flat[::17]) + 0.5
+        if cn == 3:
+            assert np.array_equal(G.convert_to(f, np.int16), O.convert_f32(f, np.int16))
+            u = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            assert np.array_equal(G.convert_to(u, np.int16), u.astype(np.int16)) and np.array_equal(G.convert_to(u, np.float32), u.astype(np.float32))
+            s16 = rng.integers(-500, 900, (h, w, 3)).astype(np.int16)
+            assert np.array_equal(G.convert_to(s16, np.uint8), np.clip(s16, 0, 255).astype(np.uint8))
+        else:
+            u = rng.integers(0, 256, (h, w)).astype(np.uint8)
+            assert np.array_equal(G.convert_to(u, np.float32), u.astype(np.float32))
+    elif which == 2:    # gain in the warp + dilate in the feed, through a blend
+        w, h = int(rng.integers(8, 300)), int(rng.integers(8, 220))
+        f = float(rng.uniform(0.5, 2.0) * max(w, h))
+        K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+        kind = int(rng.integers(0, 2))
+        Rs = [rot(rng, 0.15), rot(rng, 0.15)]
+        wp = (G.CylindricalWarper() if kind == 0 else G.SphericalWarper()).create(f)
+        gains = [float(rng.uniform(0.6, 1.6)), 1.0]
+        kw, kh = int(rng.integers(1, 34)), int(rng.integers(1, 34))
+        typ = int(rng.integers(0, 3))
+        nbands = int(rng.integers(1, 5))
+        b = [G.MultiBandBlender(False, nbands, 0), G.FeatherBlender(False, 0.1), G.NoBlender()][typ]
+        if typ < 2:
+            b.set_deferred_level0([False, True, "copy"][int(rng.integers(0, 3))])
+        corners, sizes, parts = [], [], []
+        for i in range(2):
+            src = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            roi, _ = O.detect_roi(kind, f, K, Rs[i], w, h)
+            if (roi[2] - roi[0] + 1) * (roi[3] - roi[1] + 1) > 2_000_000 or roi[2] < roi[0] or roi[3] < roi[1]:
+                return "skip"
+            wp.set_gain(gains[i])
+            c, wi, wm = wp.warp_with_mask(src, K, Rs[i])
+            oc, owi, _ = O.warp_u8(kind, f, K, Rs[i], src, 1, 2)
+            _, owm, _ = O.warp_u8(kind, f, K, Rs[i], np.full((h, w), 255, np.uint8), 0, 0)
+            owi = O.gain_apply(owi, gains[i])
+            assert tuple(c) == tuple(oc) and np.array_equal(wi, owi) and np.array_equal(wm, owm)
+            seam = (rng.random(wm.shape) < rng.choice([0.001, 0.02, 0.4])).astype(np.uint8) * 255
+            corners.append(tuple(c)); sizes.append((wm.shape[1], wm.shape[0])); parts.append((wi, seam, wm))
+        ob = [O.MultiBand(nbands, 0), O.Feather(0.1), O.NoBlend()][typ]
+        b.prepare(corners, sizes)
+        ob.prepare(corners, sizes)
+        for (wi, seam, wm), c in zip(parts, corners):
+            b.feed_dilated(wi.astype(np.int16), seam, wm, kw, kh, c)
+            ob.feed(wi.astype(np.int16), O.dilate_rect(seam, kw, kh) & wm, c)
+        d, m = b.blend()
+        od, om = ob.blend(False) if typ == 0 else ob.blend()
+        assert np.array_equal(m, om) and np.array_equal(d, od), (typ, kw, kh)
+    else:               # the two warps of a tile as calls of their own, device mats with odd pitches
+        import torch
+        w, h = int(rng.integers(2, 500)), int(rng.integers(3, 360))
+        f = float(rng.uniform(0.3, 3.0) * max(w, h))
+        K = np.array([[f, 0, w / 2 + rng.uniform(-3, 3)], [0, f * rng.uniform(0.9, 1.1), h / 2 + rng.uniform(-3, 3)], [0, 0, 1]], np.float32)
+        R = rot(rng, 0.6)
+        kind = int(rng.integers(0, 2))
+        roi, _ = O.detect_roi(kind, f, K, R, w, h)
+        if (roi[2] - roi[0] + 1) * (roi[3] - roi[1] + 1) > 3_000_000 or roi[2] < roi[0] or roi[3] < roi[1]:
+            return "skip"
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        mask = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        wp = (G.CylindricalWarper() if kind == 0 else G.SphericalWarper()).create(f)
+        _, owi, _ = O.warp_u8(kind, f, K, R, img, 1, 2)
+        _, owm, _ = O.warp_u8(kind, f, K, R, mask, 0, 0)
+        dh, dw = owm.shape
+        pi, pm = dw * 3 + int(rng.integers(0, 7)), dw + int(rng.integers(0, 7))
+        di = torch.zeros((dh * pi + 5,), dtype=torch.uint8, device="cuda")[int(rng.integers(0, 4)):][:dh * pi].as_strided((dh, dw, 3), (pi, 3, 1))
+        dm = torch.zeros((dh * pm + 5,), dtype=torch.uint8, device="cuda")[int(rng.integers(0, 4)):][:dh * pm].as_strided((dh, dw), (pm, 1))
+        wp.warp(torch.from_numpy(img).cuda(), K, R, 1, 2, dst=di)
+        wp.warp(torch.from_numpy(mask).cuda(), K, R, 0, 0, dst=dm)
+        assert np.array_equal(di.cpu().numpy(), owi) and np.array_equal(dm.cpu().numpy(), owm)
+
+
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair, case_strip, case_strip_feather, case_batch]
+         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls]
 
 
 def run(budget, seed0, verbose=True):
