@@ -1217,6 +1217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 
 #include "collapse_roll.inc"
 #include "pyrdown_l0.inc"
+#include "collapse_top.inc"
 
 // level 0 -> 1 of every recorded tile: CV_8UC3 and CV_16SC3 tiles through k_pyr_down0 (ISX_PD0=0: the general kernel, for A/B runs)
 template <int M, int SK>
@@ -1925,7 +1926,34 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     // either side.  Whatever else those blocks compute (and whatever they read outside need_k: levels left over from an earlier cycle)
     // reaches no pixel of the window - every input of a pixel of need_{k-1} lies in need_k by construction - so the window's pixels
     // are those of the whole mosaic, bit for bit, and a mosaic can be cut into column strips computed on different GPUs.
-    for (int k = L; k >= 1; --k) {
+    // The steps above the last two or three levels in ONE launch (collapse_top.inc): out_L .. out_{kout + 1} then never touch memory.
+    // ISX_TOP=0: one launch per step (A/B runs).
+    int k_first = L;
+    {
+        static const bool top_on = [] { const char* e = getenv("ISX_TOP"); return !(e && e[0] == '0'); }();
+        const int D = std::min(TOP_DMAX, L - 1), kout = L - D;
+        if (top_on && D >= 2) {
+            TopTiles tt;
+            memset(&tt, 0, sizeof(tt));
+            tt.n = n; tt.D = D;
+            double bytes = (double)d[kout].rows * d[kout].cols * alg_d_rgb(prec);
+            for (int t = 0; t < n; ++t) {
+                const isx_blender::TileRec& r = b->tiles[t];
+                tt.x_tl[t] = r.x_tl >> kout; tt.y_tl[t] = r.y_tl >> kout; tt.w[t] = r.g[kout].cols; tt.h[t] = r.g[kout].rows;
+                for (int i = 0; i <= D; ++i) {
+                    tt.g[t][i] = r.g[kout + i].img;
+                    // every level once as a fine level (record + weight; the top one as the gathered top), every level but the output's once as a pyrUp source
+                    bytes += (double)r.g[kout + i].rows * r.g[kout + i].cols * (alg_g(prec) + (i > 0 ? alg_g_rgb(prec) : 0.0));
+                }
+            }
+            const int gx_all = cdiv(d[kout].cols, TOP_BW);
+            const int bx_lo = need_lo[kout] / TOP_BW, bx_hi = std::min(cdiv(need_hi[kout], TOP_BW), gx_all);
+            const dim3 grid(bx_hi - bx_lo, cdiv(d[kout].rows, TOP_BH));
+            ISX_LAUNCH("collapse_top", bytes * (double)(bx_hi - bx_lo) / gx_all, st, (k_collapse_top<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
+            k_first = kout;
+        }
+    }
+    for (int k = k_first; k >= 1; --k) {
         TileSet ts = base(k - 1);
         const int gx_all = cdiv(d[k].cols, WAVE);
         const int bx_lo = need_lo[k - 1] / (2 * WAVE), bx_hi = std::min(cdiv(need_hi[k - 1], 2 * WAVE), gx_all);
