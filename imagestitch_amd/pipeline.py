@@ -362,7 +362,10 @@ class SplitStitcher:
     no exchange), so the strips are independent chains, and strip i + 1 starts when strip i has issued its two full-size pyramid kernels
     (the event isx_blender_set_mark_event records behind the level-1 pyrDown) - its large kernels then run beside strip i's small ones.
     Every strip warps only the tile columns it needs and writes its columns of ONE output mat.  Within a step only: the first strip of a
-    step waits for the last strip of the step before."""
+    step waits for the last strip of the step before.
+    MEASURED (tools/probes/split_probe.py, profiles/round4_split_strips.txt): identical mosaics, and SLOWER than the single chain - two strips
+    are two chains of launches, the caller's thread needs 0.1 ms to enqueue one chain, and the step becomes bound by that (0.28 - 0.37 ms
+    against 0.21).  Kept as the record of that experiment (and as a user of the window machinery on one GPU), not used by bench.py."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32, device=0, out_dtype="int16",
                  nsplit=2, tile_type="u8", stagger_level=1, chain_steps=False):
@@ -429,39 +432,6 @@ class SplitStitcher:
         for ev in self.done:
             main.wait_event(ev)
         self._first = False
-        return self.out, self.out_mask
-
-    def capture(self):
-        """The staggered step as ONE hipGraph: the strips' chains become parallel branches (forked from the capture stream, joined at the
-        end), the stagger an edge from strip i's level-1 pyrDown to strip i + 1's first node - one graph launch per step instead of two
-        dozen kernel launches per strip from the host."""
-        torch = self.torch
-        dev = self.parts[0].device
-        self.gstream = torch.cuda.Stream(device=dev)
-        self.gstream.wait_stream(torch.cuda.current_stream(dev))
-
-        def one():
-            root = torch.cuda.current_stream(dev)
-            for i, (part, st) in enumerate(zip(self.parts, self.streams)):
-                st.wait_stream(root)
-                with torch.cuda.stream(st):
-                    if i > 0 and self.go[i - 1] is not None:
-                        st.wait_event(self.go[i - 1])
-                    part.step()
-                    part.warper.join()
-                    self.done[i].record(st)
-            for ev in self.done:
-                root.wait_event(ev)
-        with torch.cuda.stream(self.gstream):
-            one()
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.gstream, capture_error_mode="relaxed"):
-            one()
-        return self.graph
-
-    def replay(self):
-        self.graph.replay()
         return self.out, self.out_mask
 
     def check_plan(self):

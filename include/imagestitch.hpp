@@ -116,6 +116,17 @@ public:
         Rect r; r.x = roi[0]; r.y = roi[1]; r.width = roi[2] - roi[0] + 1; r.height = roi[3] - roi[1] + 1;
         return r;
     }
+    // Not in the reference: the image and its all-255 mask in one pass (W:229 + W:232; dst_img CV_8UC3 or CV_16SC3 = + W:294), and the gain of
+    // GainCompensator::apply (W:241-244) folded into that pass's store (isx_warper_set_gain; 1.0 = off)
+    Point warpWithMask(const Mat& src, const float K[9], const float R[9], Mat& dst_img, Mat& dst_mask, int img_type = ISX_8UC3) {
+        int roi[4];
+        check(isx_warper_roi(h_, src.cols(), src.rows(), K, R, roi, nullptr));
+        dst_img.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, img_type);
+        dst_mask.create(roi[3] - roi[1] + 1, roi[2] - roi[0] + 1, ISX_8UC1);
+        check(isx_warper_warp_with_mask_roi(h_, src.c(), nullptr, K, R, roi, dst_img.c(), dst_mask.c()));
+        return Point(roi[0], roi[1]);
+    }
+    void setGain(double gain) { check(isx_warper_set_gain(h_, gain)); }
     isx_warper* handle() { return h_; }
 private:
     isx_warper* h_ = nullptr;
@@ -145,6 +156,11 @@ public:
     }
     void prepare(Rect dst_roi) { check(isx_blender_prepare_roi(h_, dst_roi.x, dst_roi.y, dst_roi.width, dst_roi.height)); }
     void feed(const Mat& img, const Mat& mask, Point tl) { check(isx_blender_feed(h_, img.c(), mask.c(), tl.x, tl.y)); }   // W:302
+    // Not in the reference: W:286-302 in one call - feed(img, dilate(seam_mask, MORPH_RECT kw x kh) & warped_mask, tl), the mask prepared
+    // straight into the blender's own buffer (isx_blender_feed_dilated)
+    void feedDilated(const Mat& img, const Mat& seam_mask, const Mat& warped_mask, int kw, int kh, Point tl) {
+        check(isx_blender_feed_dilated(h_, img.c(), seam_mask.c(), warped_mask.c(), kw, kh, tl.x, tl.y));
+    }
     void blend(Mat& dst, Mat& dst_mask) {   // W:313
         int w, h;
         check(isx_blender_result_size(h_, &w, &h));
@@ -201,10 +217,24 @@ public:
     void setSharpness(float val) { check(isx_blender_set_sharpness(h_, val)); }   // fb->setSharpness(0.1)  W:280
 };
 
+// cv::detail::Blender itself - what Blender::createDefault(Blender::NO, false) returns (W:276): feed() copies the tile under its mask,
+// blend() zeroes what no mask covered
+class NoBlender : public Blender {
+public:
+    explicit NoBlender(int device = 0) { check(isx_blender_create(ISX_BLEND_NO, 0, ISX_PREC_I16, device, &h_)); }
+};
+
 inline std::shared_ptr<Blender> Blender::createDefault(int type, bool try_gpu, int precision) {
+    if (type == NO) return std::make_shared<NoBlender>();
     if (type == FEATHER) return std::make_shared<FeatherBlender>();
-    if (type != MULTI_BAND) throw Exception(ISX_ERR_UNSUPPORTED, "Blender::createDefault: MULTI_BAND and FEATHER are implemented on this path");
+    if (type != MULTI_BAND) throw Exception(ISX_ERR_INVALID, "Blender::createDefault: NO, FEATHER or MULTI_BAND");
     return std::make_shared<MultiBandBlender>(try_gpu, 5, precision);
+}
+
+// src.convertTo(dst, type) with alpha = 1, beta = 0 between the CV_8U / CV_16S / CV_32F depths (W:261, W:294, W:315's input)
+inline void convertTo(const Mat& src, Mat& dst, int type, int device = 0) {
+    if (dst.empty() || dst.rows() != src.rows() || dst.cols() != src.cols() || dst.type() != type) dst.create(src.rows(), src.cols(), type);
+    check(isx_convert_to(src.c(), dst.c(), device, nullptr));
 }
 
 // dilate(mask, getStructuringElement(MORPH_RECT, Size(kw, kh))) [& other]  (W:286-301)

@@ -136,6 +136,23 @@ private:
     isx::FeatherBlender b_;
 };
 
+class HipNoBlender : public HipBlenderBase {                    // Blender::createDefault(Blender::NO, false)  W:276: cv::detail::Blender itself
+public:
+    explicit HipNoBlender(int device = 0) : b_(device) {}
+protected:
+    isx::Blender& blender() override { return b_; }
+private:
+    isx::NoBlender b_;
+};
+
+// Blender::createDefault(type, try_gpu) (W:271, 276, 278) for the three types the reference names; the caller owns the object
+// (`Ptr<Blender> blender(isx_cv::createDefaultBlender(Blender::NO));`)
+inline cv::detail::Blender* createDefaultBlender(int type) {
+    if (type == cv::detail::Blender::NO) return new HipNoBlender();
+    if (type == cv::detail::Blender::FEATHER) return new HipFeatherBlender();
+    return new HipMultiBandBlender();
+}
+
 }  // namespace isx_cv
 
 #endif  // IMAGESTITCH_CV_HPP

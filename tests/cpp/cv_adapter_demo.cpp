@@ -102,6 +102,23 @@ int main(int argc, char** argv) {
         blender->blend(result, result_mask);                                             // W:313
         dump(argv[6], "result", result);
         dump(argv[6], "result_mask", result_mask);
+        {   // W:276   blender = Blender::createDefault(Blender::NO, false);   (the line the demo runs before it settles on FEATHER)
+            std::unique_ptr<Blender> nb(isx_cv::createDefaultBlender(Blender::NO));
+            nb->prepare(corners, sizes);
+            for (int k = 0; k < num_images; ++k) {
+                Mat img_s(images_warped[k].rows, images_warped[k].cols, CV_16SC3);
+                for (int y = 0; y < img_s.rows; ++y) {
+                    const unsigned char* s = images_warped[k].ptr<unsigned char>(y);
+                    short* d = img_s.ptr<short>(y);
+                    for (int x = 0; x < img_s.cols * 3; ++x) d[x] = s[x];
+                }
+                nb->feed(img_s, masks_warped[k], corners[k]);
+            }
+            Mat nr, nm;
+            nb->blend(nr, nm);
+            dump(argv[6], "no_result", nr);
+            dump(argv[6], "no_mask", nm);
+        }
         try { blender->feed(result, result_mask, Point(0, 0)); printf("no-throw\n"); return 4; }
         catch (const isx::Exception& e) { printf("throws %d\n", e.code); }
     } catch (const std::exception& e) {

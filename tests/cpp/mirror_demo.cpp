@@ -119,6 +119,19 @@ int main(int argc, char** argv) {
             dump(argv[6], "batch1", outs[1]);
             dump(argv[6], "batchmask1", out_masks[1]);
         }
+        {   // W:276   Blender::createDefault(Blender::NO, false), the tiles converted with convertTo(CV_16S) (W:294)
+            auto nb = isx::Blender::createDefault(isx::Blender::NO, false);
+            nb->prepare(corners, sizes);
+            for (int k = 0; k < num_images; ++k) {
+                isx::Mat img_s;
+                isx::convertTo(images_warped[k], img_s, ISX_16SC3);
+                nb->feed(img_s, masks_warped[k], corners[k]);
+            }
+            isx::Mat nr, nm;
+            nb->blend(nr, nm);
+            dump(argv[6], "no_result", nr);
+            dump(argv[6], "no_mask", nm);
+        }
         // error behaviour: feed after blend must throw like a CV_Assert would
         try { blender->feed(result, result_mask, isx::Point(0, 0)); printf("no-throw\n"); return 4; }
         catch (const isx::Exception& e) { printf("throws %d\n", e.code); }

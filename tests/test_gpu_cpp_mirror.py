@@ -65,6 +65,14 @@ def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path, demo):
     got = np.fromfile(str(tmp_path / "o_result.raw"), np.int16).reshape(r, c, 3)
     gm = np.fromfile(str(tmp_path / "o_result_mask.raw"), np.uint8).reshape(r, c)
     assert np.array_equal(got, od) and np.array_equal(gm, om)
+    nb = oracle.NoBlend()          # Blender::createDefault(Blender::NO) (W:276) on the same tiles: the plain masked paste
+    nb.prepare([corners[0], corners[1]], sizes)
+    for i in range(2):
+        nb.feed(o_w[i].astype(np.int16), seam[i], corners[i])
+    nd, nm = nb.blend()
+    assert info["no_result"] == info["result"]
+    assert np.array_equal(np.fromfile(str(tmp_path / "o_no_result.raw"), np.int16).reshape(r, c, 3), nd)
+    assert np.array_equal(np.fromfile(str(tmp_path / "o_no_mask.raw"), np.uint8).reshape(r, c), nm)
     if demo == "mirror_demo":     # the mosaic again as two column strips of 384 (Blender::setWindow): each holds its columns of the whole
         assert c > 384
         for k in range(2):

@@ -2,13 +2,13 @@
 # Collects the measurement evidence of a round on the GPU box (run via gpurun from the repo root):
 #   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh round2 [fuzz_seconds]'
 # Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
-TAG=${1:-round2}; FUZZ=${2:-600}
+TAG=${1:-round4}; FUZZ=${2:-600}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 line() { grep "^{" | tail -1; }
 # 1. HBM traffic per kernel (two PMC passes of their own), then the default line that reads it
 python tools/measure_traffic.py $O/${TAG}_traffic.json > $O/traffic.log 2>&1
-cp $O/${TAG}_traffic.json profiles/${TAG}_traffic.json 2>/dev/null
+cp $O/${TAG}_traffic.json profiles/round4_traffic.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 2>/dev/null | line > $O/${TAG}_bench_n1.json
 # 2. the same command under the kernel tracer
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -41,6 +41,18 @@ b config4_forcedist_chunk_isx --force-dist --pairs 4 --gather chunk --gather-bac
 b config4_forcedist_chunk_p2p --force-dist --pairs 4 --gather chunk --gather-backend p2p
 b config5_ring8_8k --kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 5 --warmup 2
 b config5_8k_pair --kind spherical --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3
+# round 4: CV_16SC3 tiles (what the reference's feed() receives) on the planned step, both arithmetic modes; the probes of the round
+b s16_tiles_f32 --tile-type s16
+b s16_tiles_i16 --tile-type s16 --precision i16
+b top_off --steps 100
+ISX_TOP=0 python bench.py --no-cpu-baseline --no-dropin --steps 100 2>/dev/null | line > $O/${TAG}_bench_top_off_ISX_TOP0.json
+python tools/probes/fusion_probe.py > $O/${TAG}_n3_fusions.txt 2>&1
+python tools/probes/graph_probe.py > $O/${TAG}_graph_vs_eager.txt 2>&1
+python tools/probes/split_probe.py 1 2 > $O/${TAG}_split_strips.txt 2>&1
+python tools/probes/roi_latency_probe.py > $O/${TAG}_roi_latency.txt 2>&1; ISX_ROI_POLL=0 python tools/probes/roi_latency_probe.py >> $O/${TAG}_roi_latency.txt 2>&1
+python tools/probes/literal_host_probe.py 1 > $O/${TAG}_literal_host_time.txt 2>&1
+for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== pipeline_probe $m" >> $O/${TAG}_literal_kernels.txt; python tools/pipeline_probe.py $m 2>&1 | tail -14 >> $O/${TAG}_literal_kernels.txt; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/chain_probe.hip -o /tmp/chain_probe 2>/dev/null && timeout 60 /tmp/chain_probe > $O/${TAG}_chain_by_flags.txt 2>&1
 # 4b. config 5 as ONE panorama in column strips: every rank's share at 2 / 4 / 8 ranks, each alone on this GPU (no gather)
 C5="--kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3"
 mkdir -p $O/strips

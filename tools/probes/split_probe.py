@@ -1,6 +1,6 @@
 """One 4K pair as nsplit staggered column strips on nsplit streams (pipeline.SplitStitcher) against the single chain (PairStitcher):
 identical mosaics, ms per step of each.  usage: split_probe.py [prec] [nsplit ...]"""
-import os, sys, time
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from imagestitch_amd import synth
@@ -17,11 +17,14 @@ def bench(step, n=40):
     for _ in range(5):
         step()
     torch.cuda.synchronize()
+    gc.collect(); gc.disable()
     t0 = time.perf_counter()
     for _ in range(n):
         step()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    dt = (time.perf_counter() - t0) / n * 1e3
+    gc.enable()
+    return dt
 
 ps = PairStitcher(imgs, K, Rs, F, "cylindrical", 5, prec, 0, None, "int16")
 ref, refm = [t.clone() for t in ps.step()]
@@ -35,14 +38,4 @@ for ns in splits:
             same = bool(torch.equal(out, ref) and torch.equal(m, refm))
             t = bench(sp.step)
             print("split %d stagger %-4s chain_steps %-5s identical %s  %.4f ms per step  %.1f Gpix/s  plan %d" % (ns, stag, chain, same, t, 2 * W * H / t / 1e6, sp.check_plan()))
-            if not chain:
-                try:
-                    sp.capture()
-                    out, m = sp.replay()
-                    torch.cuda.synchronize()
-                    same = bool(torch.equal(out, ref) and torch.equal(m, refm))
-                    t = bench(sp.replay)
-                    print("split %d stagger %-4s AS ONE GRAPH        identical %s  %.4f ms per step  %.1f Gpix/s  plan %d" % (ns, stag, same, t, 2 * W * H / t / 1e6, sp.check_plan()))
-                except Exception as e:
-                    print("graph capture failed:", repr(e)[:300])
             del sp
