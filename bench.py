@@ -364,6 +364,10 @@ def main():
                          "schedule from the links)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--preflight-ms", type=float, default=60.0,
+                    help="untimed steps run for this long BEFORE the W warm-up steps, so that the timed region does not start on the clock an idle GPU "
+                         "sits at (tools/probes/ramp_probe.py: after the set-up's idle time the first ~70 steps of a 4K pair run 4-7 %% slower than the "
+                         "steady state, and --warmup 5 --steps 20 ends inside that ramp); their count is reported as preflight.steps. 0 = off")
     ap.add_argument("--cycle", default="deferred", choices=["deferred", "copy", "eager"],
                     help="blender cycle: deferred on the stitcher's own buffers (default), deferred with private copies of the fed mats "
                          "(OpenCV's feed contract, isx_blender_set_deferred_level0 = 2), or the eager destination-pyramid cycle")
@@ -653,6 +657,23 @@ def main():
     # The collection itself ran before the warm-up: any idle stretch in front of the region starts it on a colder clock
     # (tools/probes/region_probe.py: 20 steps right after 5 ms of idle GPU run 3 % slower per step than after none).
     gc.disable()
+    # pre-flight: the set-up above left the GPU idle for seconds (and the serialised step nearly so); the same step, untimed, until the
+    # clocks have settled.  Reported in the line (preflight.steps) together with the rate of W + K steps started on an idle GPU.
+    preflight_steps = 0
+    if args.preflight_ms > 0 and args.warmup >= 1:
+        tp = time.perf_counter()
+        while True:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            preflight_steps += 10
+            done = (time.perf_counter() - tp) * 1e3 >= args.preflight_ms
+            if use_dist:        # every rank runs the same number of (collective) steps: all agree block by block
+                flag = torch.tensor([1 if done else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                done = bool(flag.item())
+            if done:
+                break
     for _ in range(max(args.warmup - 2, 1 if args.warmup >= 1 else 0)):   # the rest of the W warm-up steps, exactly as the timed ones (at least one: right behind the serialised step the GPU is idle)
         step()
     fence()
@@ -676,6 +697,20 @@ def main():
         enq.append(time.perf_counter() - te)
     fence()
     host_enqueue_ms = sorted(enq)[len(enq) // 2] * 1e3
+    # the same W + K steps started on an idle GPU (what the line would read without the pre-flight): reported beside `value`
+    after_idle = None
+    if preflight_steps and not use_dist:
+        time.sleep(0.4)
+        gc.disable()
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ti = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        after_idle = time.perf_counter() - ti
+        gc.enable()
     split = None
     if use_dist:
         # outside the timed region ("report Mpix/s with and without the gather"): the same K steps
@@ -769,6 +804,10 @@ def main():
             "step_hbm": step_hbm,
             "kernels_ms_one_step": per_kernel,
         }
+        out["preflight"] = {"steps": preflight_steps, "ms": args.preflight_ms,
+                            "what": "untimed steps before the W warm-up steps: the set-up leaves the GPU idle and its clock takes ~70 steps to settle "
+                                    "(profiles/round4_clock_ramp.txt); --preflight-ms 0 switches them off",
+                            "after_idle_Mpix_s": round(mpix_step * args.steps / after_idle, 1) if after_idle else None}
         if split:
             dt_c, dt_g, nsend = split
             out["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),

@@ -44,8 +44,10 @@ b config5_8k_pair --kind spherical --width 7680 --height 4320 --focal 6000 --yaw
 # round 4: CV_16SC3 tiles (what the reference's feed() receives) on the planned step, both arithmetic modes; the probes of the round
 b s16_tiles_f32 --tile-type s16
 b s16_tiles_i16 --tile-type s16 --precision i16
-b top_off --steps 100
-ISX_TOP=0 python bench.py --no-cpu-baseline --no-dropin --steps 100 2>/dev/null | line > $O/${TAG}_bench_top_off_ISX_TOP0.json
+b steps100 --steps 100
+b no_preflight --preflight-ms 0
+ISX_TOP=0 python bench.py --no-cpu-baseline --no-dropin --steps 100 2>/dev/null | line > $O/${TAG}_bench_steps100_ISX_TOP0.json
+python tools/probes/ramp_probe.py > $O/${TAG}_clock_ramp.txt 2>&1
 python tools/probes/fusion_probe.py > $O/${TAG}_n3_fusions.txt 2>&1
 python tools/probes/graph_probe.py > $O/${TAG}_graph_vs_eager.txt 2>&1
 python tools/probes/split_probe.py 1 2 > $O/${TAG}_split_strips.txt 2>&1
