@@ -6,8 +6,11 @@
 // Loeffler-Ligtenberg-Moschytz, CONST_BITS 13, PASS1_BITS 2), "fancy" triangle-filter upsampling of h2v1 / h2v2 chroma (jdsample.c: 3/4 + 1/4
 // with the alternating rounding bias, edge samples replicated), pixel replication for other ratios, and the fixed-point YCbCr -> RGB of
 // jdcolor.c (16 fractional bits).  tests/test_imgio.py pins it bit for bit to Pillow's libjpeg-turbo on 4:4:4 / 4:2:2 / 4:2:0 / grey files
-// of odd sizes, with and without restart intervals.  Not supported (ISX_ERR_UNSUPPORTED): progressive and arithmetic-coded files, 12-bit
-// samples, CMYK.  Output: CV_8UC3 BGR (IMREAD_COLOR), host or device mat.
+// of odd sizes, with and without restart intervals.  Progressive files (SOF2: spectral selection and successive approximation, jdphuff.c)
+// are decoded into the same coefficient arrays scan by scan and then take the same inverse DCT / upsampling / colour conversion; a
+// progressive file whose scans do not bring every coefficient to full precision (libjpeg would smooth its blocks) is refused.
+// Not supported (ISX_ERR_UNSUPPORTED): arithmetic-coded and lossless files, 12-bit samples, CMYK.  Output: CV_8UC3 BGR (IMREAD_COLOR),
+// host or device mat.
 #include "isx_internal.hpp"
 
 #include <algorithm>
@@ -20,7 +23,10 @@ using namespace isx;
 
 namespace {
 
-struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int wblk = 0, hblk = 0; int dc_pred = 0; std::vector<short> coef; std::vector<unsigned char> plane; int pw = 0, ph = 0; };
+struct Comp {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int wblk = 0, hblk = 0; int dc_pred = 0; std::vector<short> coef; std::vector<unsigned char> plane; int pw = 0, ph = 0;
+    signed char coef_bits[64];      // progressive: the point transform each coefficient (zigzag index) was last sent with, -1 = never (jdphuff.c)
+};
 
 struct HuffDec {
     bool present = false;
@@ -41,6 +47,8 @@ struct Jpeg {
     int restart = 0;
     bool adobe = false; int adobe_transform = 0;
     bool progressive = false, got_sof = false;
+    int scans = 0;
+    int ss = 0, se = 63, ah = 0, al = 0, eobrun = 0;      // the current scan's spectral band and bit position (progressive), its end-of-band run
     // bit reader
     unsigned long long bits = 0; int nbits = 0; bool hit_marker = false;
 };
@@ -104,7 +112,7 @@ inline int get_bits(Jpeg& j, int n) {
     const int v = peek(j, n); j.nbits -= n; return v;
 }
 int decode_sym(Jpeg& j, const HuffDec& h) {
-    if (j.nbits < 16) fill_bits(j);
+    if (j.nbits < 17) fill_bits(j);       // (the search below looks at up to 17 bits before it gives up)
     const int look = peek(j, 8);
     if (h.look_nbits[look]) { j.nbits -= h.look_nbits[look]; return h.look_sym[look]; }
     int l = 9, code = peek(j, 9);
@@ -131,6 +139,78 @@ int decode_block(Jpeg& j, Comp& c, short* blk) {
         if (k > 63) return -1;
         blk[ZIGZAG[k]] = (short)extend(get_bits(j, ss), ss);
         ++k;
+    }
+    return 0;
+}
+
+// ---- progressive scans (jdphuff.c): the block's coefficients persist between scans ----------------------------------------------
+int prog_dc_first(Jpeg& j, Comp& c, short* blk) {
+    const int s = decode_sym(j, j.dc[c.td]);
+    if (s < 0 || s > 15) return -1;
+    c.dc_pred += s ? extend(get_bits(j, s), s) : 0;
+    blk[0] = (short)(c.dc_pred * (1 << j.al));
+    return 0;
+}
+int prog_dc_refine(Jpeg& j, Comp&, short* blk) {
+    if (get_bits(j, 1)) blk[0] = (short)(blk[0] | (1 << j.al));
+    return 0;
+}
+int prog_ac_first(Jpeg& j, Comp& c, short* blk) {
+    if (j.eobrun > 0) { --j.eobrun; return 0; }
+    for (int k = j.ss; k <= j.se; ++k) {
+        const int rs = decode_sym(j, j.ac[c.ta]);
+        if (rs < 0) return -1;
+        const int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return -1;
+            blk[ZIGZAG[k]] = (short)(extend(get_bits(j, s), s) * (1 << j.al));
+        } else if (r == 15) k += 15;
+        else {
+            j.eobrun = 1 << r;
+            if (r) j.eobrun += get_bits(j, r);
+            --j.eobrun;
+            break;
+        }
+    }
+    return 0;
+}
+inline void prog_correct(Jpeg& j, short& coef, int p1, int m1) {      // one correction bit for an already-nonzero coefficient
+    if (get_bits(j, 1) && (coef & p1) == 0) coef = (short)(coef >= 0 ? coef + p1 : coef + m1);
+}
+int prog_ac_refine(Jpeg& j, Comp& c, short* blk) {
+    const int p1 = 1 << j.al, m1 = -(1 << j.al);
+    int k = j.ss;
+    if (j.eobrun == 0) {
+        for (; k <= j.se; ++k) {
+            const int rs = decode_sym(j, j.ac[c.ta]);
+            if (rs < 0) return -1;
+            int r = rs >> 4, s = rs & 15;
+            if (s) s = get_bits(j, 1) ? p1 : m1;      // (a size other than 1 is a bad code; libjpeg warns and goes on the same way)
+            else if (r != 15) {
+                j.eobrun = 1 << r;
+                if (r) j.eobrun += get_bits(j, r);
+                break;                                  // end of band
+            }
+            // over the already-nonzero coefficients (a correction bit each) and r still-zero ones
+            do {
+                short& t = blk[ZIGZAG[k]];
+                if (t != 0) prog_correct(j, t, p1, m1);
+                else if (--r < 0) break;
+                ++k;
+            } while (k <= j.se);
+            if (s) {
+                if (k > 63) return -1;
+                blk[ZIGZAG[k]] = (short)s;
+            }
+        }
+    }
+    if (j.eobrun > 0) {
+        for (; k <= j.se; ++k) {
+            short& t = blk[ZIGZAG[k]];
+            if (t != 0) prog_correct(j, t, p1, m1);
+        }
+        --j.eobrun;
     }
     return 0;
 }
@@ -218,7 +298,8 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                 q += 16 + cnt;
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {     // SOFn
-            ISX_CHECK_ARG(m == 0xC0 || m == 0xC1, ISX_ERR_UNSUPPORTED, "imread: %s: only baseline / extended sequential Huffman JPEG is decoded (SOF%u)", path, m - 0xC0);
+            ISX_CHECK_ARG(m == 0xC0 || m == 0xC1 || m == 0xC2, ISX_ERR_UNSUPPORTED, "imread: %s: only baseline / extended sequential / progressive Huffman JPEG is decoded (SOF%u)", path, m - 0xC0);
+            j.progressive = m == 0xC2;
             ISX_CHECK_ARG(!j.got_sof, ISX_ERR_INVALID, "imread: %s: a second frame header (libjpeg: JERR_SOF_DUPLICATE)", path);
             ISX_CHECK_ARG(len >= 8 && j.data[s] == 8, ISX_ERR_UNSUPPORTED, "imread: %s: %u-bit samples", path, (unsigned)j.data[s]);
             j.height = (int)rd16(j, s + 1); j.width = (int)rd16(j, s + 3); j.ncomp = j.data[s + 5];
@@ -247,6 +328,7 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                 Comp& k = j.comp[c];
                 k.wblk = j.mcux * k.h; k.hblk = j.mcuy * k.v;
                 k.coef.assign((size_t)k.wblk * k.hblk * 64, 0);
+                memset(k.coef_bits, -1, sizeof(k.coef_bits));
             }
         } else if (m == 0xDD) {
             ISX_CHECK_ARG(len >= 4, ISX_ERR_INVALID, "imread: %s: truncated DRI segment", path);
@@ -264,9 +346,30 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                 for (int c = 0; c < j.ncomp; ++c) if (j.comp[c].id == id) k = &j.comp[c];
                 ISX_CHECK_ARG(k != nullptr, ISX_ERR_INVALID, "imread: %s: scan names an unknown component", path);
                 k->td = j.data[s + 2 + 2 * i] >> 4; k->ta = j.data[s + 2 + 2 * i] & 15;
-                ISX_CHECK_ARG(k->td < 4 && k->ta < 4 && j.dc[k->td].present && j.ac[k->ta].present, ISX_ERR_INVALID, "imread: %s: scan uses an undefined Huffman table", path);
+                ISX_CHECK_ARG(k->td < 4 && k->ta < 4, ISX_ERR_INVALID, "imread: %s: scan uses an undefined Huffman table", path);
+                for (int q = 0; q < i; ++q) ISX_CHECK_ARG(sc[q] != k, ISX_ERR_INVALID, "imread: %s: scan names a component twice", path);
                 sc[i] = k;
             }
+            j.ss = j.data[s + 1 + 2 * ns]; j.se = j.data[s + 2 + 2 * ns]; j.ah = j.data[s + 3 + 2 * ns] >> 4; j.al = j.data[s + 3 + 2 * ns] & 15;
+            int (*block_fn)(Jpeg&, Comp&, short*) = decode_block;
+            if (j.progressive) {        // jdphuff.c start_pass_phuff_decoder: the scan's band and bit position must make sense
+                const bool dc_scan = j.ss == 0;
+                ISX_CHECK_ARG((dc_scan ? j.se == 0 : (j.se >= j.ss && j.se <= 63 && ns == 1)) && j.al <= 13 && (j.ah == 0 || j.ah == j.al + 1), ISX_ERR_INVALID,
+                              "imread: %s: bad progressive scan parameters (Ss %d Se %d Ah %d Al %d, %d components)", path, j.ss, j.se, j.ah, j.al, ns);
+                block_fn = dc_scan ? (j.ah ? prog_dc_refine : prog_dc_first) : (j.ah ? prog_ac_refine : prog_ac_first);
+                for (int i = 0; i < ns; ++i) {
+                    if (dc_scan && j.ah == 0) ISX_CHECK_ARG(j.dc[sc[i]->td].present, ISX_ERR_INVALID, "imread: %s: scan uses an undefined Huffman table", path);
+                    if (!dc_scan) ISX_CHECK_ARG(j.ac[sc[i]->ta].present, ISX_ERR_INVALID, "imread: %s: scan uses an undefined Huffman table", path);
+                    for (int c = j.ss; c <= j.se; ++c) sc[i]->coef_bits[c] = (signed char)j.al;
+                }
+            } else {
+                for (int i = 0; i < ns; ++i)
+                    ISX_CHECK_ARG(j.dc[sc[i]->td].present && j.ac[sc[i]->ta].present, ISX_ERR_INVALID, "imread: %s: scan uses an undefined Huffman table", path);
+            }
+            j.eobrun = 0;
+            // a few hundred bytes of scan headers over a frame that passed the size check must not buy minutes of decoding: real encoders
+            // use about ten scans (libjpeg's default script), the format's own bit positions and bands allow some hundreds
+            ISX_CHECK_ARG(++j.scans <= 256, ISX_ERR_INVALID, "imread: %s: more than 256 scans", path);
             const int mcux = j.mcux, mcuy = j.mcuy;      // (blocks per component and the coefficient buffers were sized with the frame header)
             j.pos = e; j.bits = 0; j.nbits = 0; j.hit_marker = false;
             for (int c = 0; c < j.ncomp; ++c) j.comp[c].dc_pred = 0;
@@ -280,10 +383,10 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                         if (j.restart && todo == 0) {
                             j.nbits = 0; j.bits = 0;
                             while (j.pos + 1 < n && !(j.data[j.pos] == 0xFF && j.data[j.pos + 1] >= 0xD0 && j.data[j.pos + 1] <= 0xD7)) ++j.pos;
-                            j.pos += 2; j.hit_marker = false; k.dc_pred = 0; todo = j.restart;
+                            j.pos += 2; j.hit_marker = false; k.dc_pred = 0; j.eobrun = 0; todo = j.restart;
                         }
                         ISX_CHECK_ARG(bx < k.wblk && by < k.hblk, ISX_ERR_INVALID, "imread: %s: scan passes the frame", path);
-                        ISX_CHECK_ARG(decode_block(j, k, &k.coef[((size_t)by * k.wblk + bx) * 64]) == 0, ISX_ERR_INVALID, "imread: %s: corrupt entropy-coded data", path);
+                        ISX_CHECK_ARG(block_fn(j, k, &k.coef[((size_t)by * k.wblk + bx) * 64]) == 0, ISX_ERR_INVALID, "imread: %s: corrupt entropy-coded data", path);
                         --todo;
                     }
             } else {
@@ -294,13 +397,14 @@ int parse(Jpeg& j, const char* path, bool header_only) {
                             while (j.pos + 1 < n && !(j.data[j.pos] == 0xFF && j.data[j.pos + 1] >= 0xD0 && j.data[j.pos + 1] <= 0xD7)) ++j.pos;
                             j.pos += 2; j.hit_marker = false;
                             for (int c = 0; c < j.ncomp; ++c) j.comp[c].dc_pred = 0;
+                            j.eobrun = 0;
                             todo = j.restart;
                         }
                         for (int i = 0; i < ns; ++i) {
                             Comp& k = *sc[i];
                             for (int v = 0; v < k.v; ++v)
                                 for (int h = 0; h < k.h; ++h)
-                                    ISX_CHECK_ARG(my * k.v + v < k.hblk && mx * k.h + h < k.wblk && decode_block(j, k, &k.coef[((size_t)(my * k.v + v) * k.wblk + mx * k.h + h) * 64]) == 0, ISX_ERR_INVALID,
+                                    ISX_CHECK_ARG(my * k.v + v < k.hblk && mx * k.h + h < k.wblk && block_fn(j, k, &k.coef[((size_t)(my * k.v + v) * k.wblk + mx * k.h + h) * 64]) == 0, ISX_ERR_INVALID,
                                                   "imread: %s: corrupt entropy-coded data", path);
                         }
                         --todo;
@@ -418,6 +522,11 @@ static int jpeg_read_impl(const char* path, isx_mat* out) {
     ISX_TRY(load_file(path, j.data));
     ISX_TRY(parse(j, path, false));
     ISX_CHECK_ARG(out->rows == j.height && out->cols == j.width, ISX_ERR_SIZE, "imread: out is %dx%d, %s is %dx%d", out->cols, out->rows, path, j.width, j.height);
+    if (j.progressive)      // every coefficient at full precision: otherwise libjpeg smooths the blocks from their neighbours' DC values (jdcoefct.c)
+        for (int c = 0; c < j.ncomp; ++c)
+            for (int i = 0; i < 64; ++i)
+                ISX_CHECK_ARG(j.comp[c].coef_bits[i] == 0, ISX_ERR_UNSUPPORTED, "imread: %s: progressive file whose scans leave coefficient %d of component %d %s", path, i, c,
+                              j.comp[c].coef_bits[i] < 0 ? "unsent" : "short of full precision");
     const int W = j.width, H = j.height;
     std::vector<unsigned char> full[3];
     for (int c = 0; c < j.ncomp; ++c) {

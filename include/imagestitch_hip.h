@@ -350,10 +350,11 @@ int isx_bmp_write(const char* path, const isx_mat* img);
  * chroma for CV_8UC3 (BGR), one component for CV_8UC1; quality 1..100 scales the Annex K quantisation tables as libjpeg does
  * (OpenCV's default is 95).  Any JPEG decoder reads the file; it is not libjpeg's byte stream.  Host or device mats.   */
 int isx_jpeg_write(const char* path, const isx_mat* img, int quality);
-/* cv::imread(path) (IMREAD_COLOR) for .jpg: baseline / extended-sequential Huffman JPEG, 8-bit, grey or YCbCr (any integer sampling;
- * 4:4:4, 4:2:2 and 4:2:0 with libjpeg's "fancy" upsampling), restart intervals, interleaved or one scan per component.  The arithmetic
- * is libjpeg's (accurate integer IDCT, its upsampling and colour conversion): what cv::imread hands back.  Progressive, arithmetic-coded,
- * 12-bit and CMYK files: ISX_ERR_UNSUPPORTED.  `out` is a CV_8UC3 mat (host or device) of the size isx_jpeg_size reports.            */
+/* cv::imread(path) (IMREAD_COLOR) for .jpg: baseline / extended-sequential / progressive Huffman JPEG, 8-bit, grey or YCbCr (any integer
+ * sampling; 4:4:4, 4:2:2 and 4:2:0 with libjpeg's "fancy" upsampling), restart intervals, interleaved or one scan per component.  The
+ * arithmetic is libjpeg's (accurate integer IDCT, its upsampling and colour conversion): what cv::imread hands back.  Arithmetic-coded,
+ * lossless, 12-bit and CMYK files, and progressive files whose scans stop short of full precision (libjpeg would smooth those):
+ * ISX_ERR_UNSUPPORTED.  `out` is a CV_8UC3 mat (host or device) of the size isx_jpeg_size reports.                                     */
 int isx_jpeg_size(const char* path, int* rows, int* cols);
 int isx_jpeg_read(const char* path, isx_mat* out);
 

@@ -30,6 +30,9 @@ for (w, h, q, sub) in [(37, 29, 75, 2), (64, 48, 90, 0), (100, 131, 50, 1), (17,
     b = io.BytesIO(); Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(b, "JPEG", quality=q, subsampling=sub); base.append(b.getvalue())
 g = io.BytesIO(); Image.fromarray(rng.integers(0, 255, (40, 50), dtype=np.uint8)).save(g, "JPEG", quality=80); base.append(g.getvalue())
 p = io.BytesIO(); Image.fromarray(rng.integers(0, 255, (40, 50, 3), dtype=np.uint8)).save(p, "JPEG", quality=80, progressive=True); base.append(p.getvalue())
+for (w, h, q, sub, kw) in [(61, 47, 70, 2, {}), (90, 33, 92, 0, {"optimize": True}), (40, 77, 40, 1, {"restart_marker_blocks": 2}), (24, 24, 85, 2, {})]:      # progressive: half of the corpus
+    for _ in range(2):
+        b = io.BytesIO(); Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(b, "JPEG", quality=q, subsampling=sub, progressive=True, **kw); base.append(b.getvalue())
 os.makedirs("c", exist_ok=True)
 for it in range(4000):
     data = bytearray(base[it % len(base)]); mode = it % 5
