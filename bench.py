@@ -11,6 +11,11 @@ with one GPU (config 2) and to 4 with N > 1 (config 4: 64 x 4K tiles on 8 GPUs =
 N > 1 the blended mosaics are assembled on every rank with ONE all-gather (RCCL over xGMI).  Weak scaling: per-GPU
 work is fixed.  Mpix = source-tile pixels processed.  Rank 0 prints one JSON line.
 
+Before the W warm-up steps the same step runs untimed for --preflight-ms (default 60 ms; the count is reported as preflight.steps): after the
+idle seconds of the set-up the GPU's clock takes ~70 steps to settle and a 20-step region would end inside that ramp
+(profiles/round4_clock_ramp.txt).  preflight.after_idle_Mpix_s is the rate of the same W + K steps started on an idle GPU, measured after
+the headline region; --preflight-ms 0 switches the pre-flight off.
+
 At N = 1 the line also carries `dropin`: the same workload as a caller written against cv::detail::RotationWarper /
 cv::detail::Blender gets it - every warp returns its corner to the host (W:160), feed() consumes its inputs (W:305-308) -
 with device mats and with host (cv::Mat-like, PCIe-inclusive) mats; timed after the headline region, never part of `value`.
