@@ -290,3 +290,21 @@ def test_the_two_warps_of_a_tile_as_calls_of_their_own(gpu, oracle, kind):
             warper.warp(torch.from_numpy(img).cuda(), K, R, gpu.INTER_LINEAR, gpu.BORDER_REFLECT, dst=di)
             warper.warp(torch.from_numpy(mask).cuda(), K, R, gpu.INTER_NEAREST, gpu.BORDER_CONSTANT, dst=dm)
             assert np.array_equal(di.cpu().numpy(), owi) and np.array_equal(dm.cpu().numpy(), owm)
+
+
+def test_int16_arithmetic_on_floats_equals_the_integer_forms_at_4k(gpu):
+    """ISX_PREC_I16 in k_collapse_roll / k_pyr_down0 runs on integer-valued floats (round 4); the integer forms it replaced are still in the
+    library (k_collapse_gather as the last step: ISX_ROLL=0, k_pyr_down_multi at level 0: ISX_PD0=0).  CV_16SC3 tiles of the whole short
+    range with saturating differences and masks with holes, 4096 x 2160, 7 bands: same mosaic (tools/probes/int16_forms_probe.py holds
+    the larger sizes, profiles/round4_int16_forms.json)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = os.path.join(root, "tools", "probes", "int16_forms_probe.py")
+    got = {}
+    for roll, pd0 in (("1", "1"), ("0", "0")):
+        env = dict(os.environ, ISX_ROLL=roll, ISX_PD0=pd0)
+        out = subprocess.check_output([sys.executable, probe, "--child", "s16", "4096", "2160", "7"], env=env, text=True)
+        line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+        got[(roll, pd0)] = line[1]
+        assert ("collapse_roll" if roll == "1" else "collapse_gather") in " ".join(line[2:])
+    assert got[("1", "1")] == got[("0", "0")]
