@@ -128,7 +128,7 @@ int decode_block(Jpeg& j, Comp& c, short* blk) {
     int s = decode_sym(j, j.dc[c.td]);
     if (s < 0 || s > 15) return -1;
     int diff = s ? extend(get_bits(j, s), s) : 0;
-    c.dc_pred += diff;
+    c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);
     blk[0] = (short)c.dc_pred;
     for (int k = 1; k < 64;) {
         const int rs = decode_sym(j, j.ac[c.ta]);
@@ -147,8 +147,8 @@ int decode_block(Jpeg& j, Comp& c, short* blk) {
 int prog_dc_first(Jpeg& j, Comp& c, short* blk) {
     const int s = decode_sym(j, j.dc[c.td]);
     if (s < 0 || s > 15) return -1;
-    c.dc_pred += s ? extend(get_bits(j, s), s) : 0;
-    blk[0] = (short)(c.dc_pred * (1 << j.al));
+    c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)(s ? extend(get_bits(j, s), s) : 0));      // (a hostile file can run the predictor past INT_MAX: wrap, as the stored short does)
+    blk[0] = (short)((unsigned)c.dc_pred << j.al);
     return 0;
 }
 int prog_dc_refine(Jpeg& j, Comp&, short* blk) {
