@@ -2728,6 +2728,7 @@ static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* 
     ISX_TRY(check_mat(dst, "blend: dst"));
     ISX_CHECK_ARG(dst->type == ISX_16SC3 || dst->type == ISX_8UC3 || (dst->type == ISX_32FC3 && b->prec != ISX_PREC_I16), ISX_ERR_TYPE,
                   "blend: dst must be CV_16SC3, CV_8UC3%s, got %s", b->prec != ISX_PREC_I16 ? " or CV_32FC3" : "", type_name(dst->type));
+    ISX_CHECK_ARG(!(b->type == ISX_BLEND_NO && dst->type == ISX_32FC3), ISX_ERR_TYPE, "blend: Blender::NO hands out its CV_16SC3 canvas (or CV_8UC3), not CV_32FC3");
     const bool windowed = b->win_x1 > b->win_x0;
     const int out_cols = windowed ? b->win_x1 - b->win_x0 : b->fw;   // a window's mats hold its columns only
     if (windowed) {

@@ -292,6 +292,25 @@ def test_the_two_warps_of_a_tile_as_calls_of_their_own(gpu, oracle, kind):
             assert np.array_equal(di.cpu().numpy(), owi) and np.array_equal(dm.cpu().numpy(), owm)
 
 
+def test_no_blender_refuses_a_float_result_and_a_window(gpu):
+    """Blender::NO hands out its CV_16SC3 canvas: a CV_32FC3 result (whatever precision the handle was created with) and a column window
+    are refused, not mis-served."""
+    import torch
+    from imagestitch_amd import IsxError, _lib as L
+    b = gpu.NoBlender()
+    img = torch.zeros((64, 80, 3), dtype=torch.int16, device="cuda")
+    msk = torch.full((64, 80), 255, dtype=torch.uint8, device="cuda")
+    b.prepare([(0, 0)], [(80, 64)])
+    b.feed(img, msk, (0, 0))
+    with pytest.raises(IsxError):
+        b.blend(out_f32=True)
+    b.prepare([(0, 0)], [(80, 64)])
+    b.feed(img, msk, (0, 0))
+    b.set_window(0, 128)
+    with pytest.raises(IsxError):
+        b.blend()
+
+
 def test_int16_arithmetic_on_floats_equals_the_integer_forms_at_4k(gpu):
     """ISX_PREC_I16 in k_collapse_roll / k_pyr_down0 runs on integer-valued floats (round 4); the integer forms it replaced are still in the
     library (k_collapse_gather as the last step: ISX_ROLL=0, k_pyr_down_multi at level 0: ISX_PD0=0).  CV_16SC3 tiles of the whole short
