@@ -1827,9 +1827,14 @@ int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, cons
         for (int t = 0; t < ts.n; ++t)
             if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].rows < 2 || ts.s0[t].iend == 0u ||      // iend != 0: a CV_8UC3 / CV_16SC3 tile below 2 GiB, 32-bit offsets
                 (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return ISX_OK;
-        // two rows per wave while at most two tiles reach a strip (a pair, a row of tiles with narrow overlaps); one row and a third slot
+        // two rows per wave while at most two tiles reach a strip (a pair, a row of tiles with narrow overlaps); a third slot
         // for panoramas whose tiles overlap their second neighbours (BASELINE config 5); k_collapse_gather beyond that
-        if (rsel != 1 && roll_max_tiles(ts, coarse, cx_lo, cx_hi, 2) <= 2) return launch_collapse_roll_r<M, SK, 2, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        // ... and two rows with a third slot (round 4: 4 waves per SIMD instead of 5, still faster than one-row strips - config 5's last step
+        // 0.704 -> 0.654 ms; ISX_ROLL_R23=0: the one-row form, for A/B runs)
+        static const bool r23 = [] { const char* e = getenv("ISX_ROLL_R23"); return !(e && e[0] == '0'); }();
+        const int most2 = rsel != 1 ? roll_max_tiles(ts, coarse, cx_lo, cx_hi, 2) : 99;
+        if (most2 <= 2) return launch_collapse_roll_r<M, SK, 2, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        if (r23 && most2 <= 3) return launch_collapse_roll_r<M, SK, 2, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
         const int most = roll_max_tiles(ts, coarse, cx_lo, cx_hi, 1);
         if (most <= 2) return launch_collapse_roll_r<M, SK, 1, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
         if (most <= 3) return launch_collapse_roll_r<M, SK, 1, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
