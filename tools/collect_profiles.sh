@@ -40,6 +40,7 @@ b config4_forcedist_single --force-dist --pairs 4 --gather single
 b config4_forcedist_chunk_isx --force-dist --pairs 4 --gather chunk --gather-backend isx
 b config4_forcedist_chunk_p2p --force-dist --pairs 4 --gather chunk --gather-backend p2p
 b config5_ring8_8k --kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 5 --warmup 2
+ISX_ROLL_R23=0 python bench.py --no-cpu-baseline --no-dropin --kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 5 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_config5_ring8_8k_ISX_ROLL_R23_0.json
 b config5_8k_pair --kind spherical --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3
 # round 4: CV_16SC3 tiles (what the reference's feed() receives) on the planned step, both arithmetic modes; the probes of the round
 b s16_tiles_f32 --tile-type s16
