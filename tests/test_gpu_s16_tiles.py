@@ -327,3 +327,47 @@ def test_int16_arithmetic_on_floats_equals_the_integer_forms_at_4k(gpu):
         got[(roll, pd0)] = line[1]
         assert ("collapse_roll" if roll == "1" else "collapse_gather") in " ".join(line[2:])
     assert got[("1", "1")] == got[("0", "0")]
+
+
+@pytest.mark.parametrize("prec", ["i16", "f32"])
+def test_dense_result_of_odd_width_equals_the_pitched_one_and_the_oracle(gpu, oracle, prec):
+    """blend() into a dense CV_16SC3 cv::Mat whose width is odd (rows start on 2-byte boundaries: what dst.create() gives the reference's
+    result, W:313) takes k_collapse_roll's vector stores since round 4 (they are typed 2-byte aligned); same bytes as a result with 4-byte
+    aligned rows, an offset view included, and as the oracle's."""
+    import torch
+    P = {"i16": (gpu.PREC_I16, oracle.I16), "f32": (gpu.PREC_F32, oracle.F32)}[prec]
+    h, w = 230, 301
+    tiles = [synth.make_tile(h, w, 60 + i) for i in range(2)]
+    corners = [(0, 0), (188, 7)]                      # mosaic 489 x 237: an odd width
+    sizes = [(w, h), (w, h)]
+    masks = [np.full((h, w), 255, np.uint8) for _ in range(2)]
+    masks[0][:, 250:] = 0; masks[1][:, :40] = 0
+    ob = oracle.MultiBand(4, P[1])
+    ob.prepare(corners, sizes)
+    for i in range(2):
+        ob.feed(tiles[i].astype(np.int16), masks[i], corners[i])
+    od, om = ob.blend(False)
+    fh, fw = od.shape[:2]
+    assert fw % 2 == 1
+    outs = []
+    for layout in ("dense", "pitched", "offset"):
+        b = gpu.MultiBandBlender(False, 4, P[0], 0)
+        b.set_deferred_level0(True)
+        b.prepare(corners, sizes)
+        keep = []
+        for i in range(2):
+            t16 = torch.from_numpy(tiles[i].astype(np.int16)).cuda(); m = torch.from_numpy(masks[i]).cuda()
+            keep += [t16, m]
+            b.feed(t16, m, corners[i])
+        if layout == "dense":
+            dst = torch.empty((fh, fw, 3), dtype=torch.int16, device="cuda"); dm = torch.empty((fh, fw), dtype=torch.uint8, device="cuda")
+            assert (dst.stride(0) * 2) % 4 == 2
+        elif layout == "pitched":
+            dst = torch.empty((fh, fw + 1, 3), dtype=torch.int16, device="cuda")[:, :fw]; dm = torch.empty((fh, fw + 3), dtype=torch.uint8, device="cuda")[:, :fw]
+        else:                                          # rows 4-byte aligned in pitch but starting 2 bytes into a dword
+            dst = torch.empty((fh, fw + 3, 3), dtype=torch.int16, device="cuda")[:, 1:fw + 1]; dm = torch.empty((fh, fw + 5), dtype=torch.uint8, device="cuda")[:, 1:fw + 1]
+        b.blend(dst, dm)
+        assert b.last_path()["last_step"] == "collapse_roll"
+        outs.append((dst.cpu().numpy().copy(), dm.cpu().numpy().copy()))
+    for d, m in outs:
+        assert np.array_equal(d, od) and np.array_equal(m, om)
