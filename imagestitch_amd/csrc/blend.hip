@@ -149,6 +149,38 @@ __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const 
     }
 }
 
+// PLANAR tile level (round 4, level 1 of the deferred cycle when k_collapse_roll runs the last step): the record's image channels as dense
+// 12-byte records at L.img and its weight in a float plane at L.wgt (inside the same allocation: 12 n + 4 n bytes).  The last collapse
+// step reads the image channels of level 1 only (pyrUp never reads a coarse weight): with 16-byte records it fetched the weights' 4 bytes
+// per pixel for nothing (14.8 MB per 4K pair); pyrDown of level 1 and the level-1 collapse step read both parts, as many bytes as before.
+typedef unsigned u32x3_rec __attribute__((ext_vector_type(3), aligned(4)));
+template <int M>
+__device__ __forceinline__ Px<M> load_px_planar(const LevelBuf& L, int x, int y) {
+    static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
+    const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
+    const u32x3_rec v = *(const u32x3_rec*)((const char*)L.img + (size_t)i * 12u);
+    Px<M> p;
+    if constexpr (M == M_I16) { p.c0 = (int)v.x; p.c1 = (int)v.y; p.c2 = (int)v.z; }
+    else { p.c0 = __uint_as_float(v.x); p.c1 = __uint_as_float(v.y); p.c2 = __uint_as_float(v.z); }
+    p.w = L.wgt[i];
+    return p;
+}
+// the image channels of a register record as a dense 12-byte record (planar tile levels; out_1 in 12-byte records, OutMat::rec12)
+template <int M>
+__device__ __forceinline__ void store_rgb12(const LevelBuf& L, unsigned i, const Px<M>& p) {
+    u32x3_rec v;
+    if constexpr (M == M_I16) { v.x = (unsigned)p.c0; v.y = (unsigned)p.c1; v.z = (unsigned)p.c2; }
+    else { v.x = __float_as_uint(p.c0); v.y = __float_as_uint(p.c1); v.z = __float_as_uint(p.c2); }
+    *(u32x3_rec*)((char*)L.img + (size_t)i * 12u) = v;
+}
+template <int M>
+__device__ __forceinline__ void store_px_planar(const LevelBuf& L, int x, int y, const Px<M>& p) {
+    static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
+    const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
+    store_rgb12<M>(L, i, p);
+    L.wgt[i] = p.w;
+}
+
 // level-0 pixel of the tile pyramid at padded coordinates (x, y) in [0,width) x [0,height)
 template <int M, int SK>
 __device__ __forceinline__ Px<M> load_src0(const Src0& s, int x, int y) {
@@ -329,7 +361,7 @@ constexpr int PD_NR = 2 * PD_TY + 3;
 constexpr int PD_OW = WAVE - 2;
 constexpr int PD_WAVES = 8;
 
-template <int M> __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv);
+template <int M, bool PLD = false> __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv);
 
 // pyrDown's row filter at one output column: c = pixel 2x, l1 / r1 = pixels 2x - 1 / 2x + 1, l2 / r2 = pixels 2x - 2 / 2x + 2;
 // tap5's association, the float precisions on (b, g) / (r, w) register pairs (packed fp32, each half rounded on its own)
@@ -355,7 +387,7 @@ __device__ __forceinline__ Px<M> pyr_down_row5(const Px<M>& c, const Px<M>& l1, 
 // The row phase of a block: NR input rows starting at row `row0` of the source level (each through REFLECT_101), row-filtered for the
 // output column `ox` of this lane, into hb[0 .. NR).  (pyr_down_block: NR = NR rows from 2 oy0 - 2; the fused level-0 + level-1 kernel
 // of pyrdown_l0.inc: 41 rows.)
-template <int M, int SK, int NR>
+template <int M, int SK, int NR, bool PLS = false>
 __device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& src, int ox, int row0, Px<M> (*hb)[WAVE]) {
     constexpr int RPW = (NR + PD_WAVES - 1) / PD_WAVES;
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
@@ -374,6 +406,9 @@ __device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& sr
             if constexpr (SK != SK_LEVEL) {
                 if (cB == cA + 1) rw[i] = src0_pair_issue<SK>(s0, cA, iy);
                 else rw[i].fast = false;
+            } else if constexpr (PLS) {
+                A[i] = load_px_planar<M>(src, cA, iy);
+                B[i] = load_px_planar<M>(src, cB, iy);
             } else {
                 A[i] = load_px<M, false>(src, cA, iy);
                 B[i] = load_px<M, false>(src, cB, iy);
@@ -395,13 +430,13 @@ __device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& sr
     }
 }
 
-template <int M, int SK>
+template <int M, int SK, bool PLS = false, bool PLD = false>
 __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by, Px<M> (*hb)[WAVE]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
-    pyr_down_rows<M, SK, PD_NR>(s0, src, ox, 2 * oy0 - 2, hb);
+    pyr_down_rows<M, SK, PD_NR, PLS>(s0, src, ox, 2 * oy0 - 2, hb);
     __syncthreads();
-    pyr_down_columns<M>(hb, dst, ox, oy0, lane, wv);
+    pyr_down_columns<M, PLD>(hb, dst, ox, oy0, lane, wv);
 }
 
 // pyrDown's column filter over five row-filtered rows + the 1/256 (the (v + 128) >> 8 of the 16-bit pyramid)
@@ -427,7 +462,7 @@ __device__ __forceinline__ Px<M> pyr_down_col5(const Px<M>& r0, const Px<M>& r1,
 }
 
 // the column filter of a block out of the row-filtered rows in LDS (after the block's barrier)
-template <int M>
+template <int M, bool PLD>
 __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv) {
     const int dw = dst.cols, dh = dst.rows;
     if (lane == 0 || lane == 63 || ox >= dw) return;
@@ -436,7 +471,8 @@ __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelB
         int ty = wv + PD_WAVES * i, oy = oy0 + ty;
         if (oy >= dh) break;
         const Px<M> o = pyr_down_col5<M>(hb[2 * ty][lane], hb[2 * ty + 1][lane], hb[2 * ty + 2][lane], hb[2 * ty + 3][lane], hb[2 * ty + 4][lane]);
-        store_px<M, false>(dst, ox, oy, o);
+        if constexpr (PLD) store_px_planar<M>(dst, ox, oy, o);
+        else store_px<M, false>(dst, ox, oy, o);
     }
 }
 
@@ -708,6 +744,8 @@ struct OutMat {  // the caller's blend() outputs
     int grp, gx, gy; // grp > 0: a 1-D launch in the XCD-aware block order of isx_device.hpp (xcd_block) over gx x gy blocks
     unsigned xmagic; // xcd_magic(grp, gx)
     int band;        // > 0: xcd_band_block's mapping, block rows per XCD band
+    int rec12;       // deferred cycle, k_collapse_roll runs the last step: out_1 holds dense 12-byte image records (no fourth dword nobody reads):
+                     // the level-1 step (k_collapse_gather, not FINE0) writes them, k_collapse_roll reads them
 };
 
 // saturate_cast<short / uchar>(float) = sat(cvRound(v)).  BOUNDED: the caller guarantees |v| < 2^31 (blends of CV_8UC3 / CV_16SC3 tiles
@@ -866,14 +904,15 @@ struct TileSet {                 // per-tile views of one pyramid level pair, in
 
 static_assert(sizeof(TileSet) + 2 * sizeof(LevelBuf) + sizeof(OutMat) <= 4096, "k_collapse_gather's arguments exceed the kernel-argument limit");
 
-template <int M, int SK>
+// PLS: the source level is PLANAR (level 1 of the deferred cycle, see load_px_planar)
+template <int M, int SK, bool PLS = false>
 __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
     if ((int)blockIdx.x * PD_OW >= dst.cols || (int)blockIdx.y * PD_TY >= dst.rows || (int)blockIdx.x < ts.bx_lo[t] || (int)blockIdx.x >= ts.bx_hi[t]) return;
     __shared__ Px<M> hb[PD_NR][WAVE];
-    pyr_down_block<M, SK>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y, hb);
+    pyr_down_block<M, SK, PLS>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y, hb);
 }
 
 // top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t})) at level-L pixel (x, y); the tile rectangles of
@@ -1044,7 +1083,15 @@ __device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const in
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     if constexpr (FINE0) rw[s][dy] = src0_pair_issue<SK>(s0, 2 * lcx, 2 * lcy + dy);
-                    else { gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy); }
+                    else {
+                        if constexpr (M == M_F32 || M == M_I16) {
+                            if (ts.fine[t].wgt != nullptr) {     // planar level 1 (block-uniform)
+                                gg[s][dy][0] = load_px_planar<M>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px_planar<M>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy);
+                                continue;
+                            }
+                        }
+                        gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy);
+                    }
                 }
             }
         if constexpr (!DMA_T || !DMA_O) {
@@ -1154,6 +1201,9 @@ __device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const in
             if constexpr (FINE0) {
                 if (allin) write_final_pair<M, BOUNDED, true>(out, 2 * cx, fy, dd[0], dd[1]);
                 else write_final_pair<M, BOUNDED>(out, 2 * cx, fy, dd[0], dd[1]);
+            } else if (out.rec12) {
+                const unsigned i12 = __umul24((unsigned)fy, (unsigned)fine_out.cols) + 2u * (unsigned)cx;
+                store_rgb12<M>(fine_out, i12, dd[0]); store_rgb12<M>(fine_out, i12 + 1u, dd[1]);
             } else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
         }
     } else {
@@ -1185,7 +1235,10 @@ __device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const in
         if constexpr (FINE0) {
             if (allin) write_final_pair<M, false, true>(out, 2 * cx, fy, dd[0], dd[1]);
             else write_final_pair<M>(out, 2 * cx, fy, dd[0], dd[1]);
-        } else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
+        } else if (out.rec12) {
+                const unsigned i12 = __umul24((unsigned)fy, (unsigned)fine_out.cols) + 2u * (unsigned)cx;
+                store_rgb12<M>(fine_out, i12, dd[0]); store_rgb12<M>(fine_out, i12 + 1u, dd[1]);
+            } else { store_px<M, OUT_DST>(fine_out, 2 * cx, fy, dd[0]); store_px<M, OUT_DST>(fine_out, 2 * cx + 1, fy, dd[1]); }
     }
     }
     PT(10);                     // epilogue: normalise, pyrUp of out, convert, stores issued
@@ -1220,10 +1273,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 #include "collapse_top.inc"
 
 // level 0 -> 1 of every recorded tile: CV_8UC3 and CV_16SC3 tiles through k_pyr_down0 (ISX_PD0=0: the general kernel, for A/B runs)
+// planar: level 1 is written as 12-byte image records + a weight plane (ts.coarse[t].wgt set by the caller; k_pyr_down0 only)
 template <int M, int SK>
-int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st) {
+int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar = false) {
     static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
     if constexpr (SK == SK_U8 || SK == SK_S16) {
+        if constexpr (M == M_F32 || M == M_I16) {
+            if (planar) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK, true>), grid, dim3(512), 0, ts); return ISX_OK; }
+        }
         if (fast) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK>), grid, dim3(512), 0, ts); return ISX_OK; }
     }
     ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
@@ -1817,27 +1874,42 @@ int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& co
     *done = true;
     return ISX_OK;
 }
-template <int M, int SK>
-int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, const LevelBuf& coarse, const OutMat& o, int cx_lo, int cx_hi, double bytes, bool* done) {
+// which instantiation runs the last step: 0 = none (k_collapse_gather), else 10 R + MAXT
+template <int SK>
+int roll_variant(const TileSet& ts, const LevelBuf& coarse, int cx_lo, int cx_hi) {
     static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
     static const int rsel = [] { const char* e = getenv("ISX_ROLL_R"); return e ? atoi(e) : 2; }();      // rows per wave (tuning runs only)
-    *done = false;
     if constexpr (SK == SK_U8 || SK == SK_S16) {
-        if (!mode || coarse.cols < 2 || (unsigned long long)coarse.rows * coarse.cols * 16ull >= (1ull << 32)) return ISX_OK;
+        if (!mode || coarse.cols < 2 || (unsigned long long)coarse.rows * coarse.cols * 16ull >= (1ull << 32)) return 0;
         for (int t = 0; t < ts.n; ++t)
             if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].rows < 2 || ts.s0[t].iend == 0u ||      // iend != 0: a CV_8UC3 / CV_16SC3 tile below 2 GiB, 32-bit offsets
-                (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return ISX_OK;
+                (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return 0;
+        if (cdiv(cx_hi - cx_lo, RL_CW) <= 0 || coarse.rows <= 0) return 0;
         // two rows per wave while at most two tiles reach a strip (a pair, a row of tiles with narrow overlaps); a third slot
         // for panoramas whose tiles overlap their second neighbours (BASELINE config 5); k_collapse_gather beyond that
         // ... and two rows with a third slot (round 4: 4 waves per SIMD instead of 5, still faster than one-row strips - config 5's last step
         // 0.704 -> 0.654 ms; ISX_ROLL_R23=0: the one-row form, for A/B runs)
         static const bool r23 = [] { const char* e = getenv("ISX_ROLL_R23"); return !(e && e[0] == '0'); }();
         const int most2 = rsel != 1 ? roll_max_tiles(ts, coarse, cx_lo, cx_hi, 2) : 99;
-        if (most2 <= 2) return launch_collapse_roll_r<M, SK, 2, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
-        if (r23 && most2 <= 3) return launch_collapse_roll_r<M, SK, 2, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        if (most2 <= 2) return 22;
+        if (r23 && most2 <= 3) return 23;
         const int most = roll_max_tiles(ts, coarse, cx_lo, cx_hi, 1);
-        if (most <= 2) return launch_collapse_roll_r<M, SK, 1, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
-        if (most <= 3) return launch_collapse_roll_r<M, SK, 1, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+        if (most <= 2) return 12;
+        if (most <= 3) return 13;
+    }
+    return 0;
+}
+template <int M, int SK>
+int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, const LevelBuf& coarse, const OutMat& o, int cx_lo, int cx_hi, double bytes, int variant, bool* done) {
+    *done = false;
+    if constexpr (SK == SK_U8 || SK == SK_S16) {
+        switch (variant) {
+            case 22: return launch_collapse_roll_r<M, SK, 2, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 23: return launch_collapse_roll_r<M, SK, 2, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 12: return launch_collapse_roll_r<M, SK, 1, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 13: return launch_collapse_roll_r<M, SK, 1, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+            default: break;
+        }
     }
     return ISX_OK;
 }
@@ -1891,12 +1963,32 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         prod_hi[k] = std::min(std::max(need_hi[k], 2 * (prod_hi[k + 1] - 1) + 3), d[k].cols);
     }
     const double gin0 = src_px_bytes(SK) + 1.0;
+    // 0. Which kernel will run the last step?  Known before anything is launched, because two formats follow from it (round 4): when it is
+    //    k_collapse_roll and level 1 of the collapsed pyramid comes from k_collapse_gather (L = 2, or L >= 5 with k_collapse_top above it),
+    //    out_1 is written as dense 12-byte image records (OutMat::rec12) and level 1 of every tile PLANAR (load_px_planar) - the last step
+    //    reads the image channels of both and never their fourth dword: 26.9 MB of 265 per 4K pair fetched for nothing with 16-byte records.
+    //    ISX_OUT12=0 / ISX_G1P=0: the 16-byte records (A/B runs).
+    int roll_var = 0;
+    bool rec12 = false, g1_planar = false;
+    if (L >= 2) {
+        static const bool top_on0 = [] { const char* e = getenv("ISX_TOP"); return !(e && e[0] == '0'); }();
+        static const bool out12_on = [] { const char* e = getenv("ISX_OUT12"); return !(e && e[0] == '0'); }();
+        static const bool g1p_on = [] { const char* e = getenv("ISX_G1P"); return !(e && e[0] == '0'); }();
+        TileSet ts1 = base(0);
+        for (int t = 0; t < n; ++t) { ts1.fine[t] = b->tiles[t].g[0]; ts1.coarse[t] = b->tiles[t].g[1]; }
+        roll_var = roll_variant<SK>(ts1, d[1], need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols));
+        const int D0 = std::min(TOP_DMAX, L - 1);
+        const bool lvl1_by_gather = !(top_on0 && D0 >= 2) || L - D0 >= 2;
+        rec12 = roll_var != 0 && lvl1_by_gather && out12_on;
+        g1_planar = roll_var != 0 && lvl1_by_gather && g1p_on && (M == M_F32 || M == M_I16);
+    }
+    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + (size_t)g.rows * g.cols * 12u); return g; };
     // 1. Gaussian chains: one launch per level for all tiles.  (Per-tile chains on side streams, started
     //    by feed() to overlap with the next tile's VALU-bound warp, were measured: no gain — a kernel that
     //    fills every wave slot leaves nothing for a concurrent one — so the simpler form stays.)
     bool all_on_side = b->chain_on_side.size() >= (size_t)n;
     for (int t = 0; t < n && all_on_side; ++t) all_on_side = b->chain_on_side[t] != 0;
-    if (all_on_side) ISX_TRY(join_side_streams(b));
+    if (all_on_side) { ISX_TRY(join_side_streams(b)); g1_planar = false; }     // (chains launched by feed() wrote 16-byte records)
     for (int k = 0; k < L && !all_on_side; ++k) {
         TileSet ts = base(k);
         int maxc = 0, maxr = 0;
@@ -1904,6 +1996,8 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
             ts.fine[t] = r.g[k]; ts.coarse[t] = r.g[k + 1];
+            if (g1_planar && k == 0) ts.coarse[t] = planar_of(r.g[1]);
+            if (g1_planar && k == 1) ts.fine[t] = planar_of(r.g[1]);
             maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
             double share = 1.0;
             if (windowed) {   // the tile's columns of level k + 1 inside prod_{k+1}, as block columns of its own grid
@@ -1915,8 +2009,10 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             bytes += share * ((double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec));
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
-        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st)));
-        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar)));
+        else if (k == 1 && g1_planar) {
+            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts);
+        } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
         // the full-size level-0 kernel is behind us: from here to the last collapse step the launches are small
         if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
     }
@@ -1967,6 +2063,8 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
             ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
+            if (g1_planar && k == 2) ts.fine[t] = planar_of(r.g[1]);
+            if (g1_planar && k == 1) ts.coarse[t] = planar_of(r.g[1]);
             if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;                        // + the weights of G_L
             bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
                    + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
@@ -1974,6 +2072,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
         OutMat o = out;
         o.bx0 = bx_lo;
+        o.rec12 = (rec12 && k <= 2) ? 1 : 0;      // k = 2 writes out_1, k = 1 reads it
         // last two steps (levels 0 and 1; the level-1 step runs at the fabric's rate: 48.5 -> 46.2 us for the four upper steps; no gain
         // from level 2 up): XCD-aware block order in groups of 2 block rows (see OutMat).  Measured on the 4K pair (tools/measure_traffic.py,
         // profiles/round2_xcd_order.txt): fabric traffic per launch 383 MB in plain row-major order, 282 MB with groups of 2, 268 with 4,
@@ -1987,7 +2086,10 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             bytes = bytes * frac + (double)out.rows * (need_hi[0] - need_lo[0]) * (out.img_f32 == 1 ? 13.0 : (out.img_f32 == 2 ? 4.0 : 7.0));   // result + mask
             if (k != L) {
                 bool done = false;
-                ISX_TRY((launch_collapse_roll<M, SK>(b, st, ts, d[1], out, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, &done)));
+                OutMat o1 = out;
+                o1.rec12 = rec12 ? 1 : 0;
+                ISX_TRY((launch_collapse_roll<M, SK>(b, st, ts, d[1], o1, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, roll_var, &done)));
+                ISX_CHECK_ARG(done || !(rec12 || g1_planar), ISX_ERR_STATE, "blend: the last step's kernel was planned as k_collapse_roll and did not run");
                 if (done) { b->path_last = 3; continue; }
             }
             b->path_last = 2;
@@ -2762,7 +2864,7 @@ static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* 
     o.img = (unsigned char*)b->st_out.d.data; o.img_step = b->st_out.d.step; o.img_f32 = dst->type == ISX_32FC3 ? 1 : (dst->type == ISX_8UC3 ? 2 : 0);
     o.mask = dst_mask ? (unsigned char*)b->st_outmask.d.data : nullptr;
     o.mask_step = dst_mask ? b->st_outmask.d.step : 0;
-    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0; o.xmagic = 0; o.band = 0;
+    o.rows = b->fh; o.cols = b->fw; o.bx0 = 0; o.grp = 0; o.gx = 0; o.gy = 0; o.xmagic = 0; o.band = 0; o.rec12 = 0;
     if (windowed) {
         // the kernels keep addressing the mosaic's columns: the mats' origins move left by the window's first column (a multiple of
         // ISX_WINDOW_GRANULE, so every alignment is kept and a block of the last step starts exactly there), the right crop is the
