@@ -2195,6 +2195,41 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
         return bs[m]->tiles[(size_t)(t - first[m])];
     };
     const double gin0 = src_px_bytes(SK) + 1.0;
+    // 0. the last step as the rolling kernel when every mosaic qualifies (roll_variant's conditions, two tiles per strip at most) - decided
+    //    before anything is launched: level 1 then goes without its dead fourth dword, as in run_blend_deferred_t (rec12, planar G_1)
+    bool roll_ok = false;
+    unsigned roll_blocks = 0;
+    int r_grp[BATCH_MAX], r_gx[BATCH_MAX], r_gy[BATCH_MAX];
+    if (L >= 2) {
+        static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
+        const TileSet ts = base(0);
+        bool ok = mode != 0 && (SK == SK_U8 || SK == SK_S16);
+        for (int m = 0; m < nb && ok; ++m) {
+            const LevelBuf& c = d[m][1];
+            ok = c.cols >= 2 && (unsigned long long)c.rows * c.cols * 16ull < (1ull << 32);
+            TileSet one;
+            memset(&one, 0, sizeof(one));
+            one.n = first[m + 1] - first[m];
+            for (int t = 0; t < one.n && ok; ++t) {
+                const int g = first[m] + t;
+                const LevelBuf& g1 = tile_rec(g).g[1];
+                one.x_tl[t] = ts.x_tl[g]; one.y_tl[t] = ts.y_tl[g]; one.w[t] = ts.w[g]; one.h[t] = ts.h[g];
+                ok = g1.cols >= 2 && ts.s0[g].cols >= 2 && ts.s0[g].rows >= 2 && ts.s0[g].iend != 0u &&
+                     (unsigned long long)g1.rows * g1.cols * 16ull < (1ull << 32);
+            }
+            ok = ok && roll_max_tiles(one, c, 0, c.cols, 2) <= 2;
+            if (ok) {
+                const int nsx = cdiv(c.cols, RL_CW), nby = cdiv(cdiv(c.rows, 2), ROLL_WAVES), grp = std::max(2, nsx == 1 ? 2 : 1);
+                r_grp[m] = grp; r_gx[m] = nsx; r_gy[m] = nby;
+                roll_blocks = std::max(roll_blocks, xcd_band_blocks(grp, nsx, nby));
+            }
+        }
+        roll_ok = ok;
+    }
+    static const bool out12_on = [] { const char* e = getenv("ISX_OUT12"); return !(e && e[0] == '0'); }();
+    static const bool g1p_on = [] { const char* e = getenv("ISX_G1P"); return !(e && e[0] == '0'); }();
+    const bool rec12 = roll_ok && out12_on, g1_planar = roll_ok && g1p_on && (M == M_F32 || M == M_I16);
+    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + (size_t)g.rows * g.cols * 12u); return g; };
     // 1. Gaussian chains: one launch per level for every tile of every mosaic
     for (int k = 0; k < L; ++k) {
         TileSet ts = base(k);
@@ -2203,12 +2238,16 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
         for (int t = 0; t < nt; ++t) {
             const isx_blender::TileRec& r = tile_rec(t);
             ts.fine[t] = r.g[k]; ts.coarse[t] = r.g[k + 1];
+            if (g1_planar && k == 0) ts.coarse[t] = planar_of(r.g[1]);
+            if (g1_planar && k == 1) ts.fine[t] = planar_of(r.g[1]);
             maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
             bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), nt);
-        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st)));
-        else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar)));
+        else if (k == 1 && g1_planar) {
+            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts);
+        } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
         for (int m = 0; m < nb; ++m)
             if (k == bs[m]->mark_level && bs[m]->mark_event) ISX_HIP(hipEventRecord(bs[m]->mark_event, st));
     }
@@ -2223,49 +2262,30 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
         for (int t = 0; t < nt; ++t) {
             const isx_blender::TileRec& r = tile_rec(t);
             ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
+            if (g1_planar && k == 2) ts.fine[t] = planar_of(r.g[1]);
+            if (g1_planar && k == 1) ts.coarse[t] = planar_of(r.g[1]);
             if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;
             bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec)) + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);
         }
         for (int m = 0; m < nb; ++m) {
             bo.coarse_out[m] = d[m][k]; bo.fine_out[m] = d[m][k - 1]; bo.out[m] = outs[m];
             bo.out[m].bx0 = 0; bo.out[m].grp = 0; bo.out[m].band = 0;
+            bo.out[m].rec12 = (rec12 && k <= 2) ? 1 : 0;       // k = 2 writes out_1, k = 1 reads it
             if (k != L) bytes += (double)d[m][k].rows * d[m][k].cols * alg_d_rgb(prec);
             if (k == 1) bytes += (double)outs[m].rows * outs[m].cols * (outs[m].img_f32 == 1 ? 13.0 : (outs[m].img_f32 == 2 ? 4.0 : 7.0));
             else bytes += (double)d[m][k - 1].rows * d[m][k - 1].cols * alg_d_rgb(prec);
             gx = std::max(gx, cdiv(d[m][k].cols, WAVE)); gy = std::max(gy, cdiv(d[m][k].rows, UP_TY));
         }
-        if (k == 1 && k != L) {      // the last step: the rolling kernel when every mosaic qualifies (launch_collapse_roll's conditions)
-            static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
-            bool ok = mode != 0 && (SK == SK_U8 || SK == SK_S16);
-            unsigned nblk = 0;
-            for (int m = 0; m < nb && ok; ++m) {
-                const LevelBuf& c = d[m][1];
-                ok = c.cols >= 2 && (unsigned long long)c.rows * c.cols * 16ull < (1ull << 32);
-                TileSet one;
-                memset(&one, 0, sizeof(one));
-                one.n = first[m + 1] - first[m];
-                for (int t = 0; t < one.n && ok; ++t) {
-                    const int g = first[m] + t;
-                    one.x_tl[t] = ts.x_tl[g]; one.y_tl[t] = ts.y_tl[g]; one.w[t] = ts.w[g]; one.h[t] = ts.h[g];
-                    ok = ts.coarse[g].cols >= 2 && ts.s0[g].cols >= 2 && ts.s0[g].rows >= 2 && ts.s0[g].iend != 0u &&
-                         (unsigned long long)ts.coarse[g].rows * ts.coarse[g].cols * 16ull < (1ull << 32);
-                }
-                ok = ok && roll_max_tiles(one, c, 0, c.cols, 2) <= 2;
-                if (ok) {
-                    const int nsx = cdiv(c.cols, RL_CW), nby = cdiv(cdiv(c.rows, 2), ROLL_WAVES), grp = std::max(2, nsx == 1 ? 2 : 1);
-                    OutMat& o = bo.out[m];
-                    o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx); o.band = cdiv(nby, 8);
-                    nblk = std::max(nblk, xcd_band_blocks(grp, nsx, nby));
-                }
+        if (k == 1 && roll_ok) {      // the last step as the rolling kernel (decided above)
+            for (int m = 0; m < nb; ++m) {
+                OutMat& o = bo.out[m];
+                o.grp = r_grp[m]; o.gx = r_gx[m]; o.gy = r_gy[m]; o.xmagic = xcd_magic(r_grp[m], r_gx[m]); o.band = cdiv(r_gy[m], 8);
             }
             if constexpr (SK == SK_U8 || SK == SK_S16) {
-                if (ok) {
-                    ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll_batch<M, SK, 2, 2>), dim3(nblk, 1, nb), dim3(64 * ROLL_WAVES), 0, ts, bo, 0);
-                    for (int m = 0; m < nb; ++m) bs[m]->path_last = 3;
-                    continue;
-                }
+                ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll_batch<M, SK, 2, 2>), dim3(roll_blocks, 1, nb), dim3(64 * ROLL_WAVES), 0, ts, bo, 0);
+                for (int m = 0; m < nb; ++m) bs[m]->path_last = 3;
+                continue;
             }
-            for (int m = 0; m < nb; ++m) { bo.out[m].grp = 0; bo.out[m].band = 0; }
         }
         dim3 grid(gx, gy, nb);
         if (k <= 2 && gy >= 16) {     // the XCD-aware block order of the single path (groups of 2 block rows), every mosaic with its own extent

@@ -1,0 +1,33 @@
+"""Level 1 of the deferred cycle has two layouts (round 4): 16-byte records, and - when k_collapse_roll runs the last step - dense 12-byte
+image records for out_1 plus PLANAR tile levels (12-byte image records + a weight plane).  The layout is chosen per process
+(ISX_OUT12 / ISX_G1P), so the comparison runs tests/helpers/level1_formats_digest.py in two child processes: every blend of its set
+(single and batched chains, three precisions, both tile types, 2 / 5 / 7 bands, a column window) must hash the same in both.  (That
+each of them equals the oracle is what the rest of the suite shows with the defaults.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "level1_formats_digest.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [ln for ln in r.stdout.splitlines() if ln.split(" ")[0] in ("single", "batch", "window")]
+
+
+def test_level1_layouts_give_the_same_bits(gpu):
+    new = _run({"ISX_OUT12": "1", "ISX_G1P": "1"})
+    old = _run({"ISX_OUT12": "0", "ISX_G1P": "0"})
+    only_out = _run({"ISX_OUT12": "1", "ISX_G1P": "0"})
+    only_g1 = _run({"ISX_OUT12": "0", "ISX_G1P": "1"})
+    assert len(new) > 100 and len(new) == len(old)
+    # the last step of most of the set is k_collapse_roll (path 3): the set exercises the new layouts
+    assert sum(1 for ln in new if ln.startswith("single") and ln.split(" ")[6] == "collapse_roll") > 60
+    for a, b, c, d in zip(new, old, only_out, only_g1):
+        assert a == b == c == d, (a, b, c, d)
