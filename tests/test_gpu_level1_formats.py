@@ -26,8 +26,8 @@ def test_level1_layouts_give_the_same_bits(gpu):
     old = _run({"ISX_OUT12": "0", "ISX_G1P": "0"})
     only_out = _run({"ISX_OUT12": "1", "ISX_G1P": "0"})
     only_g1 = _run({"ISX_OUT12": "0", "ISX_G1P": "1"})
-    assert len(new) > 100 and len(new) == len(old)
+    assert len(new) >= 66 and len(new) == len(old) == len(only_out) == len(only_g1)
     # the last step of most of the set is k_collapse_roll (path 3): the set exercises the new layouts
-    assert sum(1 for ln in new if ln.startswith("single") and ln.split(" ")[6] == "collapse_roll") > 60
+    assert sum(1 for ln in new if ln.startswith("single") and ln.split(" ")[6] == "collapse_roll") >= 36
     for a, b, c, d in zip(new, old, only_out, only_g1):
         assert a == b == c == d, (a, b, c, d)
