@@ -118,11 +118,11 @@ class MultiBandBlender:
         return w.value, h.value
 
     def last_path(self):
-        """isx_blender_last_path: which kernels the last blend() ran - {"cycle": eager | deferred | deferred_batched, "last_step": none |
+        """isx_blender_last_path: which kernels the last blend() ran - {"cycle": eager | deferred | deferred_batched | deferred_strips, "last_step": none |
         collapse | collapse_gather | collapse_roll}."""
         c, k = C.c_int(), C.c_int()
         check(self._lib.isx_blender_last_path(self._h, C.byref(c), C.byref(k)))
-        return {"cycle": ("eager", "deferred", "deferred_batched")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
+        return {"cycle": ("eager", "deferred", "deferred_batched", "deferred_strips")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
 
     def level(self, i):
         """Accumulated destination pyramid level i (parity tests): (laplacian HxWx3, weight HxW)."""

@@ -893,6 +893,7 @@ __global__ __launch_bounds__(256) void k_collapse(LevelBuf coarse, LevelBuf fine
 // eager path (0 + a == a exactly), so the results are identical.
 // ------------------------------------------------------------------------------------------------
 constexpr int DEF_MAX = 20;     // kernel arguments hold one TileSet: 20 tiles keep a launch's argument block below the 4 KB limit
+constexpr int DEF_REC_MAX = 4096;   // tiles a deferred cycle records; with more than DEF_MAX of them blend() works in column strips (run_blend_deferred_strips)
 struct TileSet {                 // per-tile views of one pyramid level pair, indexed by the (uniform) tile id
     int n;
     Src0 s0[DEF_MAX];            // level-0 view (used where the fine / source level is level 0)
@@ -2112,12 +2113,87 @@ int run_blend_deferred(isx_blender* b, const OutMat& out) {
     }
 }
 
+// A deferred cycle of MORE than DEF_MAX tiles (a long panorama: BASELINE config 4's 64 tiles in one mosaic): the result is produced in column
+// strips, each by the deferred chain over the tiles that can reach it - the rule and the machinery of isx_blender_set_window (every strip equals
+// the same columns of the whole blend bit for bit, tests/test_gpu_strips.py), applied by the library itself.  Strips are multiples of
+// ISX_WINDOW_GRANULE wide and as wide as DEF_MAX tiles allow (greedy from the left); a tile that reaches several strips has the columns of its
+// Gaussian levels each strip needs produced once per strip.  *done = false: some 128-column strip is reached by more than DEF_MAX tiles (tiles
+// stacked in many rows) - the caller falls back to the eager cycle.
+template <int M>
+int run_blend_deferred_strips(isx_blender* b, const OutMat& out, bool* done) {
+    *done = false;
+    const int L = b->num_bands;
+    const bool user_win = b->win_x1 > b->win_x0;
+    const int X0 = user_win ? b->win_x0 : 0, X1 = user_win ? std::min(b->win_x1, b->fw) : b->fw;
+    auto reach = [&](int x0, int x1, std::vector<int>* idx) {      // mosaic.tiles_for_window
+        int lo = x0, hi = std::min(x1, b->dst[0].cols), cnt = 0;
+        std::vector<char> hit(b->tiles.size(), 0);
+        for (int k = 0; k <= L; ++k) {
+            if (k > 0) { lo = std::max(lo / 2 - 1, 0); hi = std::min((hi - 1) / 2 + 2, b->dst[k].cols); }
+            for (size_t t = 0; t < b->tiles.size(); ++t) {
+                const isx_blender::TileRec& r = b->tiles[t];
+                if ((r.x_tl >> k) < hi && ((r.x_tl + r.width) >> k) > lo) hit[t] = 1;
+            }
+        }
+        for (size_t t = 0; t < hit.size(); ++t)
+            if (hit[t]) { ++cnt; if (idx) idx->push_back((int)t); }
+        return cnt;
+    };
+    std::vector<std::pair<int, int>> wins;
+    for (int x = X0; x < X1;) {
+        int e = std::min(x + ISX_WINDOW_GRANULE, X1);
+        if (reach(x, e, nullptr) > DEF_MAX) return ISX_OK;
+        while (e < X1 && reach(x, std::min(e + ISX_WINDOW_GRANULE, X1), nullptr) <= DEF_MAX) e = std::min(e + ISX_WINDOW_GRANULE, X1);
+        wins.emplace_back(x, e);
+        x = e;
+    }
+    ISX_TRY(join_side_streams(b));       // chains that feed() started wrote whole levels of single tiles: the strips produce their own columns
+    std::vector<isx_blender::TileRec> all;
+    std::vector<char> on_side;
+    all.swap(b->tiles);
+    on_side.swap(b->chain_on_side);
+    const int wx0 = b->win_x0, wx1 = b->win_x1;
+    int rc = ISX_OK, last = 0;
+    for (size_t j = 0; j < wins.size() && rc == ISX_OK; ++j) {
+        std::vector<int> idx;
+        b->tiles.swap(all);
+        reach(wins[j].first, wins[j].second, &idx);
+        b->tiles.swap(all);
+        b->tiles.clear();
+        for (int t : idx) b->tiles.push_back(all[(size_t)t]);
+        OutMat o = out;
+        o.cols = std::min(wins[j].second, b->fw);
+        if (b->tiles.empty()) {          // no tile reaches the strip: Blender::blend zeroes what no weight covers (W:313)
+            b->tiles.push_back(all[0]);
+        }
+        b->win_x0 = wins[j].first; b->win_x1 = wins[j].second;
+        rc = run_blend_deferred<M>(b, o);
+        last = std::max(last, b->path_last);
+    }
+    b->tiles.swap(all);
+    b->chain_on_side.swap(on_side);
+    b->win_x0 = wx0; b->win_x1 = wx1;
+    ISX_TRY(rc);
+    b->path_cycle = 3; b->path_last = last;
+    *done = true;
+    return ISX_OK;
+}
+
 template <int M>
 int run_blend(isx_blender* b, const OutMat& out) {
     hipStream_t st = b->stream;
     const int L = b->num_bands, prec = M;
     LevelBuf* d = b->dst;
-    if (b->level0_pending) return run_blend_deferred<M>(b, out);
+    if (b->level0_pending) {
+        if (b->tiles.size() <= (size_t)DEF_MAX) return run_blend_deferred<M>(b, out);
+        static const bool strips_on = [] { const char* e = getenv("ISX_STRIPS"); return !(e && e[0] == '0'); }();    // ISX_STRIPS=0: the eager cycle, as before round 4 (A/B runs)
+        bool done = false;
+        if (strips_on) ISX_TRY(run_blend_deferred_strips<M>(b, out, &done));
+        if (done) return ISX_OK;
+        ISX_CHECK_ARG(b->win_x1 <= b->win_x0, ISX_ERR_UNSUPPORTED, "blend: more than %d tiles reach a %d-column strip of the window - a column window needs the deferred cycle",
+                      DEF_MAX, ISX_WINDOW_GRANULE);
+        ISX_TRY(flush_deferred(b));      // the cycle continues eagerly
+    }
     b->path_cycle = 0; b->path_last = L >= 1 ? 1 : 0;
     if (L == 0) {
         dim3 grid(cdiv(d[0].cols, 64), cdiv(d[0].rows, 4));
@@ -2547,7 +2623,7 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     const int sk = src_kind_of(img->type);
     const int L0 = b->num_bands;
     const bool can_defer = b->deferred && L0 >= 1 && L0 <= ACC_MAXL && !b->cleared &&
-                           (b->tiles.empty() ? b->fed.empty() : b->level0_pending) && b->tiles.size() < (size_t)DEF_MAX &&
+                           (b->tiles.empty() ? b->fed.empty() : b->level0_pending) && b->tiles.size() < (size_t)DEF_REC_MAX &&
                            (b->tiles.empty() || b->tiles[0].sk == sk);
     if (!can_defer) ISX_TRY(flush_deferred(b));
     const size_t slot = b->tiles.size();

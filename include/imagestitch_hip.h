@@ -272,7 +272,8 @@ int isx_blender_set_window(isx_blender* b, int x0, int x1);
 int isx_blender_result_size(isx_blender* b, int* width, int* height);
 /* Which code path the last isx_blender_blend / _blend_batch of a multi-band blender took - the fast kernels have limits (tile type, tiles
  * per place, tile count: DESIGN.md §3) and nothing else says which side of them a blend ran on.  cycle: 0 eager (the destination pyramid),
- * 1 deferred, 2 deferred inside a batched chain; last_step: the kernel of the last collapse step - 0 none (a 0-band blend), 1 k_collapse,
+ * 1 deferred, 2 deferred inside a batched chain, 3 deferred in column strips (more than 20 recorded tiles: the library cuts the result into
+ * strips that at most 20 tiles reach and runs the deferred chain per strip - bit-identical to the whole blend); last_step: the kernel of the last collapse step - 0 none (a 0-band blend), 1 k_collapse,
  * 2 k_collapse_gather, 3 k_collapse_roll.  Either pointer may be NULL.                                                          */
 int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step);
 /* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast
