@@ -241,8 +241,10 @@ int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* 
  * feed()/feed_u8() must stay valid and unmodified until blend() returns (OpenCV's feed() consumes
  * its inputs immediately — the reference clears the fed images before blend(), W:305-308 — so this
  * is not the default).  Host mats are staged in per-tile device buffers owned by the blender:
- * nothing changes for them.  At most 20 tiles of one type are deferred; beyond that, and when
- * isx_blender_debug_level is called, the recorded tiles are replayed through the eager path.
+ * nothing changes for them.  A launch's arguments hold 20 tiles: a cycle of more tiles (up to 4096, one type) is blended in column strips
+ * that at most 20 tiles reach, each by the same chain and bit-identical to the whole blend (isx_blender_last_path: cycle 3); when some
+ * 128-column strip is reached by more than 20 tiles, when a tile of another type is fed, and when isx_blender_debug_level is called,
+ * the recorded tiles are replayed through the eager path.
  * on = 2 keeps OpenCV's contract: feed() takes a private copy of every DEVICE mat it records (one device-to-device
  * pass on the handle's stream, 4 B/px for a CV_8UC3 tile + mask), so the caller may release or overwrite the fed
  * mats as soon as feed() returns - the drop-in mode for callers written against cv::detail::Blender (W:286-308). */
