@@ -2125,28 +2125,38 @@ int run_blend_deferred_strips(isx_blender* b, const OutMat& out, bool* done) {
     const int L = b->num_bands;
     const bool user_win = b->win_x1 > b->win_x0;
     const int X0 = user_win ? b->win_x0 : 0, X1 = user_win ? std::min(b->win_x1, b->fw) : b->fw;
-    auto reach = [&](int x0, int x1, std::vector<int>* idx) {      // mosaic.tiles_for_window
-        int lo = x0, hi = std::min(x1, b->dst[0].cols), cnt = 0;
-        std::vector<char> hit(b->tiles.size(), 0);
-        for (int k = 0; k <= L; ++k) {
-            if (k > 0) { lo = std::max(lo / 2 - 1, 0); hi = std::min((hi - 1) / 2 + 2, b->dst[k].cols); }
-            for (size_t t = 0; t < b->tiles.size(); ++t) {
-                const isx_blender::TileRec& r = b->tiles[t];
-                if ((r.x_tl >> k) < hi && ((r.x_tl + r.width) >> k) > lo) hit[t] = 1;
-            }
-        }
-        for (size_t t = 0; t < hit.size(); ++t)
-            if (hit[t]) { ++cnt; if (idx) idx->push_back((int)t); }
-        return cnt;
-    };
+    // Which tiles can reach the columns [x0, x1) of the result?  mosaic.tiles_for_window's rule - the tile's fed rectangle meets, at some level k,
+    // the columns need_k of that level the window depends on (need_k = need_{k-1} halved and widened by pyrUp's one column on either side) - bounded
+    // from outside by ONE interval per tile: need_k lies within (x0 / 2^k - 3, x1 / 2^k + 3), so a tile that reaches the window has
+    // x_tl - 4 * 2^L < x1 and x0 < x_tl + width + 3 * 2^L.  Tiles inside the interval that do not reach the window change none of its pixels (every
+    // input of a pixel of need_{k-1} lies in need_k): a superset is as exact as the set itself, and planning is interval counting.
+    const int n_all = (int)b->tiles.size(), m5 = 5 << L, m3 = 3 << L;
+    std::vector<std::pair<int, int>> iv((size_t)n_all);            // (lo, hi): the window [x0, x1) takes the tile iff x0 < hi && x1 > lo
+    for (int t = 0; t < n_all; ++t) iv[(size_t)t] = std::make_pair(b->tiles[(size_t)t].x_tl - m5, b->tiles[(size_t)t].x_tl + b->tiles[(size_t)t].width + m3);
+    std::vector<int> by_lo((size_t)n_all);
+    for (int t = 0; t < n_all; ++t) by_lo[(size_t)t] = t;
+    std::sort(by_lo.begin(), by_lo.end(), [&](int a, int c) { return iv[(size_t)a].first < iv[(size_t)c].first; });
     std::vector<std::pair<int, int>> wins;
     for (int x = X0; x < X1;) {
-        int e = std::min(x + ISX_WINDOW_GRANULE, X1);
-        if (reach(x, e, nullptr) > DEF_MAX) return ISX_OK;
-        while (e < X1 && reach(x, std::min(e + ISX_WINDOW_GRANULE, X1), nullptr) <= DEF_MAX) e = std::min(e + ISX_WINDOW_GRANULE, X1);
+        // the window starts at x and grows until the (DEF_MAX + 1)-th tile (in the order of their intervals' left ends, those that end at or before x skipped) begins
+        int cnt = 0, limit = X1;
+        for (int q = 0; q < n_all; ++q) {
+            const std::pair<int, int>& v = iv[(size_t)by_lo[(size_t)q]];
+            if (v.second <= x) continue;
+            if (++cnt > DEF_MAX) { limit = std::max(v.first, 0); break; }
+        }
+        int e = X1;
+        if (limit < X1) {
+            e = (limit / ISX_WINDOW_GRANULE) * ISX_WINDOW_GRANULE;      // x1 > lo is strict: a window ending AT the tile's left end does not take it
+            if (e <= x) return ISX_OK;                                  // more than DEF_MAX tiles over the first granule: the caller goes eager
+        }
         wins.emplace_back(x, e);
         x = e;
     }
+    auto reach = [&](int x0, int x1, std::vector<int>* idx) {
+        for (int t = 0; t < n_all; ++t)
+            if (x0 < iv[(size_t)t].second && x1 > iv[(size_t)t].first) idx->push_back(t);
+    };
     ISX_TRY(join_side_streams(b));       // chains that feed() started wrote whole levels of single tiles: the strips produce their own columns
     std::vector<isx_blender::TileRec> all;
     std::vector<char> on_side;
@@ -2156,9 +2166,7 @@ int run_blend_deferred_strips(isx_blender* b, const OutMat& out, bool* done) {
     int rc = ISX_OK, last = 0;
     for (size_t j = 0; j < wins.size() && rc == ISX_OK; ++j) {
         std::vector<int> idx;
-        b->tiles.swap(all);
         reach(wins[j].first, wins[j].second, &idx);
-        b->tiles.swap(all);
         b->tiles.clear();
         for (int t : idx) b->tiles.push_back(all[(size_t)t]);
         OutMat o = out;

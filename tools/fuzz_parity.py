@@ -526,8 +526,69 @@ def case_round4_calls(rng):
         assert np.array_equal(di.cpu().numpy(), owi) and np.array_equal(dm.cpu().numpy(), owm)
 
 
+
+
+def case_many_tiles(rng):
+    """Round 4: more than 20 tiles in one deferred multi-band cycle - blend() cuts the result into column strips that at most 20 tiles reach
+    (run_blend_deferred_strips), or falls back to the eager cycle when a strip is reached by more (tiles stacked); rows with random overlaps,
+    sometimes two rows, both tile types, every precision, references and private copies, sometimes inside a caller's column window."""
+    import torch
+    n = int(rng.integers(21, 45))
+    s16 = bool(rng.integers(0, 2))
+    rows = int(rng.integers(1, 3))
+    corners, sizes, x = [], [], 0
+    for i in range(n):
+        w, h = int(rng.integers(8, 90)), int(rng.integers(6, 70))
+        corners.append((x, int(rng.integers(-10, 11)) + (i % rows) * int(rng.integers(20, 60))))
+        sizes.append((w, h))
+        x += int(w * rng.uniform(0.0, 0.9))         # 0: a tile over its neighbour (many over one place)
+    bands, prec = int(rng.integers(1, 6)), int(rng.integers(0, 3))
+    mode = [True, "copy"][int(rng.integers(0, 2))]
+    mb = G.MultiBandBlender(False, bands, prec)
+    mb.set_deferred_level0(mode)
+    ob = O.MultiBand(bands, prec)
+    mb.prepare(corners, sizes)
+    ob.prepare(corners, sizes)
+    fw, _ = mb.result_size()
+    win = None
+    if fw > 400 and rng.integers(0, 3) == 0:
+        x0 = int(rng.integers(0, fw // 256)) * 128
+        x1 = min(x0 + int(rng.integers(1, 6)) * 128, (fw // 128) * 128)
+        if x1 > x0:
+            win = (x0, x1)
+            mb.set_window(x0, x1)
+    keep = []
+    for (w, h), c in zip(sizes, corners):
+        img = rng.integers(-3000, 3001, (h, w, 3)).astype(np.int16) if s16 else rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        mask = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        mask[rng.random((h, w)) < rng.uniform(0, 0.5)] = 0
+        mask[rng.random((h, w)) < rng.uniform(0, 0.7)] = 255
+        ob.feed(img.astype(np.int16), mask, c)
+        ti, tm = torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()
+        keep.append((ti, tm))
+        if s16:
+            mb.feed(ti, tm, c)
+        else:
+            mb.feed_u8(ti, tm, c)
+        if mode == "copy":
+            ti.fill_(1), tm.fill_(2)
+    f32 = prec != 0 and bool(rng.integers(0, 2))
+    try:
+        d, m = mb.blend(out_f32=f32)
+    except Exception as e:      # the one refusal of the path: a caller's window with more than 20 tiles over one 128-column strip (no eager cycle to fall back to)
+        if win and "more than 20 tiles reach" in str(e):
+            return "skip"
+        raise
+    d, m = d.cpu().numpy(), m.cpu().numpy()
+    od, om = ob.blend(f32)
+    if win:
+        od, om = od[:, win[0]:win[1]], om[:, win[0]:win[1]]
+    assert np.array_equal(m, om)
+    assert np.array_equal(d, od), (n, bands, prec, mode, win, mb.last_path(), np.argwhere(d != od)[:3])
+
+
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls]
+         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls, case_many_tiles]
 
 
 def run(budget, seed0, verbose=True):
