@@ -1458,7 +1458,9 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         w->sph_memo.push_back(e);
         return ISX_OK;
     }
-    if (!sync_free && w->roi_cache_on)
+    // (without isx_warper_set_roi_cache the list holds the LAST result only: the reference asks for the same ROI twice in a row - warp(img, K, R)
+    // then warp(mask, K, R), W:229,232 - and the second answer is the first one's, a pure function of the same arguments)
+    if (!sync_free)
         for (const auto& e : w->roi_cache)
             if (e.sw == sw && e.sh == sh && memcmp(&e.proj, &w->proj, sizeof(Proj)) == 0) {
                 std::copy(e.roi, e.roi + 4, roi);
@@ -1521,8 +1523,9 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     }
     if (mm) { mm[0] = tl_uf; mm[1] = tl_vf; mm[2] = br_uf; mm[3] = br_vf; }
     roi[0] = f2i_host(tl_uf); roi[1] = f2i_host(tl_vf); roi[2] = f2i_host(br_uf); roi[3] = f2i_host(br_vf);   // W:83-86
-    if (w->roi_cache_on) {
-        if (w->roi_cache.size() >= 16) w->roi_cache.erase(w->roi_cache.begin());
+    {
+        const size_t cap = w->roi_cache_on ? 16 : 1;
+        while (w->roi_cache.size() >= cap) w->roi_cache.erase(w->roi_cache.begin());
         isx_warper::RoiEntry e;
         memset(&e, 0, sizeof(e));
         e.proj = w->proj; e.sw = sw; e.sh = sh;
@@ -1786,7 +1789,7 @@ int isx_warper_set_gain(isx_warper* w, double gain) {
 int isx_warper_set_roi_cache(isx_warper* w, int on) {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_roi_cache: null warper");
     w->roi_cache_on = on != 0;
-    if (!on) w->roi_cache.clear();
+    if (!on) w->roi_cache.clear();      // (the last result is remembered again from the next call on)
     return ISX_OK;
 }
 

@@ -113,7 +113,8 @@ int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const 
 /* Opt-in: remember detectResultRoi's result per (K, R, scale, source size) - it is a pure function of them - so that a
  * fixed rig's repeated isx_warper_warp / _roi / _build_maps calls skip the GPU scan and its host round trip (the corner
  * must reach the host before the destination can be sized, W:148-150).  The spherical ROI (host code) is not cached.
- * Off by default: every call then computes its ROI as the reference does.                                           */
+ * Off by default: only the LAST result is then remembered - the reference asks for the same ROI twice in a row (warp(img, K, R), then
+ * warp(mask, K, R), W:229,232) and the second call returns the first one's answer; any other call computes its ROI as the reference does. */
 int isx_warper_set_roi_cache(isx_warper* w, int on);
 /* compensator->apply(i, corners[i], images_warped[i], masks_warped[i]) (W:241-244) folded into the fused tile warps that
  * follow (isx_warper_warp_with_mask / _roi / _planned with src_mask == NULL): every byte of the warped IMAGE becomes
