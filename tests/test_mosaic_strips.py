@@ -161,3 +161,36 @@ def test_strips_assemble_the_panorama_world2_gloo():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_one_interval_per_tile_bounds_the_reach_rule_from_outside():
+    """The library's own strips (run_blend_deferred_strips in csrc/blend.hip: a cycle of more than 20 tiles is blended in column strips) plan with
+    ONE interval per tile instead of the level-by-level rule: a window [x0, x1) takes a tile iff x0 < fx + fw + 3 * 2^L and x1 > fx - 5 * 2^L.  That
+    must be a SUPERSET of tiles_for_window (extra tiles change no pixel of the window, a missing one would): checked on random rigs and windows."""
+    rng = np.random.default_rng(12)
+    checked = 0
+    for _ in range(300):
+        n = int(rng.integers(2, 40))
+        bands = int(rng.integers(1, 8))
+        sizes = [(int(rng.integers(4, 900)), int(rng.integers(4, 300))) for _ in range(n)]
+        corners = [(int(rng.integers(-3000, 3000)), int(rng.integers(-100, 100))) for _ in range(n)]
+        c, s = np.asarray(corners), np.asarray(sizes)
+        tl, br = c.min(0), (c + s).max(0)
+        w, h = int(br[0] - tl[0]), int(br[1] - tl[1])
+        L = min(bands, int(np.ceil(np.log(float(max(w, h))) / np.log(2.0))))
+        m = 1 << L
+        roi = (int(tl[0]), int(tl[1]), w + (m - w % m) % m, h + (m - h % m) % m)
+        for _ in range(6):
+            x0 = int(rng.integers(0, max(w // 128, 1))) * 128
+            x1 = min(x0 + int(rng.integers(1, 12)) * 128, w)
+            if x1 <= x0:
+                continue
+            exact = set(mosaic.tiles_for_window(corners, sizes, bands, x0, x1))
+            bound = set()
+            for i in range(n):
+                fx, _, fw, _ = mosaic.feed_rect(roi, L, corners[i], sizes[i])
+                if x0 < fx + fw + 3 * m and x1 > fx - 5 * m:
+                    bound.add(i)
+            assert exact <= bound, (corners, sizes, bands, x0, x1, exact - bound)
+            checked += 1
+    assert checked > 1000
