@@ -124,6 +124,12 @@ class MultiBandBlender:
         check(self._lib.isx_blender_last_path(self._h, C.byref(c), C.byref(k)))
         return {"cycle": ("eager", "deferred", "deferred_batched", "deferred_strips")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
 
+    def feed_path(self):
+        """isx_blender_feed_path: how the last blend()'s tiles were fed in mode 2 - {"fused_tiles": n, "narrowed": none | confirmed | widened}."""
+        f, n = C.c_int(), C.c_int()
+        check(self._lib.isx_blender_feed_path(self._h, C.byref(f), C.byref(n)))
+        return {"fused_tiles": f.value, "narrowed": ("none", "confirmed", "widened")[n.value]}
+
     def level(self, i):
         """Accumulated destination pyramid level i (parity tests): (laplacian HxWx3, weight HxW)."""
         r, c = C.c_int(), C.c_int()

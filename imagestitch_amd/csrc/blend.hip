@@ -29,6 +29,7 @@
 #include "isx_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -1600,10 +1601,21 @@ struct isx_blender {
     std::vector<int4> fed;
     bool cleared = false;
     // deferred level 0: tiles recorded by feed(), consumed by blend()
-    struct TileRec { Src0 s0; int sk; LevelBuf g[MAX_LEVELS]; int x_tl, y_tl, width, height; };
+    // fused feed (k_feed_pd0, deferred mode 2): g1 = 0 level 1 not produced yet, 1 produced by feed() as 16-byte records, 2 produced PLANAR;
+    // narrow != 0: a CV_16SC3 tile whose private copy was written as CV_8UC3 (sk = SK_U8, fed_sk = SK_S16) with escape segments in `wide`
+    struct TileRec { Src0 s0; int sk; LevelBuf g[MAX_LEVELS]; int x_tl, y_tl, width, height;
+                     int fed_sk = 0, g1 = 0, narrow = 0; unsigned char* wide = nullptr; size_t wide_step = 0; unsigned char* chunk = nullptr; int nbx = 0; };
     bool deferred = false;          // requested by the caller
     bool deferred_copy = false;     // ... with private copies of the fed device mats (OpenCV's contract kept)
     std::vector<std::unique_ptr<DevBuf>> tile_copy_img, tile_copy_mask;
+    std::vector<std::unique_ptr<DevBuf>> tile_copy_wide, tile_chunk;     // narrowed tiles: the CV_16SC3 escape buffer and the segment map
+    DevBuf feed_state;              // one device word per tile slot: "a segment of the narrowed copy escaped" (k_feed_pd0 sets, k_feed_publish clears)
+    int* feed_pin = nullptr;        // pinned host words {sequence number, violation seen} that k_feed_publish writes
+    int feed_seq = 0;
+    int narrow_pending = 0;         // recorded tiles of this cycle whose narrowed copies have not been confirmed (0 .. tiles.size())
+    bool narrow_published = false;  // k_feed_publish of this cycle has been enqueued
+    bool narrow_off = false;        // a cycle was violated once: this blender keeps CV_16SC3 copies from now on
+    bool fused_cycle = false;       // some tile of this cycle came through k_feed_pd0 (level 1 produced by feed())
     bool level0_pending = false;    // recorded tiles have not been accumulated into dst[0] yet
     std::vector<TileRec> tiles;
     std::vector<std::unique_ptr<DevBuf>> tile_arenas;      // one per recorded tile (their pyramids must outlive feed)
@@ -1622,6 +1634,7 @@ struct isx_blender {
     // able to say which side of them it ran on.  cycle: 0 eager, 1 deferred, 2 deferred as part of a batched chain; last: the kernel of
     // the last collapse step - 0 none (a 0-band blend, Feather, NO), 1 k_collapse, 2 k_collapse_gather, 3 k_collapse_roll
     int path_cycle = 0, path_last = 0;
+    int path_fused = 0, path_narrow = 0;   // isx_blender_feed_path: tiles of the last blend() that came through k_feed_pd0; 0 none narrowed, 1 narrowed copies confirmed, 2 widened
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_ready, ev_done;
     std::vector<char> chain_on_side;   // per recorded tile: its chain was launched by feed()
@@ -1692,6 +1705,85 @@ double covered_px(const isx_blender* b, int x, int y, int w, int h) {
                 if (xs[i] >= q.x && xs[i + 1] <= q.z && ys[j] >= q.y && ys[j + 1] <= q.w) { area += (double)(xs[i + 1] - xs[i]) * (ys[j + 1] - ys[j]); break; }
         }
     return area;
+}
+
+// k_feed_pd0 for (precision, tile type, level-1 layout, copy format)
+template <int M, int SK>
+int launch_feed_pd0_t(bool planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
+    if constexpr (SK == SK_S16) {
+        if (narrow) {
+            if constexpr (M == M_F32 || M == M_I16) {
+                if (planar) { ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, true, CF_NARROW>), grid, dim3(512), 0, s0, g1, fc); return ISX_OK; }
+            }
+            ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, false, CF_NARROW>), grid, dim3(512), 0, s0, g1, fc);
+            return ISX_OK;
+        }
+    }
+    if constexpr (M == M_F32 || M == M_I16) {
+        if (planar) { ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, true, CF_SAME>), grid, dim3(512), 0, s0, g1, fc); return ISX_OK; }
+    }
+    ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, false, CF_SAME>), grid, dim3(512), 0, s0, g1, fc);
+    return ISX_OK;
+}
+int launch_feed_pd0(int prec, int sk, bool planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
+    switch (prec) {
+        case M_I16: return sk == SK_U8 ? launch_feed_pd0_t<M_I16, SK_U8>(planar, narrow, s0, g1, fc, grid, bytes, st) : launch_feed_pd0_t<M_I16, SK_S16>(planar, narrow, s0, g1, fc, grid, bytes, st);
+        case M_F32: return sk == SK_U8 ? launch_feed_pd0_t<M_F32, SK_U8>(planar, narrow, s0, g1, fc, grid, bytes, st) : launch_feed_pd0_t<M_F32, SK_S16>(planar, narrow, s0, g1, fc, grid, bytes, st);
+        default: return sk == SK_U8 ? launch_feed_pd0_t<M_F16, SK_U8>(planar, narrow, s0, g1, fc, grid, bytes, st) : launch_feed_pd0_t<M_F16, SK_S16>(planar, narrow, s0, g1, fc, grid, bytes, st);
+    }
+}
+
+// Narrowed tiles (k_feed_pd0<.., CF_NARROW>): the violation words of the cycle's tiles go to the host in one small launch ...
+int narrow_publish(isx_blender* b) {
+    if (b->narrow_pending == 0 || b->narrow_published) return ISX_OK;
+    const int seq = ++b->feed_seq;
+    ISX_LAUNCH("feed_publish", 0.0, b->stream, k_feed_publish, dim3(1), dim3(64), 0, (unsigned*)b->feed_state.p, (int)b->tiles.size(), b->feed_pin, seq);
+    b->narrow_published = true;
+    return ISX_OK;
+}
+// ... and are read here (the caller has enqueued whatever does not depend on the answer).  No violation (always, after W:294): the tiles are
+// CV_8UC3 tiles from here on.  Violation: every narrowed segment is widened into the escape buffer (k_feed_widen), which then is the tile's
+// CV_16SC3 private copy, the tiles become CV_16SC3 tiles again (*widened = true) and this blender stops narrowing.
+int narrow_resolve(isx_blender* b, bool* widened) {
+    *widened = false;
+    if (b->narrow_pending == 0) return ISX_OK;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        ISX_CHECK_ARG(hipStreamIsCapturing(b->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone, ISX_ERR_STATE,
+                      "blend: tiles fed before the capture began cannot be blended inside it (their narrowed copies are confirmed on the host)");
+    }
+    ISX_TRY(narrow_publish(b));
+    const int seq = b->feed_seq;
+    // (a spin, not hipStreamSynchronize: the stream already holds the launches that follow the publish, and waiting for those would leave the GPU
+    // idle while the last step is enqueued; when the GPU is behind the host this is where the host waits for it - one step ahead at most)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 1; __atomic_load_n(&b->feed_pin[0], __ATOMIC_ACQUIRE) != seq; ++spin) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((spin & 4095) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            ISX_HIP(hipStreamSynchronize(b->stream));
+            ISX_CHECK_ARG(__atomic_load_n(&b->feed_pin[0], __ATOMIC_ACQUIRE) == seq, ISX_ERR_HIP, "feed: the narrowed copies' check finished without publishing its result");
+        }
+    }
+    const bool bad = __atomic_load_n(&b->feed_pin[1], __ATOMIC_RELAXED) != 0;
+    b->narrow_pending = 0;
+    b->path_narrow = bad ? 2 : 1;
+    if (!bad) { for (auto& r : b->tiles) r.narrow = 0; return ISX_OK; }
+    b->narrow_off = true;
+    for (auto& r : b->tiles) {
+        if (!r.narrow) continue;
+        ISX_LAUNCH("feed_widen", (double)r.s0.rows * r.s0.cols * 9.0, b->stream, k_feed_widen, dim3(cdiv(r.s0.cols, 256), r.s0.rows), dim3(256), 0,
+                   r.s0.img, (unsigned)r.s0.img_step, r.wide, (unsigned)r.wide_step, (const unsigned char*)r.chunk, r.nbx, r.s0.rows, r.s0.cols, r.s0.left);
+        r.s0.img = r.wide; r.s0.img_step = r.wide_step;
+        r.s0.imis = (unsigned)((uintptr_t)r.s0.img & 3); r.s0.img_al = r.s0.img - r.s0.imis;
+        r.s0.iend = 0;
+        if ((unsigned long long)r.wide_step * r.s0.rows < (1ull << 31) && r.wide_step < (1u << 24) && r.s0.mend != 0u)
+            r.s0.iend = (unsigned)((size_t)(r.s0.rows - 1) * r.wide_step + (size_t)r.s0.cols * 6) + r.s0.imis;
+        r.sk = SK_S16; r.narrow = 0;
+    }
+    *widened = true;
+    return ISX_OK;
 }
 
 int src_kind_of(int type) { return type == ISX_8UC3 ? SK_U8 : (type == ISX_16SC3 ? SK_S16 : SK_F32); }
@@ -1814,6 +1906,7 @@ int join_side_streams(isx_blender* b) {
 int flush_deferred(isx_blender* b) {
     if (!b->level0_pending) return ISX_OK;
     const int L = b->num_bands;
+    { bool widened; ISX_TRY(narrow_resolve(b, &widened)); }   // the replay reads the private copies: in which type?
     ISX_TRY(join_side_streams(b));   // the replay rewrites the tiles' pyramid levels
     for (size_t t = 0; t < b->tiles.size(); ++t) {
         isx_blender::TileRec& r = b->tiles[t];
@@ -1990,7 +2083,24 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     bool all_on_side = b->chain_on_side.size() >= (size_t)n;
     for (int t = 0; t < n && all_on_side; ++t) all_on_side = b->chain_on_side[t] != 0;
     if (all_on_side) { ISX_TRY(join_side_streams(b)); g1_planar = false; }     // (chains launched by feed() wrote 16-byte records)
+    // Level 1 of tiles that came through the fused feed (k_feed_pd0) exists already, in the layout feed() expected this chain to want; when every
+    // tile has it, whole and in that layout, the level-0 launch is skipped.  Otherwise level 1 is produced here from the private copies - whose type
+    // must be known for that: the narrowed copies are confirmed first (a widened cycle re-enters as a cycle of CV_16SC3 tiles).
+    bool g1_done = true;
+    for (int t = 0; t < n; ++t) g1_done = g1_done && b->tiles[t].g1 == (g1_planar ? 2 : 1);
+    if (b->narrow_pending) {
+        ISX_TRY(narrow_publish(b));
+        if (!g1_done) {
+            bool widened = false;
+            ISX_TRY(narrow_resolve(b, &widened));
+            if constexpr (SK == SK_U8) { if (widened) return run_blend_deferred_t<M, SK_S16>(b, out); }
+        }
+    }
     for (int k = 0; k < L && !all_on_side; ++k) {
+        if (k == 0 && g1_done) {
+            if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
+            continue;
+        }
         TileSet ts = base(k);
         int maxc = 0, maxr = 0;
         double bytes = 0.0;
@@ -2055,7 +2165,9 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             k_first = kout;
         }
     }
-    for (int k = k_first; k >= 1; --k) {
+    // one collapse step; SKC = the tiles' type as the LAST step reads them (the steps above it read pyramid levels only)
+    auto step = [&](int k, auto SKC) -> int {
+        constexpr int SKL = decltype(SKC)::value;
         TileSet ts = base(k - 1);
         const int gx_all = cdiv(d[k].cols, WAVE);
         const int bx_lo = need_lo[k - 1] / (2 * WAVE), bx_hi = std::min(cdiv(need_hi[k - 1], 2 * WAVE), gx_all);
@@ -2067,7 +2179,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             if (g1_planar && k == 2) ts.fine[t] = planar_of(r.g[1]);
             if (g1_planar && k == 1) ts.coarse[t] = planar_of(r.g[1]);
             if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;                        // + the weights of G_L
-            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
+            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? src_px_bytes(SKL) + 1.0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
                    + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
         }
         dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
@@ -2089,18 +2201,39 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
                 bool done = false;
                 OutMat o1 = out;
                 o1.rec12 = rec12 ? 1 : 0;
-                ISX_TRY((launch_collapse_roll<M, SK>(b, st, ts, d[1], o1, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, roll_var, &done)));
+                ISX_TRY((launch_collapse_roll<M, SKL>(b, st, ts, d[1], o1, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, roll_var, &done)));
                 ISX_CHECK_ARG(done || !(rec12 || g1_planar), ISX_ERR_STATE, "blend: the last step's kernel was planned as k_collapse_roll and did not run");
-                if (done) { b->path_last = 3; continue; }
+                if (done) { b->path_last = 3; return ISX_OK; }
             }
             b->path_last = 2;
-            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
-            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SK, true, false>), grid, dim3(256), 0, ts, d[1], d[0], o);
+            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SKL, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
+            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SKL, true, false>), grid, dim3(256), 0, ts, d[1], d[0], o);
         } else {
             bytes = (bytes + (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec)) * frac;  // + out_{k-1}
             if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, true>), grid, dim3(256), 0, ts, d[k], d[k - 1], o);
             else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], o);
         }
+        return ISX_OK;
+    };
+    for (int k = k_first; k >= 1; --k) {
+        if (k == 1 && b->narrow_pending) {
+            // the chain up to here never looked at a level-0 pixel; the last step does: are the narrowed copies good?  (The answer has been on
+            // its way since this blend() began - k_feed_publish - and the launches above keep the GPU busy while the host reads it.)
+            bool widened = false;
+            ISX_TRY(narrow_resolve(b, &widened));
+            if constexpr (SK == SK_U8) {
+                if (widened) {      // (the roll variant was chosen on the tiles' geometry, which widening does not change)
+                    if (roll_var != 0) {
+                        bool ok = true;
+                        for (int t = 0; t < n; ++t) ok = ok && b->tiles[t].s0.iend != 0u;
+                        ISX_CHECK_ARG(ok, ISX_ERR_UNSUPPORTED, "blend: a widened tile exceeds the 2 GiB the planned last step addresses");
+                    }
+                    ISX_TRY(step(1, IC<SK_S16>{}));
+                    continue;
+                }
+            }
+        }
+        ISX_TRY(step(k, IC<SK>{}));
     }
     return ISX_OK;
 }
@@ -2123,6 +2256,7 @@ template <int M>
 int run_blend_deferred_strips(isx_blender* b, const OutMat& out, bool* done) {
     *done = false;
     const int L = b->num_bands;
+    { bool widened; ISX_TRY(narrow_resolve(b, &widened)); }      // every strip blends a subset of the records: their type is settled first
     const bool user_win = b->win_x1 > b->win_x0;
     const int X0 = user_win ? b->win_x0 : 0, X1 = user_win ? std::min(b->win_x1, b->fw) : b->fw;
     // Which tiles can reach the columns [x0, x1) of the result?  mosaic.tiles_for_window's rule - the tile's fed rectangle meets, at some level k,
@@ -2411,6 +2545,7 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
         ISX_HIP(hipMemsetAsync(b->dst_arena.p, 0, img_bytes + n, b->stream));
         b->rx = x; b->ry = y; b->rw = width; b->rh = height; b->num_bands = 0;
         b->fed.clear(); b->cleared = false; b->tiles.clear(); b->ftiles.clear(); b->level0_pending = false;
+        b->narrow_pending = 0; b->narrow_published = false; b->fused_cycle = false;
         b->prepared = true;
         return ISX_OK;
     }
@@ -2432,6 +2567,10 @@ int do_prepare(isx_blender* b, int x, int y, int width, int height) {
     // dst_.setTo(0) / the weight maps' setTo(0) are not executed: uncovered pixels are defined as zero (Cover).
     b->fed.clear();
     b->cleared = false;
+    b->path_narrow = 0;
+    if (b->narrow_pending && b->feed_state.p)      // an abandoned cycle: its violation words are not carried into the next one
+        ISX_HIP(hipMemsetAsync(b->feed_state.p, 0, (size_t)DEF_REC_MAX * 4, b->stream));
+    b->narrow_pending = 0; b->narrow_published = false; b->fused_cycle = false;
     b->tiles.clear();
     b->ftiles.clear();
     b->level0_pending = false;
@@ -2630,10 +2769,28 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     // outlive this call); an eager feed uses the shared ones.
     const int sk = src_kind_of(img->type);
     const int L0 = b->num_bands;
+    // Fused feed (round 5, k_feed_pd0): in mode 2 a CV_8UC3 / CV_16SC3 device tile is read ONCE - level 1 of its pyramid and the private copy
+    // come out of the same pass (ISX_FEED_FUSE=0: private_copy + the level-0 pyrDown inside blend(), as in round 4) - and the copy of a
+    // CV_16SC3 tile is written as CV_8UC3 (ISX_FEED_NARROW=0: as CV_16SC3), see pyrdown_l0.inc.  A cycle narrows all of its tiles or none.
+    static const bool fuse_on = [] { const char* e = getenv("ISX_FEED_FUSE"); return !(e && e[0] == '0'); }();
+    static const bool narrow_on = [] { const char* e = getenv("ISX_FEED_NARROW"); return !(e && e[0] == '0'); }();
+    const bool fusable = b->deferred && b->deferred_copy && fuse_on && !dil && !b->overlap && img->device >= 0 && mask->device >= 0 && (sk == SK_U8 || sk == SK_S16) &&
+                         (unsigned long long)img->step * img->rows < (1ull << 31) && (unsigned long long)mask->step * img->rows < (1ull << 31) &&
+                         img->step < (1u << 24) && mask->step < (1u << 24) && img->cols >= 2 && img->rows >= 2;
+    const bool cycle_narrow = !b->tiles.empty() && b->tiles[0].narrow != 0;
     const bool can_defer = b->deferred && L0 >= 1 && L0 <= ACC_MAXL && !b->cleared &&
                            (b->tiles.empty() ? b->fed.empty() : b->level0_pending) && b->tiles.size() < (size_t)DEF_REC_MAX &&
-                           (b->tiles.empty() || b->tiles[0].sk == sk);
+                           (b->tiles.empty() || b->tiles[0].fed_sk == sk) && (!cycle_narrow || (fusable && sk == SK_S16));
     if (!can_defer) ISX_TRY(flush_deferred(b));
+    const bool fused = can_defer && fusable;
+    bool narrow = false;
+    if (fused && sk == SK_S16) {
+        if (!b->tiles.empty()) narrow = cycle_narrow;
+        else if (narrow_on && !b->narrow_off) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // blend() reads the violation word on the host: not while the stream is being captured
+            narrow = hipStreamIsCapturing(b->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        }
+    }
     const size_t slot = b->tiles.size();
     if (can_defer && b->tile_arenas.size() <= slot) {
         b->tile_arenas.emplace_back(new DevBuf());
@@ -2644,10 +2801,13 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     MatStage& st_mask = can_defer ? *b->tile_mask[slot] : b->st_mask;
     DevBuf& arena = can_defer ? *b->tile_arenas[slot] : b->tile_arena;
     ISX_TRY(st_img.use_in(img, b->stream, "feed: img"));
-    if (can_defer && b->tile_copy_img.size() <= slot) { b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf()); }
+    if (can_defer && b->tile_copy_img.size() <= slot) {
+        b->tile_copy_img.emplace_back(new DevBuf()); b->tile_copy_mask.emplace_back(new DevBuf());
+        b->tile_copy_wide.emplace_back(new DevBuf()); b->tile_chunk.emplace_back(new DevBuf());
+    }
     if (dil) ISX_TRY(stage_dilated_mask(b, st_mask, mask, *dil, can_defer ? *b->tile_copy_mask[slot] : b->dil_mask, b->stream));   // the blender's own copy already
     else ISX_TRY(st_mask.use_in(mask, b->stream, "feed: mask"));
-    if (can_defer && b->deferred_copy) {
+    if (can_defer && b->deferred_copy && !fused) {
         if (img->device >= 0) ISX_TRY(private_copy(st_img.d, *b->tile_copy_img[slot], b->stream));
         if (mask->device >= 0 && !dil) ISX_TRY(private_copy(st_mask.d, *b->tile_copy_mask[slot], b->stream));
     }
@@ -2670,20 +2830,25 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     tlnx -= dx; brnx -= dx; tlny -= dy; brny -= dy;
     ISX_CHECK_ARG(tlnx >= b->rx && tlny >= b->ry, ISX_ERR_INVALID, "feed: padded tile does not fit the prepared ROI");
 
-    Src0 s0;
-    s0.img = (const unsigned char*)di.data; s0.img_step = di.step;
-    s0.mask = (const unsigned char*)dm.data; s0.mask_step = dm.step;
-    s0.rows = img->rows; s0.cols = img->cols;
-    s0.top = tl_y - tlny; s0.left = tl_x - tlnx;
-    s0.height = height; s0.width = width;
-    s0.imis = (unsigned)((uintptr_t)s0.img & 3); s0.mmis = (unsigned)((uintptr_t)s0.mask & 3);
-    s0.img_al = s0.img - s0.imis; s0.mask_al = s0.mask - s0.mmis;
-    s0.iend = 0; s0.mend = 0;
-    if ((img->type == ISX_8UC3 || img->type == ISX_16SC3) && (unsigned long long)di.step * img->rows < (1ull << 31) &&
-        (unsigned long long)dm.step * img->rows < (1ull << 31) && di.step < (1u << 24) && dm.step < (1u << 24)) {
-        s0.iend = (unsigned)((size_t)(img->rows - 1) * di.step + (size_t)img->cols * (img->type == ISX_8UC3 ? 3 : 6)) + s0.imis;
-        s0.mend = (unsigned)((size_t)(img->rows - 1) * dm.step + (size_t)img->cols) + s0.mmis;
-    }
+    // the tile as level 0 of its pyramid, read from (data, step) of an image of `type` and a mask
+    auto src0_of = [&](const void* idata, size_t istep, int type, const void* mdata, size_t mstep) {
+        Src0 q;
+        q.img = (const unsigned char*)idata; q.img_step = istep;
+        q.mask = (const unsigned char*)mdata; q.mask_step = mstep;
+        q.rows = img->rows; q.cols = img->cols;
+        q.top = tl_y - tlny; q.left = tl_x - tlnx;
+        q.height = height; q.width = width;
+        q.imis = (unsigned)((uintptr_t)q.img & 3); q.mmis = (unsigned)((uintptr_t)q.mask & 3);
+        q.img_al = q.img - q.imis; q.mask_al = q.mask - q.mmis;
+        q.iend = 0; q.mend = 0;
+        if ((type == ISX_8UC3 || type == ISX_16SC3) && (unsigned long long)istep * img->rows < (1ull << 31) &&
+            (unsigned long long)mstep * img->rows < (1ull << 31) && istep < (1u << 24) && mstep < (1u << 24)) {
+            q.iend = (unsigned)((size_t)(img->rows - 1) * istep + (size_t)img->cols * (type == ISX_8UC3 ? 3 : 6)) + q.imis;
+            q.mend = (unsigned)((size_t)(img->rows - 1) * mstep + (size_t)img->cols) + q.mmis;
+        }
+        return q;
+    };
+    Src0 s0 = src0_of(di.data, di.step, img->type, dm.data, dm.step);
 
     LevelBuf g[MAX_LEVELS];
     size_t total = 0;
@@ -2698,10 +2863,58 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
     layout_levels(g, L, height, width, b->prec, false, (char*)arena.p - skip, &total);
     g[0].img = nullptr; g[0].wgt = nullptr;
 
+    // the fused pass: G_1 and the private copies out of one read of the caller's tile
+    isx_blender::TileRec rec;
+    rec.fed_sk = sk; rec.sk = sk;
+    if (fused) {
+        const size_t ipx = narrow ? 3 : (sk == SK_U8 ? 3 : 6);
+        const size_t ipitch = ((size_t)img->cols * ipx + 63) & ~(size_t)63, mpitch = ((size_t)img->cols + 63) & ~(size_t)63;
+        ISX_TRY(b->tile_copy_img[slot]->reserve(ipitch * (size_t)img->rows + 64));
+        ISX_TRY(b->tile_copy_mask[slot]->reserve(mpitch * (size_t)img->rows + 64));
+        FeedCopy fc;
+        memset(&fc, 0, sizeof(fc));
+        fc.cimg = (unsigned char*)b->tile_copy_img[slot]->p; fc.cstep = (unsigned)ipitch;
+        fc.cmask = (unsigned char*)b->tile_copy_mask[slot]->p; fc.cmstep = (unsigned)mpitch;
+        const int nbx = cdiv(g[1].cols, PD_OW);
+        if (narrow) {
+            const size_t wpitch = ((size_t)img->cols * 6 + 63) & ~(size_t)63;
+            ISX_TRY(b->tile_copy_wide[slot]->reserve(wpitch * (size_t)img->rows + 64));
+            ISX_TRY(b->tile_chunk[slot]->reserve((size_t)nbx * (size_t)img->rows + 64));
+            if (!b->feed_state.p) {
+                ISX_TRY(b->feed_state.reserve((size_t)DEF_REC_MAX * 4));
+                ISX_HIP(hipMemsetAsync(b->feed_state.p, 0, (size_t)DEF_REC_MAX * 4, b->stream));
+            }
+            if (!b->feed_pin) {
+                ISX_HIP(hipHostMalloc((void**)&b->feed_pin, 64, hipHostMallocCoherent | hipHostMallocMapped));
+                b->feed_pin[0] = 0; b->feed_pin[1] = 0;
+            }
+            fc.wimg = (unsigned char*)b->tile_copy_wide[slot]->p; fc.wstep = (unsigned)wpitch;
+            fc.chunk = (unsigned char*)b->tile_chunk[slot]->p; fc.nbx = nbx;
+            fc.state = (unsigned*)b->feed_state.p + slot;
+            rec.narrow = 1; rec.wide = fc.wimg; rec.wide_step = wpitch; rec.chunk = fc.chunk; rec.nbx = nbx;
+        }
+        // level 1 PLANAR when the chain will most likely want it so (run_blend_deferred_t: the last step as k_collapse_roll with level 1 produced
+        // by k_collapse_gather); blend() produces the level again from the private copy in the rare cycle that wants the other layout
+        static const bool top_on0 = [] { const char* e = getenv("ISX_TOP"); return !(e && e[0] == '0'); }();
+        static const bool g1p_on = [] { const char* e = getenv("ISX_G1P"); return !(e && e[0] == '0'); }();
+        static const bool roll_on = [] { const char* e = getenv("ISX_ROLL"); return !(e && atoi(e) == 0); }();
+        const int D0 = std::min(TOP_DMAX, L - 1);
+        const bool planar = L >= 2 && (!(top_on0 && D0 >= 2) || L - D0 >= 2) && g1p_on && roll_on && (b->prec == M_F32 || b->prec == M_I16);
+        LevelBuf g1 = g[1];
+        if (planar) g1.wgt = (float*)((char*)g1.img + (size_t)g1.rows * g1.cols * 12u);
+        const double bytes = (double)height * width * (src_px_bytes(sk) + 1.0) + (double)g[1].rows * g[1].cols * alg_g(b->prec) + (double)img->rows * img->cols * ((double)ipx + 1.0);
+        ISX_TRY(launch_feed_pd0(b->prec, sk, planar, narrow, s0, g1, fc, dim3(nbx, cdiv(g[1].rows, PD_TY)), bytes, b->stream));
+        rec.g1 = planar ? 2 : 1;
+        rec.sk = narrow ? SK_U8 : sk;
+        s0 = src0_of(fc.cimg, ipitch, narrow ? ISX_8UC3 : img->type, fc.cmask, mpitch);
+        if (narrow) { ++b->narrow_pending; b->narrow_published = false; }
+        b->fused_cycle = true;
+    }
+
     int x_tl = tlnx - b->rx, y_tl = tlny - b->ry;
     if (can_defer) {   // record only: blend() does all the work
-        isx_blender::TileRec r;
-        r.s0 = s0; r.sk = sk; r.x_tl = x_tl; r.y_tl = y_tl; r.width = width; r.height = height;
+        isx_blender::TileRec r = rec;
+        r.s0 = s0; r.x_tl = x_tl; r.y_tl = y_tl; r.width = width; r.height = height;
         for (int k = 0; k <= L; ++k) r.g[k] = g[k];
         r.g[0].rows = height; r.g[0].cols = width;
         b->tiles.push_back(r);
@@ -2770,6 +2983,7 @@ int isx_blender_destroy(isx_blender* b) {
         (void)hipStreamSynchronize(b->side[i]); (void)hipStreamDestroy(b->side[i]);
         (void)hipEventDestroy(b->ev_ready[i]); (void)hipEventDestroy(b->ev_done[i]);
     }
+    if (b->feed_pin) (void)hipHostFree(b->feed_pin);
     delete b;
     return ISX_OK;
 }
@@ -2889,6 +3103,13 @@ int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) {
     return ISX_OK;
 }
 
+int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed) {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_feed_path: null blender");
+    if (fused_tiles) *fused_tiles = b->type == ISX_BLEND_MULTI_BAND ? b->path_fused : 0;
+    if (narrowed) *narrowed = b->type == ISX_BLEND_MULTI_BAND ? b->path_narrow : 0;
+    return ISX_OK;
+}
+
 int isx_blender_result_size(isx_blender* b, int* width, int* height) {
     ISX_CHECK_ARG(b != nullptr && width != nullptr && height != nullptr, ISX_ERR_INVALID, "result_size: null argument");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "result_size: prepare() has not been called");
@@ -2993,9 +3214,12 @@ static int blend_end(isx_blender* b, isx_mat* dst_mask) {
         ISX_TRY(b->st_out.finish_out(b->stream));
         if (dst_mask) ISX_TRY(b->st_outmask.finish_out(b->stream));
     }
+    b->path_fused = 0;
+    for (const auto& r : b->tiles) b->path_fused += r.g1 != 0;
     b->tiles.clear();
     b->ftiles.clear();
     b->level0_pending = false;
+    b->narrow_pending = 0; b->narrow_published = false; b->fused_cycle = false;
     b->prepared = false;   // dst_pyr_laplace_.clear(); dst_band_weights_.clear()
     return ISX_OK;
 }
@@ -3054,7 +3278,7 @@ int isx_blender_blend_batch(isx_blender** bs, int n, isx_mat* dsts, isx_mat* dst
         auto batchable = [&](const isx_blender* b) {
             return b->type == ISX_BLEND_MULTI_BAND && b->prepared && b->level0_pending && !b->tiles.empty() && b->win_x1 <= b->win_x0 &&
                    b->prec == b0->prec && b->num_bands == b0->num_bands && b->num_bands >= 1 && b->tiles[0].sk == b0->tiles[0].sk &&
-                   b->device == b0->device && b->stream == b0->stream;
+                   b->device == b0->device && b->stream == b0->stream && !b->fused_cycle;      // (a fused-feed cycle has its level 1 already: blended alone)
         };
         int j = i, tiles = 0;
         if (batchable(b0))

@@ -246,9 +246,10 @@ int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* 
  * that at most 20 tiles reach, each by the same chain and bit-identical to the whole blend (isx_blender_last_path: cycle 3); when some
  * 128-column strip is reached by more than 20 tiles, when a tile of another type is fed, and when isx_blender_debug_level is called,
  * the recorded tiles are replayed through the eager path.
- * on = 2 keeps OpenCV's contract: feed() takes a private copy of every DEVICE mat it records (one device-to-device
- * pass on the handle's stream, 4 B/px for a CV_8UC3 tile + mask), so the caller may release or overwrite the fed
- * mats as soon as feed() returns - the drop-in mode for callers written against cv::detail::Blender (W:286-308). */
+ * on = 2 keeps OpenCV's contract: feed() takes a private copy of every DEVICE mat it records, so the caller may release or overwrite
+ * the fed mats as soon as feed() returns - the drop-in mode for callers written against cv::detail::Blender (W:286-308).  For CV_8UC3
+ * and CV_16SC3 tiles that copy is a by-product of the pass that builds level 1 of the tile's pyramid (one read of the caller's mats per
+ * feed, isx_blender_feed_path); other mats take one device-to-device pass on the handle's stream.                                  */
 int isx_blender_set_deferred_level0(isx_blender* b, int on);
 /* In deferred mode: start each fed tile's Gaussian chain immediately on an internal side stream, so that
  * the (memory-bound) chain of tile t overlaps with whatever the caller enqueues next on the handle's
@@ -279,6 +280,16 @@ int isx_blender_result_size(isx_blender* b, int* width, int* height);
  * strips that at most 20 tiles reach and runs the deferred chain per strip - bit-identical to the whole blend); last_step: the kernel of the last collapse step - 0 none (a 0-band blend), 1 k_collapse,
  * 2 k_collapse_gather, 3 k_collapse_roll.  Either pointer may be NULL.                                                          */
 int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step);
+/* How the tiles of the last isx_blender_blend were FED in mode 2 (isx_blender_set_deferred_level0 = 2, OpenCV's contract W:302-308).
+ * fused_tiles: tiles whose feed() was ONE pass over the caller's CV_8UC3 / CV_16SC3 device mats - level 1 of the tile's pyramid and the
+ * private copy out of the same read (round 5; 0: host mats, other tile types, ISX_FEED_FUSE=0).  narrowed: 0 = no private copy was
+ * narrowed; 1 = the CV_16SC3 tiles held only byte values (always the case after convertTo(CV_16S) of a warped CV_8UC3 image, W:294),
+ * their private copies were kept as CV_8UC3 and the last collapse step ran its CV_8UC3 form - same bits, 3 fewer bytes per pixel written
+ * and read; 2 = some tile held a value outside [0, 255]: the copies were widened to CV_16SC3 before the last step (same bits; this
+ * blender keeps CV_16SC3 copies from then on).  The check is made on the device while the tile is read; blend() reads its one-word
+ * answer from pinned memory after it has enqueued everything that does not depend on it - no stream synchronisation.  Either pointer
+ * may be NULL.                                                                                                                    */
+int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed);
 /* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast
  * round-half-even), CV_32FC3 (F32/F16ACC32 only) or CV_8UC3 (= blend to CV_16SC3 followed by
  * result.convertTo(CV_8U), what imwrite (W:315) does to the panorama); dst_mask: CV_8UC1.  Releases the pyramids:
