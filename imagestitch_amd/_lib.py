@@ -21,7 +21,7 @@ PREC_I16, PREC_F32, PREC_F16ACC32 = 0, 1, 2
 WINDOW_GRANULE = 128       # ISX_WINDOW_GRANULE: a column window of blend() starts on a multiple of it
 
 STATUS_NAMES = {0: "ISX_OK", 1: "ISX_ERR_INVALID", 2: "ISX_ERR_TYPE", 3: "ISX_ERR_STATE", 4: "ISX_ERR_HIP",
-                5: "ISX_ERR_NOMEM", 6: "ISX_ERR_UNSUPPORTED", 7: "ISX_ERR_SIZE", 8: "ISX_ERR_PLAN"}
+                5: "ISX_ERR_NOMEM", 6: "ISX_ERR_UNSUPPORTED", 7: "ISX_ERR_SIZE", 8: "ISX_ERR_PLAN", 9: "ISX_ERR_INTERNAL"}
 
 
 class IsxMat(C.Structure):
@@ -121,6 +121,7 @@ _SIGS = {
     "isx_gather_p2p_wait": [C.c_void_p, C.c_void_p],
     "isx_gather_p2p_synchronize": [C.c_void_p],
     "isx_selftest_division": [C.c_int, C.c_int, C.c_ulonglong, _IP],
+    "isx_selftest_exception_barrier": [C.c_int],
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],
     "isx_profile_filter": [C.c_char_p],

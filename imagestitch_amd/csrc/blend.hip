@@ -2623,7 +2623,9 @@ __global__ __launch_bounds__(256) void k_copy_rows(const unsigned char* src, siz
         if (y >= rows) break;
         const unsigned char* sp = src + (size_t)y * sstep + off;
         unsigned char* dp = dst + (size_t)y * dstep + off;
-        if (y < rows - 1 || off + 16ull <= row_bytes) *(u32x4_a16*)dp = *(const u32x4_a1*)sp;
+        // a unit that overhangs its row reads into the next rows of the mat: only while its 16 bytes end inside the mat's last row (rows narrower
+        // than a unit under a small step - a mask under 16 columns wide - could otherwise run past the caller's allocation from row rows - 2 on)
+        if (off + 16ull <= row_bytes || (unsigned long long)y * sstep + off + 16ull <= (unsigned long long)(rows - 1) * sstep + row_bytes) *(u32x4_a16*)dp = *(const u32x4_a1*)sp;
         else for (unsigned b = 0; off + b < row_bytes; ++b) dp[b] = sp[b];
     }
 }
@@ -2956,7 +2958,7 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
 
 extern "C" {
 
-int isx_blender_create(int type, int num_bands, int precision, int device, isx_blender** out) {
+int isx_blender_create(int type, int num_bands, int precision, int device, isx_blender** out) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(out != nullptr, ISX_ERR_INVALID, "isx_blender_create: null out pointer");
     *out = nullptr;
@@ -2973,9 +2975,9 @@ int isx_blender_create(int type, int num_bands, int precision, int device, isx_b
     b->device = device; b->type = type; b->actual_num_bands = num_bands; b->num_bands = num_bands; b->prec = precision;
     *out = b;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_create")
 
-int isx_blender_destroy(isx_blender* b) {
+int isx_blender_destroy(isx_blender* b) ISX_ENTRY {
     if (!b) return ISX_OK;
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
@@ -2986,77 +2988,77 @@ int isx_blender_destroy(isx_blender* b) {
     if (b->feed_pin) (void)hipHostFree(b->feed_pin);
     delete b;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_destroy")
 
-int isx_blender_set_stream(isx_blender* b, void* hip_stream) {
+int isx_blender_set_stream(isx_blender* b, void* hip_stream) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_stream: null blender");
     b->stream = (hipStream_t)hip_stream;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_stream")
 
-int isx_blender_set_num_bands(isx_blender* b, int num_bands) {
+int isx_blender_set_num_bands(isx_blender* b, int num_bands) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_num_bands: null blender");
     ISX_CHECK_ARG(num_bands >= 0 && num_bands < MAX_LEVELS - 1, ISX_ERR_INVALID, "setNumBands(%d) out of range", num_bands);
     b->actual_num_bands = num_bands;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_num_bands")
 
-int isx_blender_set_deferred_level0(isx_blender* b, int on) {
+int isx_blender_set_deferred_level0(isx_blender* b, int on) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_deferred_level0: null blender");
     ISX_CHECK_ARG(!b->prepared || b->fed.empty(), ISX_ERR_STATE, "isx_blender_set_deferred_level0: tiles have already been fed in this cycle");
     b->deferred = on != 0;
     b->deferred_copy = on == 2;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_deferred_level0")
 
-int isx_blender_set_window(isx_blender* b, int x0, int x1) {
+int isx_blender_set_window(isx_blender* b, int x0, int x1) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "set_window: null blender");
     ISX_CHECK_ARG((x0 == 0 && x1 == 0) || (x0 >= 0 && x1 > x0 && x0 % ISX_WINDOW_GRANULE == 0), ISX_ERR_INVALID,
                   "set_window: columns [%d, %d): the first must be a non-negative multiple of %d and below the second (0, 0 = no window)", x0, x1, ISX_WINDOW_GRANULE);
     b->win_x0 = x0; b->win_x1 = x1;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_window")
 
-int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level) {
+int isx_blender_set_mark_event(isx_blender* b, void* hip_event, int after_level) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_mark_event: null blender");
     b->mark_event = (hipEvent_t)hip_event;
     b->mark_level = after_level;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_mark_event")
 
 #ifdef ISX_PHASE_TIMING
 // instrumented builds only (not declared in the header): sums of the 11 phases + the wave count; reset != 0 clears them
-int isx_debug_phase(unsigned long long* out12, int reset) {
+int isx_debug_phase(unsigned long long* out12, int reset) ISX_ENTRY {
     static unsigned long long h[1024][12];
     ISX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
     for (int k = 0; k < 12; ++k) { out12[k] = 0; for (int i = 0; i < 1024; ++i) out12[k] += h[i][k]; }
     if (reset) { memset(h, 0, sizeof(h)); ISX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h))); }
     return ISX_OK;
-}
+} ISX_EXIT("isx_debug_phase")
 #endif
 
-int isx_blender_set_sharpness(isx_blender* b, float sharpness) {
+int isx_blender_set_sharpness(isx_blender* b, float sharpness) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_sharpness: null blender");
     ISX_CHECK_ARG(b->type == ISX_BLEND_FEATHER, ISX_ERR_STATE, "setSharpness: not a FeatherBlender");
     ISX_CHECK_ARG(sharpness == sharpness, ISX_ERR_INVALID, "setSharpness: NaN");
     b->sharpness = sharpness;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_sharpness")
 
-int isx_blender_set_overlap(isx_blender* b, int on) {
+int isx_blender_set_overlap(isx_blender* b, int on) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_overlap: null blender");
     b->overlap = on != 0;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_set_overlap")
 
-int isx_blender_num_bands(isx_blender* b, int* num_bands) {
+int isx_blender_num_bands(isx_blender* b, int* num_bands) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr && num_bands != nullptr, ISX_ERR_INVALID, "isx_blender_num_bands: null argument");
     *num_bands = b->prepared ? b->num_bands : b->actual_num_bands;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_num_bands")
 
-int isx_blender_prepare(isx_blender* b, int n, const int* c, const int* s) {
+int isx_blender_prepare(isx_blender* b, int n, const int* c, const int* s) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(b != nullptr && c != nullptr && s != nullptr, ISX_ERR_INVALID, "prepare: null argument");
     ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "prepare: no tiles");
@@ -3068,25 +3070,25 @@ int isx_blender_prepare(isx_blender* b, int n, const int* c, const int* s) {
         brx = std::max(brx, c[2 * i] + s[2 * i]); bry = std::max(bry, c[2 * i + 1] + s[2 * i + 1]);
     }
     return do_prepare(b, tlx, tly, brx - tlx, bry - tly);
-}
+} ISX_EXIT("isx_blender_prepare")
 
-int isx_blender_prepare_roi(isx_blender* b, int x, int y, int width, int height) {
+int isx_blender_prepare_roi(isx_blender* b, int x, int y, int width, int height) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "prepare: null blender");
     return do_prepare(b, x, y, width, height);
-}
+} ISX_EXIT("isx_blender_prepare_roi")
 
-int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y) {
+int isx_blender_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y) ISX_ENTRY {
     clear_error();
     return do_feed(b, img, mask, tl_x, tl_y, false);
-}
+} ISX_EXIT("isx_blender_feed")
 
-int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y) {
+int isx_blender_feed_u8(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, int tl_y) ISX_ENTRY {
     clear_error();
     return do_feed(b, img, mask, tl_x, tl_y, true);
-}
+} ISX_EXIT("isx_blender_feed_u8")
 
-int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* seam_mask, const isx_mat* warped_mask, int kw, int kh, int tl_x, int tl_y) {
+int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* seam_mask, const isx_mat* warped_mask, int kw, int kh, int tl_x, int tl_y) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(b != nullptr && img != nullptr && seam_mask != nullptr && warped_mask != nullptr, ISX_ERR_INVALID, "feed_dilated: null argument");
     ISX_TRY(check_mat(seam_mask, "feed_dilated: seam mask"));
@@ -3094,30 +3096,30 @@ int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* 
     ISX_CHECK_ARG(kw >= 1 && kh >= 1, ISX_ERR_INVALID, "feed_dilated: bad structuring element %d x %d", kw, kh);
     const DilateSpec ds{warped_mask, kw, kh};
     return do_feed(b, img, seam_mask, tl_x, tl_y, img->type == ISX_8UC3, &ds);
-}
+} ISX_EXIT("isx_blender_feed_dilated")
 
-int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) {
+int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_last_path: null blender");
     if (cycle) *cycle = b->type == ISX_BLEND_MULTI_BAND ? b->path_cycle : 0;
     if (last_step) *last_step = b->type == ISX_BLEND_MULTI_BAND ? b->path_last : 0;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_last_path")
 
-int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed) {
+int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_feed_path: null blender");
     if (fused_tiles) *fused_tiles = b->type == ISX_BLEND_MULTI_BAND ? b->path_fused : 0;
     if (narrowed) *narrowed = b->type == ISX_BLEND_MULTI_BAND ? b->path_narrow : 0;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_feed_path")
 
-int isx_blender_result_size(isx_blender* b, int* width, int* height) {
+int isx_blender_result_size(isx_blender* b, int* width, int* height) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr && width != nullptr && height != nullptr, ISX_ERR_INVALID, "result_size: null argument");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "result_size: prepare() has not been called");
     *width = b->fw; *height = b->fh;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_result_size")
 
-int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight, int* rows, int* cols) {
+int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight, int* rows, int* cols) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(b != nullptr && rows != nullptr && cols != nullptr, ISX_ERR_INVALID, "debug_level: null argument");
     ISX_CHECK_ARG(b->prepared, ISX_ERR_STATE, "debug_level: prepare() has not been called");
@@ -3151,7 +3153,7 @@ int isx_blender_debug_level(isx_blender* b, int level, void* lap, float* weight,
         }
     }
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_debug_level")
 
 // the checks, staging and OutMat of Blender::blend for one blender (shared by isx_blender_blend and isx_blender_blend_batch)
 static int blend_begin(isx_blender* b, isx_mat* dst, isx_mat* dst_mask, OutMat* po) {
@@ -3224,7 +3226,7 @@ static int blend_end(isx_blender* b, isx_mat* dst_mask) {
     return ISX_OK;
 }
 
-int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
+int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) ISX_ENTRY {
     clear_error();
     OutMat o;
     ISX_TRY(blend_begin(b, dst, dst_mask, &o));
@@ -3264,9 +3266,9 @@ int isx_blender_blend(isx_blender* b, isx_mat* dst, isx_mat* dst_mask) {
     }
     ISX_TRY(rc);
     return blend_end(b, dst_mask);
-}
+} ISX_EXIT("isx_blender_blend")
 
-int isx_blender_blend_batch(isx_blender** bs, int n, isx_mat* dsts, isx_mat* dst_masks) {
+int isx_blender_blend_batch(isx_blender** bs, int n, isx_mat* dsts, isx_mat* dst_masks) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(bs != nullptr && dsts != nullptr && n >= 1, ISX_ERR_INVALID, "blend_batch: bad argument");
     for (int i = 0; i < n; ++i) ISX_CHECK_ARG(bs[i] != nullptr, ISX_ERR_INVALID, "blend_batch: null blender %d", i);
@@ -3306,6 +3308,6 @@ int isx_blender_blend_batch(isx_blender** bs, int n, isx_mat* dsts, isx_mat* dst
         i = j;
     }
     return ISX_OK;
-}
+} ISX_EXIT("isx_blender_blend_batch")
 
 }  // extern "C"

@@ -91,7 +91,7 @@ struct isx_gather {
 
 extern "C" {
 
-int isx_gather_unique_id(unsigned char id[128]) {
+int isx_gather_unique_id(unsigned char id[128]) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(id != nullptr, ISX_ERR_INVALID, "isx_gather_unique_id: null id");
     Rccl* r = nullptr;
@@ -100,9 +100,9 @@ int isx_gather_unique_id(unsigned char id[128]) {
     ISX_NCCL(r, r->GetUniqueId(&u));
     std::memcpy(id, u.internal, 128);
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_unique_id")
 
-int isx_gather_create(int world, int rank, const unsigned char id[128], int device, isx_gather** out) {
+int isx_gather_create(int world, int rank, const unsigned char id[128], int device, isx_gather** out) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(out != nullptr, ISX_ERR_INVALID, "isx_gather_create: null argument");
     *out = nullptr;
@@ -124,9 +124,9 @@ int isx_gather_create(int world, int rank, const unsigned char id[128], int devi
     if (e != hipSuccess) { if (g->comm) (void)r->CommDestroy(g->comm); delete g; return fail(ISX_ERR_HIP, "isx_gather_create: %s", hipGetErrorString(e)); }
     *out = g;
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_create")
 
-int isx_gather_destroy(isx_gather* g) {
+int isx_gather_destroy(isx_gather* g) ISX_ENTRY {
     if (!g) return ISX_OK;
     int prev = 0;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
@@ -146,18 +146,18 @@ int isx_gather_destroy(isx_gather* g) {
     if (have_prev) (void)hipSetDevice(prev);
     delete g;
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_destroy")
 
-int isx_gather_all(isx_gather* g, const void* send, size_t bytes, void* recv, void* hip_stream) {
+int isx_gather_all(isx_gather* g, const void* send, size_t bytes, void* recv, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr && send != nullptr && recv != nullptr && bytes > 0, ISX_ERR_INVALID, "isx_gather_all: bad argument");
     ISX_CHECK_ARG(g->comm != nullptr, ISX_ERR_STATE, "isx_gather_all: this handle was created without a communicator (id == NULL)");
     ISX_HIP(hipSetDevice(g->device));
     ISX_NCCL(g->r, g->r->AllGather(send, recv, bytes, NCCL_UINT8, g->comm, (hipStream_t)hip_stream));
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_all")
 
-int isx_gather_chunk(isx_gather* g, const void* send_base, size_t block_bytes, size_t offset, size_t bytes, void* recv_base, void* ready_event) {
+int isx_gather_chunk(isx_gather* g, const void* send_base, size_t block_bytes, size_t offset, size_t bytes, void* recv_base, void* ready_event) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr && send_base != nullptr && recv_base != nullptr, ISX_ERR_INVALID, "isx_gather_chunk: null argument");
     ISX_CHECK_ARG(g->comm != nullptr, ISX_ERR_STATE, "isx_gather_chunk: this handle was created without a communicator (id == NULL)");
@@ -173,29 +173,29 @@ int isx_gather_chunk(isx_gather* g, const void* send_base, size_t block_bytes, s
     ISX_NCCL(g->r, g->r->AllGather((const unsigned char*)send_base + offset, dst, bytes, NCCL_UINT8, g->comm, g->comm_stream));
     ISX_HIP(hipEventRecord(g->done, g->comm_stream));
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_chunk")
 
-int isx_gather_chunk_ptr(const isx_gather* g, void* recv_base, size_t offset, size_t bytes, int rank, void** ptr) {
+int isx_gather_chunk_ptr(const isx_gather* g, void* recv_base, size_t offset, size_t bytes, int rank, void** ptr) ISX_ENTRY {
     ISX_CHECK_ARG(g != nullptr && recv_base != nullptr && ptr != nullptr && rank >= 0 && rank < g->world, ISX_ERR_INVALID, "isx_gather_chunk_ptr: bad argument");
     *ptr = (unsigned char*)recv_base + (size_t)g->world * offset + (size_t)rank * bytes;
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_chunk_ptr")
 
-int isx_gather_wait(isx_gather* g, void* hip_stream) {
+int isx_gather_wait(isx_gather* g, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr, ISX_ERR_INVALID, "isx_gather_wait: null gather");
     ISX_HIP(hipSetDevice(g->device));
     ISX_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, g->done, 0));   // the stream's next work sees every chunk enqueued so far
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_wait")
 
-int isx_gather_synchronize(isx_gather* g) {
+int isx_gather_synchronize(isx_gather* g) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr, ISX_ERR_INVALID, "isx_gather_synchronize: null gather");
     ISX_HIP(hipSetDevice(g->device));
     ISX_HIP(hipStreamSynchronize(g->comm_stream));
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_synchronize")
 
 // ---- the direct schedule: every chunk copied straight into every rank's receive buffer ----------------------------------------------
 // xGMI is point to point: a rank's block has to cross each of its world - 1 links once whatever the schedule.  An all-gather leaves
@@ -204,7 +204,7 @@ int isx_gather_synchronize(isx_gather* g) {
 // isx_gather_chunk_ptr), so the two schedules are interchangeable - and comparable: bench.py --gather-backend p2p against torch / isx
 // tells "RCCL's schedule" from "the links".  Arrival on the DESTINATION rank is not signalled by the copy itself: consumers
 // synchronise across ranks as they would after any one-sided put (bench.py: the barrier that closes the timed region).
-int isx_gather_p2p_alloc(isx_gather* g, size_t bytes, void** ptr, unsigned char handle[64]) {
+int isx_gather_p2p_alloc(isx_gather* g, size_t bytes, void** ptr, unsigned char handle[64]) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr && ptr != nullptr && handle != nullptr && bytes > 0, ISX_ERR_INVALID, "isx_gather_p2p_alloc: bad argument");
     ISX_CHECK_ARG(g->p2p_local == nullptr, ISX_ERR_STATE, "isx_gather_p2p_alloc: the receive buffer exists already");
@@ -217,7 +217,7 @@ int isx_gather_p2p_alloc(isx_gather* g, size_t bytes, void** ptr, unsigned char 
     std::memcpy(handle, &h, 64);
     *ptr = g->p2p_local;
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_p2p_alloc")
 
 // undo a partly completed isx_gather_p2p_open: close the peers' mappings opened so far, destroy the streams / events created so far and
 // leave the gather as it was before the call, so that the call can be repeated
@@ -230,7 +230,7 @@ static void p2p_rollback(isx_gather* g) {
     g->pstream.clear(); g->pdone.clear();
 }
 
-int isx_gather_p2p_open(isx_gather* g, const unsigned char* handles /* world x 64 bytes, by rank */) {
+int isx_gather_p2p_open(isx_gather* g, const unsigned char* handles /* world x 64 bytes, by rank */) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr && handles != nullptr, ISX_ERR_INVALID, "isx_gather_p2p_open: bad argument");
     ISX_CHECK_ARG(g->p2p_local != nullptr, ISX_ERR_STATE, "isx_gather_p2p_open: isx_gather_p2p_alloc first");
@@ -258,9 +258,9 @@ int isx_gather_p2p_open(isx_gather* g, const unsigned char* handles /* world x 6
     }
 #undef P2P_OPEN_HIP
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_p2p_open")
 
-int isx_gather_p2p_chunk(isx_gather* g, const void* send_base, size_t block_bytes, size_t offset, size_t bytes, void* ready_event) {
+int isx_gather_p2p_chunk(isx_gather* g, const void* send_base, size_t block_bytes, size_t offset, size_t bytes, void* ready_event) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr && send_base != nullptr, ISX_ERR_INVALID, "isx_gather_p2p_chunk: null argument");
     ISX_CHECK_ARG(!g->peer.empty(), ISX_ERR_STATE, "isx_gather_p2p_chunk: isx_gather_p2p_open first");
@@ -276,30 +276,30 @@ int isx_gather_p2p_chunk(isx_gather* g, const void* send_base, size_t block_byte
         ISX_HIP(hipEventRecord(g->pdone[r], g->pstream[r]));
     }
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_p2p_chunk")
 
 // makes hip_stream wait (without blocking the host) for every copy this rank has enqueued so far (its send block may then be rewritten)
-int isx_gather_p2p_wait(isx_gather* g, void* hip_stream) {
+int isx_gather_p2p_wait(isx_gather* g, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr, ISX_ERR_INVALID, "isx_gather_p2p_wait: null gather");
     ISX_HIP(hipSetDevice(g->device));
     for (size_t r = 0; r < g->pdone.size(); ++r) ISX_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, g->pdone[r], 0));
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_p2p_wait")
 
-int isx_gather_p2p_synchronize(isx_gather* g) {
+int isx_gather_p2p_synchronize(isx_gather* g) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(g != nullptr, ISX_ERR_INVALID, "isx_gather_p2p_synchronize: null gather");
     ISX_HIP(hipSetDevice(g->device));
     for (size_t r = 0; r < g->pstream.size(); ++r) ISX_HIP(hipStreamSynchronize(g->pstream[r]));
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_p2p_synchronize")
 
-int isx_gather_info(const isx_gather* g, int* world, int* rank) {
+int isx_gather_info(const isx_gather* g, int* world, int* rank) ISX_ENTRY {
     ISX_CHECK_ARG(g != nullptr, ISX_ERR_INVALID, "isx_gather_info: null gather");
     if (world) *world = g->world;
     if (rank) *rank = g->rank;
     return ISX_OK;
-}
+} ISX_EXIT("isx_gather_info")
 
 }  // extern "C"

@@ -174,7 +174,7 @@ void put_marker(std::vector<unsigned char>& o, unsigned m, size_t payload_len) {
 
 extern "C" {
 
-int isx_jpeg_write(const char* path, const isx_mat* img, int quality) {
+int isx_jpeg_write(const char* path, const isx_mat* img, int quality) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imwrite: null path");
     ISX_TRY(check_mat(img, "imwrite: img"));
@@ -281,9 +281,9 @@ int isx_jpeg_write(const char* path, const isx_mat* img, int quality) {
     ok = (fclose(f) == 0) && ok;
     ISX_CHECK_ARG(ok, ISX_ERR_INVALID, "imwrite: short write to %s", path);
     return ISX_OK;
-}
+} ISX_EXIT("isx_jpeg_write")
 
-int isx_bmp_size(const char* path, int* rows, int* cols) {
+int isx_bmp_size(const char* path, int* rows, int* cols) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(path && rows && cols, ISX_ERR_INVALID, "isx_bmp_size: null argument");
     FILE* f = fopen(path, "rb");
@@ -294,9 +294,9 @@ int isx_bmp_size(const char* path, int* rows, int* cols) {
     if (rc != ISX_OK) return rc;
     *rows = bi.height; *cols = bi.width;
     return ISX_OK;
-}
+} ISX_EXIT("isx_bmp_size")
 
-int isx_bmp_read(const char* path, isx_mat* out) {
+int isx_bmp_read(const char* path, isx_mat* out) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imread: null path");
     ISX_TRY(check_mat(out, "imread: out"));
@@ -336,9 +336,9 @@ int isx_bmp_read(const char* path, isx_mat* out) {
         ISX_HIP(hipMemcpy2D(out->data, out->step, host.data(), dense, dense, bi.height, hipMemcpyHostToDevice));
     }
     return ISX_OK;
-}
+} ISX_EXIT("isx_bmp_read")
 
-int isx_bmp_write(const char* path, const isx_mat* img) {
+int isx_bmp_write(const char* path, const isx_mat* img) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imwrite: null path");
     ISX_TRY(check_mat(img, "imwrite: img"));
@@ -379,6 +379,6 @@ int isx_bmp_write(const char* path, const isx_mat* img) {
     ok = (fclose(f) == 0) && ok;
     ISX_CHECK_ARG(ok, ISX_ERR_INVALID, "imwrite: short write to %s", path);
     return ISX_OK;
-}
+} ISX_EXIT("isx_bmp_write")
 
 }  // extern "C"

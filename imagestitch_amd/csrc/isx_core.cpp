@@ -3,6 +3,8 @@
 
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 
 namespace isx {
 
@@ -18,6 +20,21 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 void clear_error() { g_err.clear(); }
+
+int on_exception(const char* entry) noexcept {
+    int code = ISX_ERR_INTERNAL;
+    const char* what = "an exception that is not a std::exception";
+    char buf[512];
+    try { throw; }
+    catch (const std::bad_alloc&) { code = ISX_ERR_NOMEM; what = "out of host memory (std::bad_alloc)"; }
+    catch (const std::length_error& e) { code = ISX_ERR_NOMEM; snprintf(buf, sizeof(buf), "a container was asked for more than it can hold (std::length_error: %s)", e.what()); what = buf; }
+    catch (const std::exception& e) { snprintf(buf, sizeof(buf), "%s", e.what()); what = buf; }
+    catch (...) { }
+    try { return fail(code, "%s: stopped a C++ exception at the C boundary: %s", entry, what); }
+    catch (...) {        // the message itself could not be stored: keep whatever isx_last_error() held, the status code still says what happened
+        return code;
+    }
+}
 
 const char* type_name(int type) {
     switch (type) {
@@ -160,29 +177,47 @@ extern "C" {
 const char* isx_last_error(void) { return g_err.c_str(); }
 const char* isx_version(void) { return "imagestitch_hip 0.1 (gfx950)"; }
 
-int isx_device_count(int* count) {
+int isx_device_count(int* count) ISX_ENTRY {
     ISX_CHECK_ARG(count != nullptr, ISX_ERR_INVALID, "isx_device_count: null pointer");
     ISX_HIP(hipGetDeviceCount(count));
     return ISX_OK;
-}
+} ISX_EXIT("isx_device_count")
 
 int isx_profile_enable(int on) { g_prof = on != 0; return ISX_OK; }
 
-int isx_profile_filter(const char* kernel_name) {
+// The barrier's own known-answer test (tests/test_abi_and_host.py, no GPU needed): throws `kind` from inside a guarded entry.
+// 0 std::bad_alloc, 1 a real std::length_error (vector::reserve beyond max_size), 2 a real allocation failure (a vector of 2^62 bytes),
+// 3 std::runtime_error, 4 a thrown int, 5 std::out_of_range from vector::at; anything else returns ISX_OK.
+int isx_selftest_exception_barrier(int kind) ISX_ENTRY {
+    clear_error();
+    std::vector<char> v;
+    switch (kind) {
+        case 0: throw std::bad_alloc();
+        case 1: v.reserve(v.max_size() + 1); break;
+        case 2: v.resize((size_t)1 << 62); break;
+        case 3: throw std::runtime_error("selftest");
+        case 4: throw 42;
+        case 5: return (int)v.at(7);
+        default: break;
+    }
+    return ISX_OK;
+} ISX_EXIT("isx_selftest_exception_barrier")
+
+int isx_profile_filter(const char* kernel_name) ISX_ENTRY {
     std::lock_guard<std::mutex> lk(g_pm);
     g_filter = kernel_name ? kernel_name : "";
     return ISX_OK;
-}
+} ISX_EXIT("isx_profile_filter")
 
-int isx_profile_sample(int every) {
+int isx_profile_sample(int every) ISX_ENTRY {
     ISX_CHECK_ARG(every >= 1, ISX_ERR_INVALID, "isx_profile_sample: every = %d", every);
     std::lock_guard<std::mutex> lk(g_pm);
     g_every = every;
     g_seen = 0;
     return ISX_OK;
-}
+} ISX_EXIT("isx_profile_sample")
 
-int isx_profile_collect(void) {
+int isx_profile_collect(void) ISX_ENTRY {
     ISX_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(g_pm);
     for (auto& e : g_entries) {
@@ -195,24 +230,24 @@ int isx_profile_collect(void) {
         e.pending.clear();
     }
     return ISX_OK;
-}
+} ISX_EXIT("isx_profile_collect")
 
-int isx_profile_reset(void) {
+int isx_profile_reset(void) ISX_ENTRY {
     ISX_TRY(isx_profile_collect());
     std::lock_guard<std::mutex> lk(g_pm);
     g_entries.clear();
     g_index.clear();
     return ISX_OK;
-}
+} ISX_EXIT("isx_profile_reset")
 
-int isx_profile_count(int* n) {
+int isx_profile_count(int* n) ISX_ENTRY {
     ISX_CHECK_ARG(n != nullptr, ISX_ERR_INVALID, "isx_profile_count: null pointer");
     std::lock_guard<std::mutex> lk(g_pm);
     *n = (int)g_entries.size();
     return ISX_OK;
-}
+} ISX_EXIT("isx_profile_count")
 
-int isx_profile_entry(int index, const char** name, long long* launches, double* total_ms, double* alg_bytes) {
+int isx_profile_entry(int index, const char** name, long long* launches, double* total_ms, double* alg_bytes) ISX_ENTRY {
     std::lock_guard<std::mutex> lk(g_pm);
     ISX_CHECK_ARG(index >= 0 && index < (int)g_entries.size(), ISX_ERR_INVALID, "isx_profile_entry: index %d out of range", index);
     const ProfEntry& e = g_entries[index];
@@ -221,6 +256,6 @@ int isx_profile_entry(int index, const char** name, long long* launches, double*
     if (total_ms) *total_ms = e.ms;
     if (alg_bytes) *alg_bytes = e.bytes;
     return ISX_OK;
-}
+} ISX_EXIT("isx_profile_entry")
 
 }  // extern "C"

@@ -17,6 +17,14 @@ namespace isx {
 // ---- errors: thread-local message + status code, no exceptions across the C boundary ----------
 int fail(int code, const char* fmt, ...);
 void clear_error();
+// The exception barrier of the C boundary (status codes, never a C++ exception - the reference's own errors are cv::Exceptions,
+// W:94-96, which a C caller, a ctypes / cgo / JNI binding or a C++ caller built with another runtime cannot catch).  Every extern "C" entry
+// is a function-try-block:   int isx_x(...) ISX_ENTRY { ... } ISX_EXIT("isx_x")
+// on_exception() runs inside the handler: std::bad_alloc / std::length_error -> ISX_ERR_NOMEM, anything else -> ISX_ERR_INTERNAL, the
+// message in isx_last_error(); it never throws itself (a fixed message when even the string cannot be stored).
+int on_exception(const char* entry) noexcept;
+#define ISX_ENTRY try
+#define ISX_EXIT(entry) catch (...) { return ::isx::on_exception(entry); }
 
 #define ISX_CHECK_ARG(cond, code, ...)                   \
     do {                                                 \

@@ -313,14 +313,16 @@ int parse(Jpeg& j, const char* path, bool header_only) {
             }
             j.got_sof = true;
             // geometry, once and for all scans: blocks per component, padded to whole MCUs.  A frame whose MCUs could not possibly fit the
-            // file (every coded block takes at least two bits: an end-of-block after a zero DC difference) is refused before anything is
+            // file (every coded block of a sequential frame takes at least two bits: an end-of-block after a zero DC difference; one bit in a progressive one) is refused before anything is
             // allocated, and so is one beyond the size the BMP reader accepts: the header of a few-hundred-byte file must not drive
             // gigabytes of allocations.
             j.mcux = (j.width + 8 * j.hmax - 1) / (8 * j.hmax); j.mcuy = (j.height + 8 * j.vmax - 1) / (8 * j.vmax);
             {
                 unsigned long long blocks = 0;
                 for (int c = 0; c < j.ncomp; ++c) blocks += (unsigned long long)j.mcux * j.comp[c].h * (unsigned long long)j.mcuy * j.comp[c].v;
-                ISX_CHECK_ARG((unsigned long long)j.width * j.height <= (1ull << 30) && blocks / 4 <= (unsigned long long)n, ISX_ERR_INVALID,
+                // (progressive frames: the DC-first scan can spend ONE bit per block - a zero difference under a 1-bit code, mozjpeg-style scan
+                // scripts without DC successive approximation - and the AC scans next to nothing through EOBRUN: blocks / 8 there)
+                ISX_CHECK_ARG((unsigned long long)j.width * j.height <= (1ull << 30) && blocks / (j.progressive ? 8 : 4) <= (unsigned long long)n, ISX_ERR_INVALID,
                               "imread: %s: a %d x %d frame cannot be held by a %zu-byte file", path, j.width, j.height, n);
             }
             if (header_only) return ISX_OK;      // (isx_jpeg_size: the caller allocates rows x cols from what this returns - after the check above)
@@ -498,21 +500,21 @@ static int jpeg_size_impl(const char* path, int* rows, int* cols) {
 }
 static int jpeg_read_impl(const char* path, isx_mat* out);
 
-int isx_jpeg_size(const char* path, int* rows, int* cols) {
+int isx_jpeg_size(const char* path, int* rows, int* cols) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(path && rows && cols, ISX_ERR_INVALID, "isx_jpeg_size: null argument");
     try { return jpeg_size_impl(path, rows, cols); }
     catch (const std::bad_alloc&) { return fail(ISX_ERR_NOMEM, "imread: %s: out of host memory", path); }
     catch (...) { return fail(ISX_ERR_INVALID, "imread: %s: unexpected failure while decoding", path); }
-}
+} ISX_EXIT("isx_jpeg_size")
 
-int isx_jpeg_read(const char* path, isx_mat* out) {
+int isx_jpeg_read(const char* path, isx_mat* out) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imread: null path");
     try { return jpeg_read_impl(path, out); }
     catch (const std::bad_alloc&) { return fail(ISX_ERR_NOMEM, "imread: %s: out of host memory", path); }
     catch (...) { return fail(ISX_ERR_INVALID, "imread: %s: unexpected failure while decoding", path); }
-}
+} ISX_EXIT("isx_jpeg_read")
 
 static int jpeg_read_impl(const char* path, isx_mat* out) {
     ISX_CHECK_ARG(path != nullptr, ISX_ERR_INVALID, "imread: null path");

@@ -244,25 +244,25 @@ LinScratch& lin_scratch() {
 
 extern "C" {
 
-int isx_blend_pair_linear_release(void) {
+int isx_blend_pair_linear_release(void) ISX_ENTRY {
     clear_error();
     LinScratch& ls = lin_scratch();
     ls.buf.release();      // (hipFree needs no current device: the caller's is left as it is)
     ls.device = -1;
     return ISX_OK;
-}
+} ISX_EXIT("isx_blend_pair_linear_release")
 
 int isx_blend_pair_linear_size(int rows1, int cols1, int rows2, int cols2, int tl1_x, int tl1_y, int tl2_x, int tl2_y,
-                               int* pano_rows, int* pano_cols) {
+                               int* pano_rows, int* pano_cols) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(pano_rows != nullptr && pano_cols != nullptr, ISX_ERR_INVALID, "blend_pair_linear_size: null argument");
     ISX_CHECK_ARG(rows1 > 0 && cols1 > 0 && rows2 > 0 && cols2 > 0, ISX_ERR_INVALID, "blend_pair_linear_size: empty tile");
     geom_sizes(rows1, cols1, rows2, cols2, tl1_x, tl1_y, tl2_x, tl2_y, pano_rows, pano_cols);
     return ISX_OK;
-}
+} ISX_EXIT("isx_blend_pair_linear_size")
 
 int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2, int tl1_x, int tl1_y, int tl2_x, int tl2_y,
-                          isx_mat* pano, int* seam_x, int device, void* hip_stream) {
+                          isx_mat* pano, int* seam_x, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_TRY(check_mat(images1, "blend_pair_linear: images1"));
     ISX_TRY(check_mat(images2, "blend_pair_linear: images2"));
@@ -314,6 +314,6 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2, int tl
     ISX_TRY(sp.finish_out(st));
     ISX_HIP(hipStreamSynchronize(st));   // the seam and a host pano are complete when the call returns (cv::Mat semantics)
     return ISX_OK;
-}
+} ISX_EXIT("isx_blend_pair_linear")
 
 }  // extern "C"

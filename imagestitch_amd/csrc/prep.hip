@@ -244,7 +244,7 @@ int dilate_and_device(const unsigned char* mask, size_t mstep, const unsigned ch
 
 extern "C" {
 
-int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int kh, isx_mat* out, int device, void* hip_stream) {
+int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int kh, isx_mat* out, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_TRY(check_mat(mask, "dilate: mask"));
     ISX_TRY(check_mat(out, "dilate: out"));
@@ -278,9 +278,9 @@ int isx_mask_dilate_and(const isx_mat* mask, const isx_mat* other, int kw, int k
     ISX_TRY(sd.finish_out(st));
     ISX_HIP(hipStreamSynchronize(st));   // tmp is freed on return
     return ISX_OK;
-}
+} ISX_EXIT("isx_mask_dilate_and")
 
-int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream) {
+int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_TRY(check_mat(image, "gain_apply: image"));
     ISX_CHECK_ARG(image->type == ISX_8UC3 || image->type == ISX_8UC1, ISX_ERR_TYPE, "gain_apply: image must be CV_8UC3 or CV_8UC1, got %s", type_name(image->type));
@@ -301,9 +301,9 @@ int isx_gain_apply(isx_mat* image, double gain, int device, void* hip_stream) {
     ISX_TRY(so.finish_out(st));
     if (image->device < 0) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
     return ISX_OK;
-}
+} ISX_EXIT("isx_gain_apply")
 
-int isx_convert_to(const isx_mat* src, isx_mat* dst, int device, void* hip_stream) {
+int isx_convert_to(const isx_mat* src, isx_mat* dst, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_TRY(check_mat(src, "convertTo: src"));
     ISX_TRY(check_mat(dst, "convertTo: dst"));
@@ -334,6 +334,6 @@ int isx_convert_to(const isx_mat* src, isx_mat* dst, int device, void* hip_strea
     ISX_TRY(so.finish_out(st));
     if (src->device < 0 || dst->device < 0) ISX_HIP(hipStreamSynchronize(st));   // the staging buffers are freed on return
     return ISX_OK;
-}
+} ISX_EXIT("isx_convert_to")
 
 }  // extern "C"

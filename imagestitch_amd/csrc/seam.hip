@@ -249,7 +249,7 @@ extern "C" {
 
 int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, int tl1_y, int tl2_x, int tl2_y, int union_tl_x, int union_tl_y,
                       const isx_mat* labels, int label, const int roi[4], int p1_x, int p1_y, int p2_x, int p2_y,
-                      int* seam_xy, int cap, int* seam_len, int* is_horizontal, int device, void* hip_stream) {
+                      int* seam_xy, int cap, int* seam_len, int* is_horizontal, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_TRY(check_mat(image1, "seam_estimate: image1"));
     ISX_TRY(check_mat(image2, "seam_estimate: image2"));
@@ -366,6 +366,6 @@ int isx_seam_estimate(const isx_mat* image1, const isx_mat* image2, int tl1_x, i
                   "seam_estimate: the restored seam does not join the tips (CV_Assert, S:953-954)");
     *seam_len = len;
     return ISX_OK;
-}
+} ISX_EXIT("isx_seam_estimate")
 
 }  // extern "C"

@@ -647,7 +647,7 @@ namespace isx { void seam_scratch_release(); }
 
 extern "C" {
 
-int isx_dp_seam_release(void) {
+int isx_dp_seam_release(void) ISX_ENTRY {
     clear_error();
     Finder& f = finder();
     f = Finder();                       // labels, union masks, contours, the seam mask: back to empty vectors
@@ -655,9 +655,9 @@ int isx_dp_seam_release(void) {
     finder_stages().device = -1;
     isx::seam_scratch_release();        // cost maps, DP records and the staging of isx_seam_estimate
     return ISX_OK;
-}
+} ISX_EXIT("isx_dp_seam_release")
 
-int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_xy, isx_mat* masks, int device, void* hip_stream) {
+int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_xy, isx_mat* masks, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(num_images >= 0 && (num_images == 0 || (images && corners_xy && masks)), ISX_ERR_INVALID, "dp_seam_find: null argument");
     if (num_images == 0) return ISX_OK;   // S:95-96
@@ -717,6 +717,6 @@ int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_x
             ISX_HIP(hipMemcpy2DAsync(masks[i].data, masks[i].step, hostm[i].data(), masks[i].cols, masks[i].cols, masks[i].rows, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     if (any_dev) ISX_HIP(hipStreamSynchronize((hipStream_t)hip_stream));   // hostm dies with this frame
     return ISX_OK;
-}
+} ISX_EXIT("isx_dp_seam_find")
 
 }  // extern "C"

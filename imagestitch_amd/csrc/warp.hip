@@ -21,6 +21,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <new>
 
 using namespace isx;
@@ -1201,6 +1202,7 @@ struct isx_warper {
     void* pin = nullptr;     // pinned host landing zone of detectResultRoi's {keys, count, first candidates}
     double gain = 1.0;       // isx_warper_set_gain: folded into the fused tile warp's store (1.0 = off)
     unsigned char gain_lut[256] = {};   // its 256-entry table (handed to the kernel in its arguments)
+    int verify_dropped = 0;  // verifications discarded under ISX_VERIFY_NEVER (isx_warper_plan_status reports them)
     RoiPin* pin2 = nullptr;  // pinned block the border scan writes its answer into (k_roi_border_pin); pin_seq: the call number it publishes
     int pin_seq = 0;
     // isx_warper_set_deferred_verify: planned warps queue their verification; isx_warper_verify enqueues the
@@ -1256,8 +1258,10 @@ int set_camera(isx_warper* w, const float K[9], const float R[9]) {
 // current position.  The scan is VALU-bound like the warp kernel: it should run under memory-bound work.
 int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
     if (w->pending.empty()) return ISX_OK;
-    static const bool never = getenv("ISX_VERIFY_NEVER") != nullptr;      // measurement aid: what the verification scans cost a step (never in a product run)
-    if (never) { w->pending.clear(); return ISX_OK; }
+    // ISX_VERIFY_NEVER: a measurement aid (what the verification scans cost a step).  A run under it is not a verified run and cannot pass
+    // for one: isx_warper_plan_status answers ISX_ERR_PLAN once a verification has been dropped here.
+    static const bool never = getenv("ISX_VERIFY_NEVER") != nullptr;
+    if (never) { w->verify_dropped += (int)w->pending.size(); w->pending.clear(); return ISX_OK; }
     hipStream_t st = w->stream;
     if (!w->side) {
         // one verification stream per DEVICE, shared by every warper on it (never destroyed): a batch of pairs would otherwise
@@ -1382,7 +1386,11 @@ int border_scan_sync(isx_warper* w, int sw, int sh, hipStream_t st, const char* 
         const auto t0 = std::chrono::steady_clock::now();
         bool synced = false;
         while (__atomic_load_n(&w->pin2->seq, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
             if (!synced && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {   // a busy GPU: wait the ordinary way (and report its errors)
                 ISX_HIP(hipStreamSynchronize(st));
                 synced = true;
@@ -1736,7 +1744,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
 
 extern "C" {
 
-int isx_warper_create(int kind, float scale, int device, isx_warper** out) {
+int isx_warper_create(int kind, float scale, int device, isx_warper** out) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(out != nullptr, ISX_ERR_INVALID, "isx_warper_create: null out pointer");
     *out = nullptr;
@@ -1750,9 +1758,9 @@ int isx_warper_create(int kind, float scale, int device, isx_warper** out) {
     w->kind = kind; w->scale = scale; w->device = device;
     *out = w;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_create")
 
-int isx_warper_destroy(isx_warper* w) {
+int isx_warper_destroy(isx_warper* w) ISX_ENTRY {
     if (!w) return ISX_OK;
     (void)hipSetDevice(w->device);
     (void)hipStreamSynchronize(w->stream);
@@ -1761,15 +1769,15 @@ int isx_warper_destroy(isx_warper* w) {
     if (w->pin2) (void)hipHostFree(w->pin2);
     delete w;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_destroy")
 
-int isx_warper_set_stream(isx_warper* w, void* hip_stream) {
+int isx_warper_set_stream(isx_warper* w, void* hip_stream) ISX_ENTRY {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_stream: null warper");
     w->stream = (hipStream_t)hip_stream;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_set_stream")
 
-int isx_warper_set_gain(isx_warper* w, double gain) {
+int isx_warper_set_gain(isx_warper* w, double gain) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_gain: null warper");
     if (gain == w->gain) return ISX_OK;
@@ -1784,40 +1792,40 @@ int isx_warper_set_gain(isx_warper* w, double gain) {
     }
     w->gain = gain;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_set_gain")
 
-int isx_warper_set_roi_cache(isx_warper* w, int on) {
+int isx_warper_set_roi_cache(isx_warper* w, int on) ISX_ENTRY {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_roi_cache: null warper");
     w->roi_cache_on = on != 0;
     if (!on) w->roi_cache.clear();      // (the last result is remembered again from the next call on)
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_set_roi_cache")
 
-int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1) {
+int isx_warper_set_dst_columns(isx_warper* w, int col0, int col1) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_dst_columns: null warper");
     ISX_CHECK_ARG((col0 == 0 && col1 == 0) || (col0 >= 0 && col1 > col0), ISX_ERR_INVALID, "isx_warper_set_dst_columns: columns [%d, %d)", col0, col1);
     w->col0 = col0; w->col1 = col1;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_set_dst_columns")
 
-int isx_warper_camera(isx_warper* w, const float K[9], const float R[9], float r_kinv[9], float k_rinv[9]) {
+int isx_warper_camera(isx_warper* w, const float K[9], const float R[9], float r_kinv[9], float k_rinv[9]) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_camera: null warper");
     ISX_TRY(set_camera(w, K, R));
     if (r_kinv) std::copy(w->proj.r_kinv, w->proj.r_kinv + 9, r_kinv);
     if (k_rinv) std::copy(w->proj.k_rinv, w->proj.k_rinv + 9, k_rinv);
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_camera")
 
-int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], int roi[4], float minmax[4]) {
+int isx_warper_roi(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], int roi[4], float minmax[4]) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && roi != nullptr, ISX_ERR_INVALID, "isx_warper_roi: null argument");
     ISX_CHECK_ARG(src_w > 0 && src_h > 0, ISX_ERR_INVALID, "isx_warper_roi: empty source size %d x %d", src_w, src_h);
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(set_camera(w, K, R));
     return detect_roi(w, src_w, src_h, roi, minmax, false, nullptr);
-}
+} ISX_EXIT("isx_warper_roi")
 
 namespace {
 int build_maps_common(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4], bool given_roi) {
@@ -1846,19 +1854,19 @@ int build_maps_common(isx_warper* w, int src_w, int src_h, const float K[9], con
 }
 }  // namespace
 
-int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4]) {
+int isx_warper_build_maps(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], isx_mat* xmap, isx_mat* ymap, int roi[4]) ISX_ENTRY {
     clear_error();
     return build_maps_common(w, src_w, src_h, K, R, xmap, ymap, roi, false);
-}
+} ISX_EXIT("isx_warper_build_maps")
 
-int isx_warper_build_maps_roi(isx_warper* w, const float K[9], const float R[9], const int roi[4], isx_mat* xmap, isx_mat* ymap) {
+int isx_warper_build_maps_roi(isx_warper* w, const float K[9], const float R[9], const int roi[4], isx_mat* xmap, isx_mat* ymap) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "buildMaps: null roi");
     int r[4] = {roi[0], roi[1], roi[2], roi[3]};
     return build_maps_common(w, 0, 0, K, R, xmap, ymap, r, true);
-}
+} ISX_EXIT("isx_warper_build_maps_roi")
 
-int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int interp, int border, isx_mat* dst, int device, void* hip_stream) {
+int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int interp, int border, isx_mat* dst, int device, void* hip_stream) ISX_ENTRY {
     clear_error();
     ISX_TRY(check_mat(src, "remap: src"));
     ISX_TRY(check_mat(xmap, "remap: xmap"));
@@ -1897,40 +1905,40 @@ int isx_remap(const isx_mat* src, const isx_mat* xmap, const isx_mat* ymap, int 
     ISX_TRY(sd.finish_out(st));
     if (src->device < 0 || xmap->device < 0 || ymap->device < 0 || dst->device < 0) ISX_HIP(hipStreamSynchronize(st));   // staging buffers are freed on return
     return ISX_OK;
-}
+} ISX_EXIT("isx_remap")
 
-int isx_warper_warp(isx_warper* w, const isx_mat* src, const float K[9], const float R[9], int interp, int border, isx_mat* dst, int corner[2]) {
+int isx_warper_warp(isx_warper* w, const isx_mat* src, const float K[9], const float R[9], int interp, int border, isx_mat* dst, int corner[2]) ISX_ENTRY {
     clear_error();
     return warp_common(w, src, nullptr, K, R, interp, border, dst, nullptr, corner, nullptr, false);
-}
+} ISX_EXIT("isx_warper_warp")
 
 int isx_warper_warp_with_mask(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9], const float R[9],
-                              isx_mat* dst_img, isx_mat* dst_mask, int corner[2]) {
+                              isx_mat* dst_img, isx_mat* dst_mask, int corner[2]) ISX_ENTRY {
     clear_error();
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, corner, nullptr, true);
-}
+} ISX_EXIT("isx_warper_warp_with_mask")
 
 int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9], const float R[9],
-                                      const int planned_roi[4], isx_mat* dst_img, isx_mat* dst_mask) {
+                                      const int planned_roi[4], isx_mat* dst_img, isx_mat* dst_mask) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(planned_roi != nullptr, ISX_ERR_INVALID, "planned warp: null planned_roi");
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, planned_roi, true);
-}
+} ISX_EXIT("isx_warper_warp_with_mask_planned")
 
-int isx_warper_warp_roi(isx_warper* w, const isx_mat* src, const float K[9], const float R[9], int interp, int border, const int roi[4], isx_mat* dst) {
+int isx_warper_warp_roi(isx_warper* w, const isx_mat* src, const float K[9], const float R[9], int interp, int border, const int roi[4], isx_mat* dst) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "warp_roi: null roi");
     return warp_common(w, src, nullptr, K, R, interp, border, dst, nullptr, nullptr, roi, false, false);
-}
+} ISX_EXIT("isx_warper_warp_roi")
 
 int isx_warper_warp_with_mask_roi(isx_warper* w, const isx_mat* src_img, const isx_mat* src_mask, const float K[9], const float R[9],
-                                  const int roi[4], isx_mat* dst_img, isx_mat* dst_mask) {
+                                  const int roi[4], isx_mat* dst_img, isx_mat* dst_mask) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "warp_with_mask_roi: null roi");
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, roi, true, false);
-}
+} ISX_EXIT("isx_warper_warp_with_mask_roi")
 
-int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches) {
+int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(mismatches != nullptr && n > 0, ISX_ERR_INVALID, "selftest_division: bad argument");
     ISX_HIP(hipSetDevice(device));
@@ -1944,49 +1952,49 @@ int isx_selftest_division(int device, int n, unsigned long long seed, int* misma
     ISX_HIP(e);
     *mismatches = (int)h;
     return ISX_OK;
-}
+} ISX_EXIT("isx_selftest_division")
 
-int isx_warper_set_deferred_verify(isx_warper* w, int on) {
+int isx_warper_set_deferred_verify(isx_warper* w, int on) ISX_ENTRY {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_deferred_verify: null warper");
     w->defer_verify = on != 0;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_set_deferred_verify")
 
-int isx_warper_verify_is_light(isx_warper* w, int src_cols, int src_rows, const float K[9], const float R[9], int* light) {
+int isx_warper_verify_is_light(isx_warper* w, int src_cols, int src_rows, const float K[9], const float R[9], int* light) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && light != nullptr && src_cols > 0 && src_rows > 0, ISX_ERR_INVALID, "isx_warper_verify_is_light: bad argument");
     ISX_TRY(set_camera(w, K, R));
     *light = (w->kind == ISX_WARP_SPHERICAL || cyl_extrema_on_border(w->proj, w->k, w->rinv, src_cols, src_rows)) ? 1 : 0;
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_verify_is_light")
 
-int isx_warper_verify(isx_warper* w) {
+int isx_warper_verify(isx_warper* w) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_verify: null warper");
     ISX_HIP(hipSetDevice(w->device));
     return flush_verify(w);
-}
+} ISX_EXIT("isx_warper_verify")
 
-int isx_warper_verify_after(isx_warper* w, void* hip_event) {
+int isx_warper_verify_after(isx_warper* w, void* hip_event) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && hip_event != nullptr, ISX_ERR_INVALID, "isx_warper_verify_after: null argument");
     ISX_HIP(hipSetDevice(w->device));
     return flush_verify(w, (hipEvent_t)hip_event);
-}
+} ISX_EXIT("isx_warper_verify_after")
 
 // Verification outside a captured step.  A planned warp queues the scan that checks its plan; inside a hipGraph that scan has to be forked
 // from the captured stream by an event, and the fork cost a replayed step 12 us (0.206 -> 0.218 ms at 4K; the eager step starts the scan on the
 // side stream with no event at all).  A capturing caller therefore drops the queued scans of the captured warps
 // (isx_warper_discard_pending) and, after every replay, queues the same verifications from the rig alone (isx_warper_queue_verify: the scan
 // reads the projection and the source size, never an image) and starts them beside the graph (isx_warper_verify).
-int isx_warper_discard_pending(isx_warper* w) {
+int isx_warper_discard_pending(isx_warper* w) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_discard_pending: null warper");
     w->pending.clear();
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_discard_pending")
 
-int isx_warper_queue_verify(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], const int planned_roi[4]) {
+int isx_warper_queue_verify(isx_warper* w, int src_w, int src_h, const float K[9], const float R[9], const int planned_roi[4]) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && K != nullptr && R != nullptr && planned_roi != nullptr, ISX_ERR_INVALID, "isx_warper_queue_verify: null argument");
     ISX_CHECK_ARG(src_w > 0 && src_h > 0, ISX_ERR_INVALID, "isx_warper_queue_verify: empty source %d x %d", src_w, src_h);
@@ -1998,9 +2006,9 @@ int isx_warper_queue_verify(isx_warper* w, int src_w, int src_h, const float K[9
     std::copy(w->k, w->k + 9, pd.k); std::copy(w->rinv, w->rinv + 9, pd.rinv);
     w->pending.push_back(pd);
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_queue_verify")
 
-int isx_warper_join(isx_warper* w) {
+int isx_warper_join(isx_warper* w) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_join: null warper");
     ISX_HIP(hipSetDevice(w->device));
@@ -2008,20 +2016,21 @@ int isx_warper_join(isx_warper* w) {
     if (!w->side) return ISX_OK;
     ISX_HIP(hipStreamWaitEvent(w->stream, w->ev_scan, 0));
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_join")
 
-int isx_warper_plan_status(isx_warper* w, int* mismatches) {
+int isx_warper_plan_status(isx_warper* w, int* mismatches) ISX_ENTRY {
     clear_error();
     ISX_CHECK_ARG(w != nullptr && mismatches != nullptr, ISX_ERR_INVALID, "plan_status: null argument");
     *mismatches = 0;
     ISX_HIP(hipSetDevice(w->device));
     ISX_TRY(flush_verify(w));
+    ISX_CHECK_ARG(w->verify_dropped == 0, ISX_ERR_PLAN, "planned warp: %d verification(s) were dropped under ISX_VERIFY_NEVER - this run's plans are unverified", w->verify_dropped);
     if (!w->scan_side.p) return ISX_OK;
     ISX_HIP(hipStreamSynchronize(w->side));
     ISX_HIP(hipStreamSynchronize(w->stream));
     ISX_HIP(hipMemcpy(mismatches, (int*)w->scan_side.p + 5, sizeof(int), hipMemcpyDeviceToHost));
     if (*mismatches) return fail(ISX_ERR_PLAN, "planned warp: %d run(s) produced a ROI that differs from the planned one", *mismatches);
     return ISX_OK;
-}
+} ISX_EXIT("isx_warper_plan_status")
 
 }  // extern "C"

@@ -179,8 +179,8 @@ class PairStitcher:
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
             if self.tile_cols is not None:
                 self.warper.set_dst_columns(0, 0)
-            if getattr(self, "_verify_outside", False):
-                self.warper.discard_pending()   # a captured step: the verification runs beside the graph (replay)
+            if getattr(self, "_capturing_outside", False):
+                self.warper.discard_pending()   # a step being captured: the verification runs beside the graph (replay)
             elif self.mark is None:
                 self.warper.verify()   # the VALU-bound scans run on the side stream under the memory-bound pyramid kernels
             self.blender.prepare(self.corners, self.sizes)
@@ -199,7 +199,7 @@ class PairStitcher:
             self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
         if self.tile_cols is not None:
             self.warper.set_dst_columns(0, 0)
-        if getattr(self, "_verify_outside", False):
+        if getattr(self, "_capturing_outside", False):
             self.warper.discard_pending()
         elif self.mark is None:
             self.warper.verify()
@@ -228,20 +228,26 @@ class PairStitcher:
         # A verification that is a border scan (self.mark is None: every tile's is) stays OUT of the graph: forked inside it by an event it cost
         # a replay 12 us (0.206 -> 0.218 ms at 4K), beside it nothing - replay() queues it from the rig alone and starts it on the
         # verification stream, as the eager step does.  A full-scan verification keeps its place inside (behind the level-`verify_at` pyrDown).
+        # _verify_outside describes the GRAPH (replay() / verify_beside() read it); _capturing_outside is set only while the warm-up and the
+        # captured step run, so that an eager step() after capture() verifies its plan inside the step again.
         self._verify_outside = self.mark is None and not self.interleave and os.environ.get("ISX_GRAPH_VERIFY_INSIDE", "") == ""
         self.gstream = torch.cuda.Stream(device=self.device)
         self.warper.set_stream(self.gstream)
         self.blender.set_stream(self.gstream)
         self.gstream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.gstream):
-            self.step()
-            self.warper.join()
-        torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.gstream, capture_error_mode="relaxed"):
-            self.step()
-            if not self._verify_outside:
-                self.warper.join()      # (with the verification outside, the captured step never leaves its stream: nothing to join)
+        self._capturing_outside = self._verify_outside
+        try:
+            with torch.cuda.stream(self.gstream):
+                self.step()
+                self.warper.join()
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.gstream, capture_error_mode="relaxed"):
+                self.step()
+                if not self._verify_outside:
+                    self.warper.join()      # (with the verification outside, the captured step never leaves its stream: nothing to join)
+        finally:
+            self._capturing_outside = False
         return self.graph
 
     def verify_beside(self):
@@ -252,6 +258,8 @@ class PairStitcher:
             self.warper.verify()
 
     def replay(self):
+        """Replays the captured step AND starts its plan's verification beside it.  A caller that replays the torch graph object directly
+        (self.graph.replay()) must call verify_beside() itself, or check_plan() has nothing to report."""
         self.graph.replay()
         self.verify_beside()
         return self.out, self.out_mask
@@ -276,12 +284,18 @@ class PairStitcher:
             for s in stitchers:
                 if join_all or not s._verify_outside:
                     s.warper.join()
-        with torch.cuda.stream(gstream):
-            one(True)
-        torch.cuda.synchronize(s0.device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=gstream, capture_error_mode="relaxed"):
-            one(False)
+        for s in stitchers:
+            s._capturing_outside = s._verify_outside
+        try:
+            with torch.cuda.stream(gstream):
+                one(True)
+            torch.cuda.synchronize(s0.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=gstream, capture_error_mode="relaxed"):
+                one(False)
+        finally:
+            for s in stitchers:
+                s._capturing_outside = False
         for s in stitchers:
             s.graph = graph
         return graph, gstream

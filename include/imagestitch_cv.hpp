@@ -36,6 +36,8 @@ public:
         if (fixed_rig) isx::check(isx_warper_set_roi_cache(w_.handle(), 1));
     }
     // Point warp(src, K, R, interp_mode, border_mode, dst)  W:145-161: ONE detectResultRoi (W:126), dst.create(h + 1, w + 1) (W:150), remap (W:157)
+    // dst may be a cv::Mat or - as the reference passes it, W:206-207, 229, 232 - a cv::UMat: create() makes the array, getMat() maps it as a Mat
+    // header that lives to the end of this call (the unmap of an OpenCL-backed UMat happens in its destructor, before the caller sees dst).
     cv::Point warp(cv::InputArray src, cv::InputArray K, cv::InputArray R, int interp_mode, int border_mode, cv::OutputArray dst) override {
         float k[9], r[9]; k9(K, k); k9(R, r);
         cv::Mat s = src.getMat();
@@ -145,12 +147,12 @@ private:
     isx::NoBlender b_;
 };
 
-// Blender::createDefault(type, try_gpu) (W:271, 276, 278) for the three types the reference names; the caller owns the object
-// (`Ptr<Blender> blender(isx_cv::createDefaultBlender(Blender::NO));`)
-inline cv::detail::Blender* createDefaultBlender(int type) {
-    if (type == cv::detail::Blender::NO) return new HipNoBlender();
-    if (type == cv::detail::Blender::FEATHER) return new HipFeatherBlender();
-    return new HipMultiBandBlender();
+// Blender::createDefault(type, try_gpu) (W:271, 276, 278) for the three types the reference names, returning what it returns - a
+// Ptr<Blender> - so that `blender = isx_cv::createDefaultBlender(Blender::MULTI_BAND);` replaces W:271 token for token
+inline cv::Ptr<cv::detail::Blender> createDefaultBlender(int type, bool /*try_gpu*/ = false) {
+    if (type == cv::detail::Blender::NO) return cv::Ptr<cv::detail::Blender>(new HipNoBlender());
+    if (type == cv::detail::Blender::FEATHER) return cv::Ptr<cv::detail::Blender>(new HipFeatherBlender());
+    return cv::Ptr<cv::detail::Blender>(new HipMultiBandBlender());
 }
 
 }  // namespace isx_cv

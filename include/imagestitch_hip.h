@@ -41,7 +41,8 @@ typedef enum {
     ISX_ERR_NOMEM = 5,       /* hipMalloc failed                                                */
     ISX_ERR_UNSUPPORTED = 6, /* valid in OpenCV, not implemented on this path                   */
     ISX_ERR_SIZE = 7,        /* caller-allocated output has the wrong rows/cols                 */
-    ISX_ERR_PLAN = 8         /* a planned (sync-free) run saw geometry that differs from plan   */
+    ISX_ERR_PLAN = 8,        /* a planned (sync-free) run saw geometry that differs from plan   */
+    ISX_ERR_INTERNAL = 9     /* a C++ exception was stopped at this boundary (never propagated) */
 } isx_status;
 
 /* ---- cv::Mat type codes: depth + ((cn-1)<<3), same numbers as OpenCV -------------------- */
@@ -439,6 +440,13 @@ int isx_gather_p2p_synchronize(isx_gather* g);
  * written out in packed FMAs (csrc/warp.hip, k_warp_tile).  This compares that recurrence with the compiler's IEEE division
  * on n pseudo-random operand pairs of the range the kernel admits to it; *mismatches must come back 0.              */
 int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches);
+/* Every entry of this header is a function-try-block: a C++ exception raised underneath it (std::bad_alloc of a host container, a
+ * std::length_error, anything a future change throws) is stopped there and comes back as a status - ISX_ERR_NOMEM for the two allocation
+ * failures, ISX_ERR_INTERNAL otherwise, the text in isx_last_error() - never as an exception in the caller's frames (the
+ * reference's own errors are cv::Exceptions, W:94-96).  This entry throws `kind` from inside such a block so that the barrier can be
+ * tested without a GPU: 0 std::bad_alloc, 1 std::length_error (vector::reserve), 2 a failing 2^62-byte allocation, 3 std::runtime_error,
+ * 4 a thrown int, 5 std::out_of_range; any other kind returns ISX_OK.                                                            */
+int isx_selftest_exception_barrier(int kind);
 
 /* ---- per-kernel HIP-event timing (feeds bench.py's roofline object) ----------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on its own stream.               */

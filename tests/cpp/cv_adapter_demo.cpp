@@ -64,6 +64,50 @@ int main(int argc, char** argv) {
             warper->warp(masks[i], K, R[i], 0 /* INTER_NEAREST */, 0 /* BORDER_CONSTANT */, masks_warped[i]);                 // W:232
             printf("corner %d %d %d\n", i, corners[i].x, corners[i].y);
         }
+        {   // The reference's own declarations (W:206-207): vector<UMat> masks_warped, images_warped - the warped tiles are UMats, and
+            // warp() receives them as OutputArray (W:229, 232); W:148 declares UMat xmap, ymap.  Same bytes as the Mat leg above,
+            // through a mapping of the UMat (not through a Mat the caller owns).
+            std::vector<UMat> images_warped_u(num_images), masks_warped_u(num_images);
+            for (int i = 0; i < num_images; ++i) {
+                Point c = warper->warp(imgs[i], K, R[i], 1, 2, images_warped_u[i]);                                         // W:229
+                Size sz = images_warped_u[i].size();                                                                       // W:230
+                warper->warp(masks[i], K, R[i], 0, 0, masks_warped_u[i]);                                                 // W:232
+                Mat iu = images_warped_u[i].getMat(ACCESS_READ), mu = masks_warped_u[i].getMat(ACCESS_READ);
+                const bool same = c.x == corners[i].x && c.y == corners[i].y && sz.width == sizes[i].width && sz.height == sizes[i].height &&
+                                  iu.type() == CV_8UC3 && mu.type() == CV_8U && mu.rows == masks_warped[i].rows && mu.cols == masks_warped[i].cols &&
+                                  memcmp(iu.data, images_warped[i].data, (size_t)iu.rows * iu.step) == 0 &&
+                                  memcmp(mu.data, masks_warped[i].data, (size_t)mu.rows * mu.step) == 0;
+                if (!same || images_warped_u[i].maps() < 2) return 6;
+            }
+            UMat xmap_u, ymap_u;                                                                                           // W:148
+            Mat xmap_m, ymap_m;
+            warper->buildMaps(Size(w, h), K, R[1], xmap_u, ymap_u);
+            warper->buildMaps(Size(w, h), K, R[1], xmap_m, ymap_m);
+            Mat xu = xmap_u.getMat(ACCESS_READ), yu = ymap_u.getMat(ACCESS_READ);
+            if (xu.rows != xmap_m.rows || xu.cols != xmap_m.cols || memcmp(xu.data, xmap_m.data, (size_t)xu.rows * xu.step) != 0 ||
+                memcmp(yu.data, ymap_m.data, (size_t)yu.rows * yu.step) != 0) return 6;
+            // feed() from a UMat mask (W:302 passes masks_seam[k], a Mat; masks_warped stays a UMat until W:296 copies it) and blend() into UMats
+            Ptr<Blender> ub = isx_cv::createDefaultBlender(Blender::NO);
+            Ptr<Blender> mbu = isx_cv::createDefaultBlender(Blender::NO);
+            ub->prepare(corners, sizes); mbu->prepare(corners, sizes);
+            for (int k = 0; k < num_images; ++k) {
+                Mat img_s(images_warped[k].rows, images_warped[k].cols, CV_16SC3);
+                for (int y = 0; y < img_s.rows; ++y) {
+                    const unsigned char* s = images_warped[k].ptr<unsigned char>(y);
+                    short* d = img_s.ptr<short>(y);
+                    for (int x = 0; x < img_s.cols * 3; ++x) d[x] = s[x];
+                }
+                ub->feed(img_s, masks_warped_u[k], corners[k]);
+                mbu->feed(img_s, masks_warped[k], corners[k]);
+            }
+            UMat ur, um;
+            Mat mr, mm;
+            ub->blend(ur, um); mbu->blend(mr, mm);
+            Mat urm = ur.getMat(ACCESS_READ), umm = um.getMat(ACCESS_READ);
+            if (urm.rows != mr.rows || urm.cols != mr.cols || memcmp(urm.data, mr.data, (size_t)mr.rows * mr.step) != 0 ||
+                memcmp(umm.data, mm.data, (size_t)mm.rows * mm.step) != 0) return 6;
+            printf("umat-leg OK\n");
+        }
         {   // buildMaps / warpRoi of the same interface (W:122): sizes as the stock class reports them
             Mat xmap, ymap;
             Rect r = warper->buildMaps(Size(w, h), K, R[0], xmap, ymap), q = warper->warpRoi(Size(w, h), K, R[0]);
@@ -103,7 +147,7 @@ int main(int argc, char** argv) {
         dump(argv[6], "result", result);
         dump(argv[6], "result_mask", result_mask);
         {   // W:276   blender = Blender::createDefault(Blender::NO, false);   (the line the demo runs before it settles on FEATHER)
-            std::unique_ptr<Blender> nb(isx_cv::createDefaultBlender(Blender::NO));
+            Ptr<Blender> nb = isx_cv::createDefaultBlender(Blender::NO);
             nb->prepare(corners, sizes);
             for (int k = 0; k < num_images; ++k) {
                 Mat img_s(images_warped[k].rows, images_warped[k].cols, CV_16SC3);

@@ -51,9 +51,51 @@ private:
     std::shared_ptr<unsigned char> own_;
 };
 
-// the array proxies: a reference to a Mat is all the adapter needs
-class _InputArray { public: _InputArray(const Mat& m) : m_(const_cast<Mat*>(&m)) {} Mat getMat() const { return *m_; } protected: Mat* m_; };
-class _OutputArray : public _InputArray { public: _OutputArray(Mat& m) : _InputArray(m) {} void create(int r, int c, int t) const { m_->create(r, c, t); } };
+// cv::UMat as the reference holds its warped tiles (W:206-207: vector<UMat> masks_warped, images_warped; W:148: UMat xmap, ymap): an array
+// that is NOT a Mat and is reached through getMat(access) - a Mat header over the UMat's storage, as cv::UMat::getMat maps it on a host
+// (non-OpenCL) build.  maps() counts the mappings so that a test can tell the adapter went through one.
+enum { ACCESS_READ = 1 << 24, ACCESS_WRITE = 1 << 25, ACCESS_RW = 3 << 24 };
+class UMat {
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    UMat() {}
+    int type() const { return type_; }
+    bool empty() const { return !buf_; }
+    Size size() const { return Size(cols, rows); }
+    void create(int r, int c, int t) {
+        if (buf_ && r == rows && c == cols && t == type_) return;
+        buf_.reset(new unsigned char[(size_t)r * c * Mat::elemSize(t)], std::default_delete<unsigned char[]>());
+        rows = r; cols = c; type_ = t; step = (size_t)c * Mat::elemSize(t);
+    }
+    Mat getMat(int /*access*/) const { ++maps_; return buf_ ? Mat(rows, cols, type_, buf_.get(), step) : Mat(); }
+    int maps() const { return maps_; }
+private:
+    int type_ = 0;
+    mutable int maps_ = 0;
+    std::shared_ptr<unsigned char> buf_;
+};
+
+// cv::Ptr of 3.4.2 is a reference-counted pointer with an explicit constructor from a raw pointer and conversions between related types
+template <class T> using Ptr = std::shared_ptr<T>;
+
+// the array proxies: a reference to a Mat or to a UMat is all the adapter needs
+class _InputArray {
+public:
+    _InputArray(const Mat& m) : m_(const_cast<Mat*>(&m)), u_(nullptr) {}
+    _InputArray(const UMat& u) : m_(nullptr), u_(const_cast<UMat*>(&u)) {}
+    Mat getMat() const { return m_ ? *m_ : u_->getMat(ACCESS_RW); }
+    bool isUMat() const { return u_ != nullptr; }
+protected:
+    Mat* m_;
+    UMat* u_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    _OutputArray(UMat& u) : _InputArray(u) {}
+    void create(int r, int c, int t) const { if (m_) m_->create(r, c, t); else u_->create(r, c, t); }
+};
 typedef _OutputArray _InputOutputArray;
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;

@@ -52,6 +52,44 @@ def test_no_cpu_fallback_without_gpu(libpath):
     assert e.value.code == 4
 
 
+def test_every_entry_is_behind_the_exception_barrier(libpath):
+    """SURVEY §5 "no exceptions across the boundary": (1) every `int isx_*` definition under csrc/ is a function-try-block
+    (ISX_ENTRY ... ISX_EXIT("its own name")), bar the three one-liners that cannot throw; (2) the barrier works: exceptions thrown inside a
+    guarded entry - incl. two REAL allocation failures of std::vector - come back as ISX_ERR_NOMEM / ISX_ERR_INTERNAL with a message, in a
+    child process that would otherwise die of std::terminate."""
+    csrc = os.path.join(ROOT, "imagestitch_amd", "csrc")
+    entries, bad = 0, []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cpp", ".hip")):
+            continue
+        src = open(os.path.join(csrc, f), errors="replace").read()
+        for m in re.finditer(r"^(?:int|void|const char\*) (isx_\w+)\(", src, re.M):
+            name = m.group(1)
+            head = src[m.start():src.index("{", m.start()) + 1]
+            if name in ("isx_last_error", "isx_version", "isx_profile_enable"):
+                continue
+            entries += 1
+            if "ISX_ENTRY" not in head or ('} ISX_EXIT("%s")' % name) not in src:
+                bad.append((f, name))
+    assert entries >= 80 and not bad, bad
+    code = r"""
+import ctypes as C, sys
+lib = C.CDLL(sys.argv[1])
+lib.isx_last_error.restype = C.c_char_p
+out = []
+for kind in range(7):
+    rc = lib.isx_selftest_exception_barrier(kind)
+    out.append((kind, rc, lib.isx_last_error().decode()))
+for o in out: print(o)
+want = {0: 5, 1: 5, 2: 5, 3: 9, 4: 9, 5: 9, 6: 0}
+assert all(rc == want[k] for k, rc, _ in out), out
+assert all(("isx_selftest_exception_barrier" in msg) == (k < 6) for k, _, msg in out), out
+print("BARRIER OK")
+"""
+    r = subprocess.run([os.sys.executable, "-c", code, libpath], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "BARRIER OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under imagestitch_amd/ may reference it."""
     pkg = os.path.join(ROOT, "imagestitch_amd")

@@ -38,6 +38,8 @@ def test_cpp_mirror_pipeline_matches_oracle(gpu, oracle, tmp_path, demo):
         elif len(t) == 4:
             info[t[0]] = (int(t[1]), int(t[2]), int(t[3]))
     assert "throws 3" in out          # feed after blend -> ISX_ERR_STATE
+    if demo == "cv_adapter_demo":     # the reference's vector<UMat> declarations (W:206-207, W:148) through the same adapter: same bytes as the Mat leg
+        assert "umat-leg OK" in out
     K, Rs = synth.camera_pair(W, H, F)
     o_w, o_m = [], []
     for i in range(2):

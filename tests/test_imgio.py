@@ -217,6 +217,44 @@ def test_progressive_jpeg_read_equals_libjpeg_bit_for_bit(isx, tmp_path, shape):
     assert n == 108
 
 
+def _one_bit_per_block_progressive_jpeg(size):
+    """A valid grey SOF2 file that spends ONE bit per block: a DC-first scan of zero differences under a 1-bit Huffman code and one AC scan of
+    end-of-band runs (what a mozjpeg-style scan script without DC successive approximation makes of a flat image)."""
+    import struct
+    def seg(marker, payload):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(payload) + 2) + payload
+    blocks = (size // 8) ** 2
+    assert size % 8 == 0 and blocks % 16384 == 0
+    out = b"\xff\xd8"
+    out += seg(0xDB, bytes([0]) + bytes([16] * 64))                                       # DQT 0
+    out += seg(0xC2, bytes([8]) + struct.pack(">HH", size, size) + bytes([1, 1, 0x11, 0]))   # SOF2: one component, 1 x 1, table 0
+    out += seg(0xC4, bytes([0x00]) + bytes([1] + [0] * 15) + bytes([0]))                  # DC table 0: the code "0" = category 0
+    out += seg(0xDA, bytes([1, 1, 0x00, 0, 0, 0x00]))                                     # SOS: DC first, Ss = Se = 0, Ah = Al = 0
+    out += bytes(blocks // 8)                                                             # one "0" bit per block
+    out += seg(0xC4, bytes([0x10]) + bytes([1] + [0] * 15) + bytes([0xE0]))               # AC table 0: the code "0" = EOB14 (a run of 16384 + 14 extra bits)
+    out += seg(0xDA, bytes([1, 1, 0x00, 1, 63, 0x00]))                                    # SOS: AC first, 1..63, Ah = Al = 0
+    nbits = 15 * (blocks // 16384)
+    pad = (-nbits) % 8
+    out += int(("0" * nbits + "1" * pad), 2).to_bytes((nbits + pad) // 8, "big")
+    return out + b"\xff\xd9"
+
+
+def test_progressive_jpeg_of_one_bit_per_block_is_read(isx, tmp_path):
+    """the frame-size plausibility bound (two bits per block) holds for sequential files only.  2048 x 2048 in 8.3 KB."""
+    data = _one_bit_per_block_progressive_jpeg(2048)
+    assert len(data) < 8400
+    p = str(tmp_path / "flat.jpg")
+    open(p, "wb").write(data)
+    ref = np.asarray(PIL.open(p).convert("RGB"))[:, :, ::-1]
+    assert ref.shape == (2048, 2048, 3) and (ref == 128).all()
+    assert np.array_equal(isx.imread(p), ref)
+    # the sequential bound is still there: the same header as SOF0 over the same few bytes is refused before anything is allocated
+    bad = data.replace(b"\xff\xc2", b"\xff\xc0", 1)
+    open(p, "wb").write(bad)
+    with pytest.raises(isx.IsxError):
+        isx.imread(p)
+
+
 def test_progressive_jpeg_incomplete_scans_are_refused(isx, tmp_path):
     """A progressive file cut before its last scans: libjpeg would decode what it has and smooth the blocks; this reader says so instead
     of returning different bytes."""
