@@ -367,6 +367,11 @@ def main():
                     help="N > 1: torch.distributed (RCCL), the library's own RCCL communicator (isx_gather_*), or the direct schedule "
                          "(isx_gather_p2p_*: every chunk copied straight into every rank's buffer, one stream per destination - tells RCCL's "
                          "schedule from the links)")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="N > 1 (or --force-dist): after the timed legs one more step, then EVERY rank compares every chunk of its gathered buffer - every pair "
+                         "of every rank, or every strip of every panorama - with that mosaic stitched serially on its own (the rank's images regenerated from "
+                         "their seed, the synchronous step, no window): multi_gpu.gather_check in the line.  The rehearsal of an N-GPU run on whatever is there "
+                         "(tests/test_gpu_dist.py walks world 8 on one GPU with it)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--preflight-ms", type=float, default=60.0,
@@ -459,9 +464,9 @@ def main():
             raise SystemExit("--shard strips: %d ranks are more than this %d-column panorama has strips of %d columns" % (strip_world, fw_all, strip_cols))
         del wp
     pstreams = [None] if (args.streams <= 1 or args.graph) else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
-    for p in range(args.pairs):
-        gen.manual_seed(synth.SEED0 + p + (0 if strips else 1000 * rank))     # strips: every rank holds the SAME panorama's tiles
-        # same statistics as synth.make_tile (sinusoid + U{-32..31} noise), generated on the device
+    def make_imgs(seed):
+        """the NT tiles of one mosaic: the statistics of synth.make_tile (sinusoid + U{-32..31} noise), generated on the device from `seed`"""
+        gen.manual_seed(seed)
         yy, xx = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
         imgs = []
         for t in range(NT):
@@ -471,11 +476,17 @@ def main():
                 noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
                 chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
             imgs.append(torch.stack(chans, dim=2).contiguous())
+        return imgs
+
+    def seed_of(p, r):
+        return synth.SEED0 + p + (0 if strips else 1000 * r)     # strips: every rank holds the SAME panorama's tiles
+
+    for p in range(args.pairs):
+        imgs = make_imgs(seed_of(p, rank))
         if p == 0 and rank == 0:
             host_imgs0 = [im.cpu().numpy() for im in imgs]
         pairs.append(PairStitcher(imgs, K, Rs, F, args.kind, args.bands, prec, local, pstreams[p % len(pstreams)], "uint8" if (world > 1 or args.force_dist) else "int16",
                                   deferred={"deferred": True, "copy": "copy", "eager": False}[args.cycle], window=window, tile_type=args.tile_type))
-        del yy, xx
     if args.roi_cache:
         for p in pairs:
             p.warper.set_roi_cache(True)
@@ -745,6 +756,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_c, dt_g = (float(v) for v in t.tolist())
         split = (dt_c, dt_g, int(send[0].numel()))
+    gather_check = None
+    if use_dist and args.check_gather:
+        # One more step; then every chunk this rank RECEIVED (world x pairs of them) against the same mosaic stitched here, serially, from the
+        # owning rank's seed: rank / world indexing, chunk offsets, the neighbour order of the direct schedule, the strips' windows - whatever
+        # would put a mosaic into the wrong place or leave a stale one there.  (--graph: the graphs always write send[0].)
+        fence()
+        gather_buf.fill_(0x5a)
+        fence()
+        step()
+        fence()
+        bad, checked = [], 0
+        for i in range(len(pairs)):
+            sh, pt = shapes[i], pitches[i]
+            off, n = chunks[i]
+            whole = None
+            if strips:      # the whole panorama i, no window: strip q is its columns windows[q]
+                ref = PairStitcher(make_imgs(seed_of(i, 0)), K, Rs, F, args.kind, args.bands, prec, local, None, "uint8", deferred=True, tile_type=args.tile_type)
+                whole = ref.step_sync()[0].clone()
+                del ref
+            for q in range(world):
+                # where rank q's chunk i lies: pair by pair, every chunk's copies are rank-major inside that chunk's own stretch of the buffer
+                # (mosaic.gather_chunk / isx_gather_chunk / p2p_chunk: world * offset + q * count); as one collective, rank-major blocks
+                at = world * off + q * n if args.gather == "chunk" else q * n_out + off
+                got = gather_buf[at:at + n].as_strided(sh, (pt, sh[2], 1))
+                if strips:
+                    w0, w1 = windows[q]
+                    valid = min(w1, fw_all) - w0
+                    same = valid > 0 and bool(torch.equal(got[:, :valid], whole[:, w0:w0 + valid]))
+                else:
+                    ref = PairStitcher(make_imgs(seed_of(i, q)), K, Rs, F, args.kind, args.bands, prec, local, None, "uint8", deferred=True, tile_type=args.tile_type)
+                    same = bool(torch.equal(got, ref.step_sync()[0]))
+                    del ref
+                checked += 1
+                if not same:
+                    bad.append((q, i))
+        t = torch.tensor([len(bad)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        gather_check = {"chunks_per_rank": checked, "mismatched_over_all_ranks": int(t.item()), "mismatched_here": bad[:8],
+                        "what": "every rank compared every received chunk with that mosaic stitched serially from the owner's seed"}
+        fence()
 
     if rank == 0:
         # strips: the unit of work is the panorama, whichever ranks touch a tile (neighbours' tiles are recomputed, not counted twice)
@@ -825,6 +876,7 @@ def main():
                                 **({"gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1)} if world > 1 else
                                    {"local_copy_GBs": round(nsend / (dt_g / args.steps) / 1e9, 1)}),
                                 "gather": args.gather, "gather_backend": args.gather_backend,
+                                **({"gather_check": gather_check} if gather_check is not None else {}),
                                 "note": "value = steps with the gathers overlapped with the blends that follow them; the two legs here are timed after "
                                         "it, each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}
         if world == 1 and args.pairs == 1 and not args.graph and not args.no_dropin:

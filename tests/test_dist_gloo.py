@@ -55,3 +55,46 @@ def test_all_gather_assembly_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_pairs, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def _worker_chunks(rank, world, port, n_pairs, ret):
+    """bench.py's default schedule over gloo: the block travels pair by pair (mosaic.gather_chunk, one collective per pair into that pair's
+    place of every rank's block), ragged shapes, 4-byte padded rows - world 8, 32 pairs = BASELINE config 4's sharding."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = mosaic.shard_pairs(n_pairs, world, rank)
+    per = hi - lo
+    ok = per == n_pairs // world
+    # every rank's pair j is (5 + j) rows x (7 + j) px x 3 bytes, rows padded to 4 bytes, filled with rank * 16 + j + 1
+    shapes = [(5 + j, 7 + j, 3) for j in range(per)]
+    pitches = [(sh[1] * sh[2] + 3) // 4 * 4 for sh in shapes]
+    n_out = sum(sh[0] * pt for sh, pt in zip(shapes, pitches))
+    send = torch.zeros((n_out,), dtype=torch.uint8)
+    gather_buf = torch.full((world * n_out,), 0x5a, dtype=torch.uint8)
+    chunks, off = [], 0
+    for j, (sh, pt) in enumerate(zip(shapes, pitches)):
+        n = sh[0] * pt
+        send[off:off + n].as_strided(sh, (pt, sh[2], 1)).fill_(rank * 16 + j + 1)
+        chunks.append((off, n))
+        off += n
+    for (o, n) in chunks:
+        mosaic.gather_chunk(send, o, n, gather_buf)
+    for q in range(world):
+        for j, ((o, n), sh, pt) in enumerate(zip(chunks, shapes, pitches)):
+            got = mosaic.chunk_view(gather_buf, world, o, n, q).as_strided(sh, (pt, sh[2], 1))     # chunk-major: world * offset + q * count
+            ok = ok and bool(torch.all(got == q * 16 + j + 1))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_assembly_world8_gloo_32_pairs():
+    """SURVEY §8(e) / BASELINE config 4 at its real world size: shard_pairs(32, 8, r) -> 4 pairs per rank, one whole-block all-gather and
+    the pair-by-pair schedule, every rank's assembled batch checked on every rank (rank / offset bugs at N > 2 would otherwise meet the
+    first 8-GPU run)."""
+    world, n_pairs = 8, 32
+    mgr = mp.Manager()
+    for worker in (_worker, _worker_chunks):
+        ret = mgr.dict()
+        mp.spawn(worker, args=(world, _free_port(), n_pairs, ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world)), (worker.__name__, dict(ret))

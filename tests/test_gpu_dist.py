@@ -328,3 +328,45 @@ def test_bench_walks_its_n2_path_on_one_gpu(gpu, tmp_path, backend, gather, shar
     assert d["n_gpus"] == 2 and d["scaling"] == ("weak" if shard == "pairs" else "strong") and d["value"] > 0 and d["config"]["pairs_per_gpu"] == 2
     mg = d["multi_gpu"]
     assert mg["gather_backend"] == backend and mg["gather"] == gather and mg["send_bytes_per_rank"] > 0 and mg["gather_bus_GBs"] > 0 and mg["without_gather_Mpix_s"] > 0
+
+
+
+@pytest.mark.parametrize("backend,gather,shard", [("p2p", "chunk", "pairs"), ("torch", "single", "pairs"), ("torch", "chunk", "pairs"), ("p2p", "single", "pairs"),
+                                                  ("p2p", "chunk", "strips"), ("torch", "single", "strips")])
+def test_bench_walks_its_n8_path_on_one_gpu(gpu, tmp_path, backend, gather, shard):
+    """The rehearsal of the first 8-GPU run: bench.py at WORLD SIZE 8 on one GPU (ISX_BENCH_ONE_GPU=1), BASELINE config 4's
+    real shape - 32 pairs, 4 per rank (small tiles) - through the direct schedule (HIP IPC between 8 processes: every rank maps 7 peers'
+    buffers and pushes to them in its neighbour order) and through torch.distributed's collectives (gloo transport), pair by pair and as one
+    collective; and ONE panorama of 64 tiles cut into 8 column strips.  --check-gather: every rank compares all 32 chunks (8 strips) it
+    received with that mosaic stitched serially from the owning rank's seed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISX_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2", "--preflight-ms", "0",
+           "--gather-backend", backend, "--gather", gather, "--check-gather", "--no-cpu-baseline", "--no-dropin", "--no-live-traffic"]
+    if shard == "strips":      # ONE panorama of 64 tiles (config 4's tile count) per step, cut into eight column strips (strong scaling)
+        cmd += ["--shard", "strips", "--tiles", "64", "--pairs", "1", "--width", "320", "--height", "180", "--focal", "800", "--yaw", "0.045", "--bands", "3"]
+    else:
+        cmd += ["--pairs", "4", "--width", "640", "--height", "360", "--focal", "500"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == ("weak" if shard == "pairs" else "strong") and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks"] == 8 and mg["gather_backend"] == backend and mg["gather"] == gather
+    chk = mg["gather_check"]
+    assert chk["chunks_per_rank"] == (32 if shard == "pairs" else 8) and chk["mismatched_over_all_ranks"] == 0, chk
+    if shard == "pairs":
+        assert d["config"]["pairs_per_gpu"] == 4 and d["config"]["tiles_per_mosaic"] == 2
+        # the send block: 4 mosaics of CV_8UC3 rows padded to 4 bytes
+        px = d["config"]["mosaic_px"]
+        assert 4 * 3 * px <= mg["send_bytes_per_rank"] <= 4 * (3 * px + 3 * 4096)
+    else:
+        assert d["config"]["tiles_per_mosaic"] == 64 and d["config"]["strip"] == "0/8"
