@@ -476,6 +476,7 @@ def main():
                 noise = torch.randint(-32, 32, (H, W), device=dev, generator=gen).float()
                 chans.append((base.round() + noise).clamp(0, 255).to(torch.uint8))
             imgs.append(torch.stack(chans, dim=2).contiguous())
+        torch.cuda.synchronize(dev)      # the tiles exist before anything on another stream reads them (or recycles this function's temporaries)
         return imgs
 
     def seed_of(p, r):
@@ -786,14 +787,27 @@ def main():
                     same = valid > 0 and bool(torch.equal(got[:, :valid], whole[:, w0:w0 + valid]))
                 else:
                     ref = PairStitcher(make_imgs(seed_of(i, q)), K, Rs, F, args.kind, args.bands, prec, local, None, "uint8", deferred=True, tile_type=args.tile_type)
-                    same = bool(torch.equal(got, ref.step_sync()[0]))
+                    ref_out = ref.step_sync()[0].clone()
+                    same = bool(torch.equal(got, ref_out))
                     del ref
                 checked += 1
                 if not same:
                     bad.append((q, i))
-        t = torch.tensor([len(bad)], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        gather_check = {"chunks_per_rank": checked, "mismatched_over_all_ranks": int(t.item()), "mismatched_here": bad[:8],
+                    if os.environ.get("ISX_CHECK_DEBUG") and q == rank and not strips:
+                        exp = ref_out
+                        d = (got != exp).any(dim=2)
+                        ys, xs = torch.nonzero(d, as_tuple=True)
+                        own = pairs[i].out
+                        msg = "rank %d pair %d: %d px differ, x %d..%d y %d..%d of %s; own out equals ref: %s; own out equals got: %s" % (
+                            rank, i, int(d.sum()), int(xs.min()), int(xs.max()), int(ys.min()), int(ys.max()), tuple(got.shape), bool(torch.equal(own, exp)), bool(torch.equal(own, got)))
+                        for rep in range(3):
+                            pairs[i].step(); torch.cuda.synchronize()
+                            msg += "; again %d: %s" % (rep, bool(torch.equal(pairs[i].out, exp)))
+                        print(msg, file=sys.stderr, flush=True)
+        every = [None] * world
+        dist.all_gather_object(every, bad)
+        gather_check = {"chunks_per_rank": checked, "mismatched_over_all_ranks": sum(len(b_) for b_ in every),
+                        "mismatched_by_rank": {str(r_): b_[:8] for r_, b_ in enumerate(every) if b_},
                         "what": "every rank compared every received chunk with that mosaic stitched serially from the owner's seed"}
         fence()
 

@@ -96,6 +96,14 @@ class PairStitcher:
         self.blender.set_overlap(self.interleave)
         self.precision, self.num_bands = precision, num_bands
         dev = torch.device("cuda", device)
+        # This object works on `stream`; its inputs were produced, and its buffers are about to be allocated, on the caller's current stream.
+        # torch's side streams are not ordered against that one: (1) the planning warps below must not read `imgs` before they exist, and
+        # (2) a buffer torch.empty() hands out here may be a block the caller's stream has released but not finished with (the caching
+        # allocator recycles within one stream's order only) - written from `stream` too early it corrupts whatever still reads that block.
+        # (Round 5: bench.py's world-8 rehearsal found exactly that - the temporaries of its image generator recycled as warped-tile
+        # buffers, one or two of 32 input images damaged for good on a busy GPU.)  So: order `stream` behind the caller's stream once.
+        if stream is not None and hasattr(stream, "wait_stream"):
+            stream.wait_stream(torch.cuda.current_stream(dev))
         # plan: ROI per tile (detectResultRoi), output buffers, seam masks
         src_size = next((im.shape[1], im.shape[0]) for im in imgs if im is not None)   # one rig: every tile has the same size
         self.rois = [self.warper.warpRoi(src_size if im is None else (im.shape[1], im.shape[0]), K, R) for im, R in zip(imgs, Rs)]
