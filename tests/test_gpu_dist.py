@@ -367,6 +367,6 @@ def test_bench_walks_its_n8_path_on_one_gpu(gpu, tmp_path, backend, gather, shar
         assert d["config"]["pairs_per_gpu"] == 4 and d["config"]["tiles_per_mosaic"] == 2
         # the send block: 4 mosaics of CV_8UC3 rows padded to 4 bytes
         px = d["config"]["mosaic_px"]
-        assert 4 * 3 * px <= mg["send_bytes_per_rank"] <= 4 * (3 * px + 3 * 4096)
+        assert mg["send_bytes_per_rank"] % 4 == 0 and 4 * 3 * px * 0.7 <= mg["send_bytes_per_rank"] <= 4 * 3 * px      # (the result is the padded mosaic - mosaic_px - cropped to the tiles' union)
     else:
         assert d["config"]["tiles_per_mosaic"] == 64 and d["config"]["strip"] == "0/8"
