@@ -204,17 +204,23 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
     for pname in ("f32", "i16"):
         prec = prec_map[pname]
         ps = PairStitcher([torch.from_numpy(h).to(dev) for h in host_imgs], K, Rs, F, args.kind, args.bands, prec, dev.index, None, "int16", deferred="copy")
+        # frac_model: SURVEY 8(d)'s work model of the pair in this precision (every level materialised once, destination pyramid read-modify-written;
+        # exact geometry) / the leg's time / 8 TB/s - the yardstick north_star's 0.60 is stated on, per path (a normalisation: see model_rate)
+        model = ps.bytes_model()["total"]
+        fm = lambda t: round(model / t / 1e9 / HBM_PEAK_GBS, 3)
         dt = timed(ps.step_sync, steps)
-        out["fused_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1)}
+        out["fused_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1), "frac_model": fm(dt)}
         ref_out, ref_mask = ps.out.clone(), ps.out_mask.clone()
         dt = timed(ps.step_literal, steps)
         same = bool(torch.equal(ps.lit_out, ref_out) and torch.equal(ps.lit_out_mask, ref_mask))
-        out["literal_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1), "equals_fused": same}
+        out["literal_device_" + pname] = {"ms_per_pair": round(dt * 1e3, 4), "Mpix_s": round(mpix / dt, 1), "frac_model": fm(dt), "equals_fused": same,
+                                          "feed_path": ps.blender.feed_path()}
         ps.warper.set_roi_cache(True)       # the adapter's fixed_rig option: detectResultRoi of an unchanged (K, R, size) is remembered
         dt = timed(ps.step_literal, steps)
         ps.warper.set_roi_cache(False)
         out["literal_device_" + pname]["fixed_rig_ms_per_pair"] = round(dt * 1e3, 4)
         out["literal_device_" + pname]["fixed_rig_Mpix_s"] = round(mpix / dt, 1)
+        out["literal_device_" + pname]["fixed_rig_frac_model"] = fm(dt)
         del ref_out, ref_mask
         seam_host = [m.cpu().numpy() for m in ps.seam]
         corners, sizes, shape_out = ps.corners, ps.sizes, tuple(ps.out.shape)
@@ -274,11 +280,19 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
                         blender.feed(w16[i], seam[i], cs[i])
                     blender.blend(res2, res_mask2)
                 dt = timed(host_literal, n_host)
+                # the caller's own share of that: convertTo(CV_16S) of both warped tiles on the host (numpy here, OpenCV in the reference), alone
+                tc = time.perf_counter()
+                for _ in range(n_host):
+                    for i in range(len(src)):
+                        np.copyto(w16[i], wimg[i])
+                dt_conv = (time.perf_counter() - tc) / n_host
                 h2d = sum(a.nbytes for a in src) + sum(a.nbytes for a in smask) + sum(a.nbytes for a in w16) + sum(a.nbytes for a in seam)
                 out["literal_host_" + pname] = {"ms_per_pair": round(dt * 1e3, 3), "Mpix_s": round(mpix / dt, 1), "h2d_MB": round(h2d / 1e6, 1),
                                                 "d2h_MB": round(d2h / 1e6, 1), "pcie_GBs": round((h2d + d2h) / dt / 1e9, 1), "steps": n_host,
                                                 "equals_fused": bool(np.array_equal(res, res2) and np.array_equal(res_mask, res_mask2)),
-                                                "note": "includes the caller's convertTo(CV_16S) on the host (numpy here)"}
+                                                "caller_convertTo_ms": round(dt_conv * 1e3, 3), "library_ms_per_pair": round((dt - dt_conv) * 1e3, 3),
+                                                "note": "ms_per_pair includes the caller's convertTo(CV_16S) on the host (numpy here), timed alone as caller_convertTo_ms; "
+                                                        "library_ms_per_pair = the calls into the library"}
             del warper, blender
     # the link alone, one direction at a time (pageable host memory, as a cv::Mat is): what the host legs above are made of
     nb = int(out["fused_host_f32"]["h2d_MB"] * 1e6 / 2)
@@ -849,9 +863,23 @@ def main():
             if unmeasured:
                 step_hbm["traffic_is_algorithmic_for"] = unmeasured
             step_hbm["frac_traffic"] = round(tr / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # every kernel of the (serialised, fully bracketed) step against the 8 TB/s roofline by its own algorithmic bytes, and - when the PMC passes
+        # ran - the fabric bytes it moved per launch and their ratio to the algorithmic ones
+        for name, v in per_kernel.items():
+            if v["ms"] > 0 and v["alg_MB"] > 0:
+                v["frac"] = round(v["alg_MB"] * 1e6 / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+            per = (allk or {}).get(name) or (allk or {}).get("k_" + name)
+            if per is not None and v["launches"]:
+                v["traffic_MB_per_launch"] = round(per / 1e6, 2)
+                if v["alg_MB"] > 0:
+                    v["traffic_over_alg"] = round(per * v["launches"] / (v["alg_MB"] * 1e6), 3)
         out = {
             "metric": "Mpix/s warp+5-band-blend @4K pair", "value": round(mpix_step * args.steps / dt, 1), "unit": "Mpix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # what ran untimed before the K timed steps: the pre-flight steps (clock ramp, see `preflight`), then the W warm-up steps (one of them the
+            # serialised, bracketed step) - `warmup` echoes the flag, this is the count
+            "preflight_steps": preflight_steps, "untimed_steps_before_region": preflight_steps + (1 if args.warmup >= 1 else 0) + 1 + max(args.warmup - 2, 1 if args.warmup >= 1 else 0),
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strips else "weak", "vs_baseline": None, "dtype": {"i16": "s16", "f32": "f32", "f16acc32": "f16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("ONE panorama per step cut into %d column strips, strip %d here: " % (strip_world, strip_rank) if strips else "") + "%s%d x (%d x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
