@@ -319,6 +319,67 @@ def dropin_legs(args, K, Rs, host_imgs, dev, prec_map):
     return out
 
 
+def a13_line(args):
+    """bench.py --a13: the in-tree linear-ramp pair blend (B:141-717: SSD cost map, greedy seam, overlap classes, ramp weights, compose) on the two
+    warped tiles of the BASELINE config-2 pair as the reference feeds them (CV_32FC3, W:261; corners from the warper), device mats.  A call ends
+    with the seam on the host (cv::Mat semantics: one synchronisation), so a step = one call.  value = source-tile Mpix/s; roofline = the heaviest
+    launch by its own algorithmic bytes, HIP events in the timed region."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import imagestitch_amd
+    from imagestitch_amd import _lib, synth
+    from imagestitch_amd.pipeline import PairStitcher
+    lib = imagestitch_amd.load()
+    dev = torch.device("cuda", 0)
+    W, H, F = args.width, args.height, args.focal
+    K, Rs = synth.camera_ring(W, H, F, 2, 2.0 * args.yaw)
+    imgs = [torch.from_numpy(synth.make_tile(H, W, i)).to(dev) for i in range(2)]
+    ps = PairStitcher(imgs, K, Rs, F, args.kind, args.bands, _lib.PREC_F32, 0, None, "int16", deferred=True)
+    ps.step_sync()
+    t1, t2 = (w.to(torch.float32).contiguous() for w in ps.warped)            # images_warped[i].convertTo(images_warped_f[i], CV_32F)  W:261
+    (x1, y1), (x2, y2) = ps.corners
+    pr, pc = C.c_int(), C.c_int()
+    _lib.check(lib.isx_blend_pair_linear_size(t1.shape[0], t1.shape[1], t2.shape[0], t2.shape[1], x1, y1, x2, y2, C.byref(pr), C.byref(pc)))
+    pano = torch.empty((pr.value, pc.value, 3), dtype=torch.float32, device=dev)
+    seam = np.zeros(pr.value, np.int32)
+    m1, m2, mp = _lib.as_mat(t1), _lib.as_mat(t2), _lib.as_mat(pano)
+
+    def call():
+        _lib.check(lib.isx_blend_pair_linear(C.byref(m1), C.byref(m2), x1, y1, x2, y2, C.byref(mp), seam.ctypes.data_as(_lib._IP), 0, None))
+    for _ in range(max(args.warmup, 1) + 50):
+        call()
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # ... and the same K calls again with every launch bracketed by HIP events (outside the timed region: bracketing serialises the launches)
+    lib.isx_profile_enable(1); lib.isx_profile_filter(None); lib.isx_profile_sample(1); lib.isx_profile_reset()
+    for _ in range(args.steps):
+        call()
+    gc.enable()
+    ent = _lib.profile_entries()
+    lib.isx_profile_enable(0)
+    per = {k: {"ms": round(v["ms"] / args.steps, 4), "alg_MB": round(v["alg_bytes"] / args.steps / 1e6, 2),
+               **({"frac": round(v["alg_bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS, 3)} if v["ms"] > 0 and v["alg_bytes"] > 0 else {})} for k, v in ent.items()}
+    dom = max(ent.items(), key=lambda kv: kv[1]["ms"])[0]
+    e = ent[dom]
+    ach = e["alg_bytes"] / e["ms"] / 1e6
+    mpix = (t1.shape[0] * t1.shape[1] + t2.shape[0] * t2.shape[1]) / 1e6
+    out = {"metric": "Mpix/s linear-ramp pair blend (B:141-717) @4K pair", "value": round(mpix / dt, 1), "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "A13: 2 warped %dx%d / %dx%d CV_32FC3 tiles of the config-2 pair (overlap %d columns) -> %dx%d panorama, one call per step, the seam returned to the host"
+                                  % (t1.shape[1], t1.shape[0], t2.shape[1], t2.shape[0], x1 + t1.shape[1] - x2, pc.value, pr.value), "warped_Mpix": round(mpix, 3)},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(e["ms"] / e["launches"], 5), "alg_bytes_per_launch": int(e["alg_bytes"] / e["launches"]), "launches": e["launches"]},
+           "kernels_ms_one_step": per, "kernel_sum_ms": round(sum(v["ms"] for v in per.values()), 4),
+           "seam_walk_ms": round(sum(v["ms"] for k, v in per.items() if k.startswith("lin_seam")), 4)}
+    print(json.dumps(out), flush=True)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it: check that the node has N GPUs, then become
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>`
@@ -381,6 +442,9 @@ def main():
                     help="N > 1: torch.distributed (RCCL), the library's own RCCL communicator (isx_gather_*), or the direct schedule "
                          "(isx_gather_p2p_*: every chunk copied straight into every rank's buffer, one stream per destination - tells RCCL's "
                          "schedule from the links)")
+    ap.add_argument("--a13", action="store_true",
+                    help="instead of the multi-band path: the reference's in-tree linear-ramp pair blend (B:141-717, SURVEY A13) on the warped CV_32FC3 tiles "
+                         "of the same pair (W:261 convertTo(CV_32F)) - Mpix/s per call on device mats and the roofline of its heaviest launch")
     ap.add_argument("--check-gather", action="store_true",
                     help="N > 1 (or --force-dist): after the timed legs one more step, then EVERY rank compares every chunk of its gathered buffer - every pair "
                          "of every rank, or every strip of every panorama - with that mosaic stitched serially on its own (the rank's images regenerated from "
@@ -414,6 +478,10 @@ def main():
     from imagestitch_amd import _lib, synth
     from imagestitch_amd.pipeline import PairStitcher
 
+    if args.a13:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+        return a13_line(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)      # does not return: this process becomes torch.distributed.run with --gpus ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))

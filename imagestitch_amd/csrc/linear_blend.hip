@@ -1,7 +1,7 @@
 // linear_blend.hip — the reference's in-tree single-band seam-ramp pair blend (B:141-717) on gfx950.
 // Stages (all row-major f32, as in the reference):
 //   k_lin_cost     costV SSD map                                  B:207-261
-//   k_lin_seam     greedy seam walk (sequential by nature)        B:268-307
+//   k_lin_seam_*   greedy seam walk as a composition of chunk maps B:268-307   (maps in parallel, 91 dependent steps, rows in parallel)
 //   k_lin_classify gray (cvtColor RGB2GRAY) + overlap classes     B:313-470
 //   k_lin_rows     per-row left/right scan, ramp weights, cleanup B:483-572   (one wave per row)
 //   k_lin_compose  left-only / right-only / weighted overlap      B:579-711
@@ -47,17 +47,23 @@ __global__ __launch_bounds__(256) void k_lin_cost(LinGeom g, const unsigned char
     costV[(size_t)y * cw + x] = c;
 }
 
-// Five waves.  The seam moves at most one column per row (B:268-307), and which way it moves from column x of row y depends on
-// costV[y + 1][x - 1 .. x + 1] alone.  So waves 1-4 (the producers) turn a window of SEAM_ROWS x 256 costs into a table of steps
-// (-1 / 0 / +1 per cell, every lane four columns of its rows, the reference's comparisons and tie order), and wave 0 (the walker)
-// only follows the table: one dependent LDS byte per row.  Chunks are double-buffered in LDS; the producer fetches a chunk's costs
-// two chunks before it is walked, centred where the seam stands then - by the time it is walked the seam has moved at most
-// 3 * SEAM_ROWS = 72 columns, well inside the 128 the window reaches to either side - so neither the memory latency nor the
-// comparisons are on the walker's path.  (First version: one wave, a 64-column window per 24 rows loaded and then walked with three
-// LDS reads and the comparisons per row: 483 us for the 2170 rows of a 4K pair.)
-constexpr int SEAM_ROWS = 24;
-constexpr int SEAM_W = 256;
-static_assert(3 * SEAM_ROWS + 2 < SEAM_W / 2, "a window fetched three chunks ahead still holds the seam and its neighbours");
+// The greedy seam walk (B:268-307) without its serial chain.  The walk is a composition of per-row maps  x -> x + dir[y][x]  (dir = -1 / 0 / +1
+// from the three costs below, the reference's comparisons and tie order; columns clamped into the cost map), and a composition of maps can be
+// bracketed any way one likes:
+//   k_lin_seam_maps  every chunk of SEAM_ROWS rows, every start column, in parallel: where does a walk that ENTERS the chunk at column x leave
+//                    it?  One thread per (chunk, column) walks its 24 rows out of a cost tile in LDS; the answer is a signed byte (|x' - x| <= 24).
+//   k_lin_seam_entry one block walks the chunk maps instead of the rows: 91 dependent steps for the 2170 rows of a 4K pair, the maps of 46 chunks
+//                    at a time staged in LDS on the +-1104 columns the seam can reach within them.
+//   k_lin_seam_fill  every chunk in parallel again: from its entry column the 24 rows of the seam itself.
+// Every step evaluates the same function of (row, column) the sequential walk evaluates: the same seam, point for point (tests/test_gpu_blend.py
+// against the oracle's walk, incl. a 4K pair).  Round 4's form - one walker wave following step tables that four producer waves built two chunks
+// ahead - paid an LDS latency per row: 196 us of the 0.33 ms a 4K pair took (first version: 483 us).
+constexpr int SEAM_ROWS = 24;          // rows per chunk map (|exit - entry| <= 24 fits a signed byte with room)
+constexpr int SEAM_TILE = 256;         // start columns per block of k_lin_seam_maps
+constexpr int SEAM_HALO = 32;          // columns either side of them that a 24-row walk can reach (>= SEAM_ROWS + 1), a multiple of the loads' width
+constexpr int SEAM_GROUP = 46;         // chunk maps per LDS stage of k_lin_seam_entry (46 x 2212 bytes = 99 KB of the CU's 160 KB; a 4K pair's 91 chunks: two stages)
+constexpr int SEAM_REACH = SEAM_ROWS * SEAM_GROUP;      // columns the seam can move within one stage
+static_assert(SEAM_HALO >= SEAM_ROWS + 1 && SEAM_ROWS < 127, "a chunk's walk stays inside its tile + halo and its displacement inside a signed byte");
 
 __device__ __forceinline__ int seam_dir(float a, float b, float c) {     // B:283-300: left / stay / right from the three costs below
     // if (a == b && a == c) stay; else if (a <= b && a <= c) left; else if (b <= a && b <= c) stay; else if (c <= a && c <= b) right
@@ -67,81 +73,79 @@ __device__ __forceinline__ int seam_dir(float a, float b, float c) {     // B:28
     d = la ? -1 : d;
     return all ? 0 : d;
 }
+// one row of the walk at column px (tile coordinates: LDS column = px - x_lo): xl = max(px - 1, 0), xr = min(px + 1, cw - 1), the oracle's clamps
+__device__ __forceinline__ int seam_step(const float* row, int px, int x_lo, int cw) {
+    const int xl = max(px - 1, 0), xr = min(px + 1, cw - 1);
+    const int d = seam_dir(row[xl - x_lo], row[px - x_lo], row[xr - x_lo]);
+    return d < 0 ? xl : (d > 0 ? xr : px);
+}
 
-constexpr int SEAM_PRODUCERS = 4;                        // producer waves: each fetches and tabulates every 4th row of a chunk
-constexpr int SEAM_PR = SEAM_ROWS / SEAM_PRODUCERS;      // rows of a chunk per producer wave
-static_assert(SEAM_ROWS % SEAM_PRODUCERS == 0, "rows of a chunk are dealt evenly to the producer waves");
-
-__global__ __launch_bounds__(64 * (1 + SEAM_PRODUCERS)) void k_lin_seam(LinGeom g, const float* costV, int* seam) {
-    __shared__ signed char dir[2][SEAM_ROWS][SEAM_W];
-    // s_px[j & 1]: the column the walker reached at the end of chunk j.  Two slots: the walker goes straight on into chunk j + 1 and writes
-    // the other slot while slower waves may still be reading this one (a single slot was a formal race: ADVICE r2)
-    __shared__ int s_x0[2], s_px[2];
-    const int cw = g.iBr + 2, lane = threadIdx.x & 63, last = g.iHe - 1;     // rows 1 .. last are chosen by the walk
-    const bool producer = threadIdx.x >= 64;
-    const int pw = (int)(threadIdx.x >> 6) - 1;          // producer wave index (rows pw, pw + 4, ...)
-    int px = g.iBr / 2;
-    if (threadIdx.x == 0) seam[0] = px;
-    if (last < 1) return;
-    const int nchunks = (last + SEAM_ROWS - 1) / SEAM_ROWS;
-    float4 S0[SEAM_PR], S1[SEAM_PR];         // producer: its rows of two chunks in flight (even chunks in S0, odd ones in S1; registers)
-    int x0_0 = 0, x0_1 = 0;
-    auto fetch = [&](float4 (&S)[SEAM_PR], int& x0, int j, int centre) {   // chunk j = rows j * SEAM_ROWS + 1 ..., columns centre - 128 .. centre + 127
-        x0 = centre - SEAM_W / 2;
-        const int py = j * SEAM_ROWS;
-        const bool inside = x0 >= 0 && x0 + SEAM_W <= cw;                  // wave-uniform: no clamping needed
-#pragma unroll
-        for (int i = 0; i < SEAM_PR; ++i) {
-            const int r = pw + SEAM_PRODUCERS * i;
-            const float* q = costV + (size_t)min(py + 1 + r, last) * cw;
-            const int c = x0 + 4 * lane;
-            float4 v;
-            if (inside) { v.x = q[c]; v.y = q[c + 1]; v.z = q[c + 2]; v.w = q[c + 3]; }
-            else { v.x = q[min(max(c, 0), cw - 1)]; v.y = q[min(max(c + 1, 0), cw - 1)]; v.z = q[min(max(c + 2, 0), cw - 1)]; v.w = q[min(max(c + 3, 0), cw - 1)]; }
-            S[i] = v;
-        }
-    };
-    auto publish = [&](const float4 (&S)[SEAM_PR], int x0, int b) {       // the step table of a chunk into LDS buffer b
-#pragma unroll
-        for (int i = 0; i < SEAM_PR; ++i) {
-            const int r = pw + SEAM_PRODUCERS * i;
-            const float4 v = S[i];
-            const float left = __shfl_up(v.w, 1), right = __shfl_down(v.x, 1);     // the window's outermost columns are never reached
-            const int d0 = seam_dir(left, v.x, v.y), d1 = seam_dir(v.x, v.y, v.z), d2 = seam_dir(v.y, v.z, v.w), d3 = seam_dir(v.z, v.w, right);
-            *(unsigned*)&dir[b][r][4 * lane] = (unsigned)(d0 & 255) | ((unsigned)(d1 & 255) << 8) | ((unsigned)(d2 & 255) << 16) | ((unsigned)(d3 & 255) << 24);
-        }
-        if (lane == 0 && pw == 0) s_x0[b] = x0;
-    };
-    auto walk = [&](int j) {                    // wave 0, lane 0: follow the table of chunk j
-        const int b = j & 1, x0 = s_x0[b], py = j * SEAM_ROWS, nr = min(SEAM_ROWS, last - py);
-        for (int r = 0; r < nr; ++r) {
-            px = min(max(px + (int)dir[b][r][px - x0], 0), cw - 1);          // xl = max(px - 1, 0), xr = min(px + 1, cw - 1)
-            seam[py + 1 + r] = px;
-        }
-        s_px[b] = px;
-    };
-    if (producer) {
-        fetch(S0, x0_0, 0, px);
-        if (nchunks > 1) fetch(S1, x0_1, 1, px);
-        publish(S0, x0_0, 0);
-        if (nchunks > 2) fetch(S0, x0_0, 2, px);          // S0 is free again
-    }
+// grid (ceil(cw / SEAM_TILE), chunks): maps[chunk][x] = (column a walk entering the chunk at x leaves it at) - x
+__global__ __launch_bounds__(SEAM_TILE + 2 * SEAM_HALO) void k_lin_seam_maps(LinGeom g, const float* costV, signed char* maps) {
+    __shared__ float tile[SEAM_ROWS][SEAM_TILE + 2 * SEAM_HALO];
+    const int cw = g.iBr + 2, last = g.iHe - 1;
+    const int j = blockIdx.y, py = j * SEAM_ROWS, nr = min(SEAM_ROWS, last - py);
+    const int x_lo = (int)blockIdx.x * SEAM_TILE - SEAM_HALO, t = threadIdx.x, x = x_lo + t;
+    const int xc = min(max(x, 0), cw - 1);
+    for (int r = 0; r < nr; ++r) tile[r][t] = costV[(size_t)(py + 1 + r) * cw + xc];      // (a column outside the map is never stepped on: the clamps keep the walk inside)
     __syncthreads();
-    for (int j = 0; j < nchunks; j += 2) {
-        // even chunk j (LDS buffer 0) is walked while the table of chunk j + 1 (S1 -> buffer 1) is written
-        if (!producer) { if (lane == 0) walk(j); }
-        else if (j + 1 < nchunks) publish(S1, x0_1, 1);
+    if (t < SEAM_HALO || t >= SEAM_HALO + SEAM_TILE || x >= cw) return;
+    int px = x;
+    for (int r = 0; r < nr; ++r) px = seam_step(tile[r], px, x_lo, cw);
+    maps[(size_t)j * cw + x] = (signed char)(px - x);
+}
+
+// one block: entry[j] = the seam's column on entering chunk j (entry[0] = iBr / 2, B:269).  A stage = the maps of SEAM_GROUP chunks on the columns
+// the seam can reach within them, fetched as unaligned dwords, eight in flight per thread (fetched byte by byte, one after the other, the two
+// stages of a 4K pair took 105 us), then SEAM_GROUP dependent LDS bytes.
+typedef unsigned lin_u32_a1 __attribute__((aligned(1)));
+constexpr int SEAM_WROW = (2 * SEAM_REACH + 1 + 3) / 4;      // dwords of one staged map row
+__global__ __launch_bounds__(1024) void k_lin_seam_entry(LinGeom g, const signed char* maps, int nchunks, int* entry) {
+    __shared__ unsigned win[SEAM_GROUP][SEAM_WROW];
+    __shared__ int s_px;
+    const int cw = g.iBr + 2;
+    int px = g.iBr / 2;
+    for (int j0 = 0; j0 < nchunks; j0 += SEAM_GROUP) {
+        const int nj = min(SEAM_GROUP, nchunks - j0), w0 = max(px - SEAM_REACH, 0), w1 = min(px + SEAM_REACH, cw - 1);
+        const int nd = (w1 - w0 + 1 + 3) / 4, total = nj * nd;      // (a row's last dword may read up to 3 bytes of the next row: inside the buffer's padding)
+        for (int base = (int)threadIdx.x; base < total; base += 8 * 1024) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 1024;
+                v[u] = 0u;
+                if (idx < total) { const int i = idx / nd, k = idx - i * nd; v[u] = *(const lin_u32_a1*)(maps + (size_t)(j0 + i) * cw + w0 + 4 * k); }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 1024;
+                if (idx < total) { const int i = idx / nd, k = idx - i * nd; win[i][k] = v[u]; }
+            }
+        }
         __syncthreads();
-        px = s_px[0];
-        if (producer && j + 3 < nchunks) fetch(S1, x0_1, j + 3, px);
-        if (j + 1 >= nchunks) break;
-        // odd chunk j + 1 (buffer 1) is walked while the table of chunk j + 2 (S0 -> buffer 0) is written
-        if (!producer) { if (lane == 0) walk(j + 1); }
-        else if (j + 2 < nchunks) publish(S0, x0_0, 0);
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < nj; ++i) { entry[j0 + i] = px; px += (int)((const signed char*)win[i])[px - w0]; }
+            s_px = px;
+        }
         __syncthreads();
-        px = s_px[1];
-        if (producer && j + 4 < nchunks) fetch(S0, x0_0, j + 4, px);
+        px = s_px;
+        __syncthreads();
     }
+}
+
+// grid (chunks): seam[py + 1 + r], r < rows of the chunk, from the chunk's entry column
+__global__ __launch_bounds__(64) void k_lin_seam_fill(LinGeom g, const float* costV, const int* entry, int* seam) {
+    __shared__ float tile[SEAM_ROWS][64];
+    const int cw = g.iBr + 2, last = g.iHe - 1;
+    const int j = blockIdx.x, py = j * SEAM_ROWS, nr = min(SEAM_ROWS, last - py), lane = threadIdx.x;
+    const int e = entry[j], x_lo = e - 32;
+    const int xc = min(max(x_lo + lane, 0), cw - 1);
+    for (int r = 0; r < nr; ++r) tile[r][lane] = costV[(size_t)(py + 1 + r) * cw + xc];
+    __syncthreads();
+    if (lane != 0) return;
+    if (j == 0) seam[0] = e;
+    int px = e;
+    for (int r = 0; r < nr; ++r) { px = seam_step(tile[r], px, x_lo, cw); seam[py + 1 + r] = px; }
 }
 
 __device__ __forceinline__ float gray_at(const float* p, int x) {
@@ -296,20 +300,33 @@ int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2, int tl
     LinScratch& ls = lin_scratch();
     if (ls.device != device) { ls.buf.release(); ls.device = device; }
     DevBuf& scratch = ls.buf;
+    const int nchunks = std::max(cdiv(g.iHe - 1, SEAM_ROWS), 1);
+    const int half_ibr = g.iBr / 2;
     size_t cost_b = ((size_t)g.iHe * cw * 4 + 255) & ~(size_t)255, seam_b = ((size_t)g.iHe * 4 + 255) & ~(size_t)255,
-           m_b = ((size_t)g.height * mw * 4 + 255) & ~(size_t)255;
-    ISX_TRY(scratch.reserve(cost_b + seam_b + 2 * m_b));
+           m_b = ((size_t)g.height * mw * 4 + 255) & ~(size_t)255, maps_b = (((size_t)nchunks * cw + 255) & ~(size_t)255) + 256, entry_b = ((size_t)nchunks * 4 + 255) & ~(size_t)255;
+    ISX_TRY(scratch.reserve(cost_b + seam_b + 2 * m_b + maps_b + entry_b));
     float* costV = (float*)scratch.p;
     int* seam = (int*)((char*)scratch.p + cost_b);
     float* m1 = (float*)((char*)scratch.p + cost_b + seam_b);
     float* m2 = (float*)((char*)m1 + m_b);
+    signed char* maps = (signed char*)((char*)m2 + m_b);
+    int* entry = (int*)((char*)maps + maps_b);
     const unsigned char* i1 = (const unsigned char*)s1.d.data;
     const unsigned char* i2 = (const unsigned char*)s2.d.data;
-    ISX_LAUNCH("lin_cost", 0.0, st, k_lin_cost, dim3(cdiv(cw, 256), g.iHe), dim3(256), 0, g, i1, i2, costV);
-    ISX_LAUNCH("lin_seam", 0.0, st, k_lin_seam, dim3(1), dim3(64 * (1 + SEAM_PRODUCERS)), 0, g, costV, seam);
-    ISX_LAUNCH("lin_classify", 0.0, st, k_lin_classify, dim3(cdiv(mw, 256), g.height), dim3(256), 0, g, i1, i2, m1, m2);
-    ISX_LAUNCH("lin_rows", 0.0, st, k_lin_rows, dim3(g.height), dim3(64), 0, g, seam, m1, m2);
-    ISX_LAUNCH("lin_compose", 0.0, st, k_lin_compose, dim3(cdiv(g.panoBr, 256), g.panoHe), dim3(256), 0, g, i1, i2, m1, m2, (unsigned char*)sp.d.data);
+    // algorithmic bytes of the launches (bench.py --a13): every input read once, every output written once
+    const double cells = (double)g.iHe * cw, ocells = (double)g.height * mw, ppx = (double)g.panoHe * g.panoBr;
+    const double left_px = (double)g.rows1 * g.dx2, right_px = (double)g.rows2 * std::max(g.panoBr - g.cols1, 0), ov_px = (double)g.height * g.width;
+    ISX_LAUNCH("lin_cost", cells * 28.0, st, k_lin_cost, dim3(cdiv(cw, 256), g.iHe), dim3(256), 0, g, i1, i2, costV);
+    if (g.iHe < 2) ISX_HIP(hipMemcpyAsync(seam, &half_ibr, sizeof(int), hipMemcpyHostToDevice, st));      // a one-row overlap: seam[0] alone (B:269)
+    else {
+        ISX_LAUNCH("lin_seam_maps", cells * 5.0, st, k_lin_seam_maps, dim3(cdiv(cw, SEAM_TILE), nchunks), dim3(SEAM_TILE + 2 * SEAM_HALO), 0, g, (const float*)costV, maps);
+        ISX_LAUNCH("lin_seam_entry", 0.0, st, k_lin_seam_entry, dim3(1), dim3(1024), 0, g, (const signed char*)maps, nchunks, entry);
+        ISX_LAUNCH("lin_seam_fill", 0.0, st, k_lin_seam_fill, dim3(nchunks), dim3(64), 0, g, (const float*)costV, (const int*)entry, seam);
+    }
+    ISX_LAUNCH("lin_classify", ocells * 32.0, st, k_lin_classify, dim3(cdiv(mw, 256), g.height), dim3(256), 0, g, i1, i2, m1, m2);
+    ISX_LAUNCH("lin_rows", ocells * 16.0, st, k_lin_rows, dim3(g.height), dim3(64), 0, g, seam, m1, m2);
+    ISX_LAUNCH("lin_compose", ppx * 12.0 + (left_px + right_px) * 12.0 + ov_px * 32.0, st, k_lin_compose, dim3(cdiv(g.panoBr, 256), g.panoHe), dim3(256), 0, g, i1, i2, m1, m2,
+               (unsigned char*)sp.d.data);
     if (seam_x) ISX_HIP(hipMemcpyAsync(seam_x, seam, (size_t)g.iHe * 4, hipMemcpyDeviceToHost, st));
     ISX_TRY(sp.finish_out(st));
     ISX_HIP(hipStreamSynchronize(st));   // the seam and a host pano are complete when the call returns (cv::Mat semantics)
