@@ -351,7 +351,9 @@ int isx_dp_seam_find(int num_images, const isx_mat* images, const int* corners_x
                      void* hip_stream);
 /* isx_dp_seam_find / isx_seam_estimate keep their work images (about 6-10 B per union pixel on the host, the staged images,
  * cost maps and DP records on the device) per calling thread between calls; this returns all of it (the analogue of the
- * DpSeamFinder going out of scope, S:1188-1192).                                                                   */
+ * DpSeamFinder going out of scope, S:1188-1192).  PER THREAD: the state is thread-local and is NOT freed when a thread ends (the
+ * HIP runtime may already be gone then) - a thread-pool caller calls this on every worker thread before that thread exits, or
+ * leaks one finder (tens of MB at 4K) per thread.                                                                    */
 int isx_dp_seam_release(void);
 
 /* ---- on-disk format either side of the path: .bmp (W:166 imread, W:155-156,315 imwrite) ----------- */
@@ -384,8 +386,9 @@ int isx_blend_pair_linear_size(int rows1, int cols1, int rows2, int cols2,
 int isx_blend_pair_linear(const isx_mat* images1, const isx_mat* images2,
                           int tl1_x, int tl1_y, int tl2_x, int tl2_y,
                           isx_mat* pano, int* seam_x, int device, void* hip_stream);
-/* isx_blend_pair_linear keeps its work buffers (cost map, seam, weight maps: 38 MB for a 4K pair) per calling thread between
- * calls; this returns them. */
+/* isx_blend_pair_linear keeps its work buffers (cost map, chunk maps, seam, weight maps: 41 MB for a 4K pair) per calling thread
+ * between calls; this returns them.  PER THREAD, and not freed at thread exit: call it on every worker thread that made the call
+ * before that thread ends (see isx_dp_seam_release). */
 int isx_blend_pair_linear_release(void);
 
 /* ---- assembling a batch of mosaics across the GPUs of a node (no counterpart in the reference; BASELINE config 4) ---------------- */
