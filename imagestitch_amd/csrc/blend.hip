@@ -1707,23 +1707,37 @@ double covered_px(const isx_blender* b, int x, int y, int w, int h) {
     return area;
 }
 
-// k_feed_pd0 for (precision, tile type, level-1 layout, copy format)
+// k_feed_pd0 / k_feed_strip for (precision, tile type, level-1 layout, copy format)
+template <int M, int SK, bool PLD, int CF>
+int launch_feed_pd0_v(const Src0& s0, const LevelBuf& g1, FeedCopy fc, dim3 grid, double bytes, hipStream_t st) {
+    // single-wave strips for the whole level (k_feed_strip) unless the tile is too small for its window scheme; ISX_FEED_STRIP=0: the block kernel
+    // (A/B runs), 4: four output rows per strip instead of two
+    static const int strip_no = [] { const char* e = getenv("ISX_FEED_STRIP"); return e ? atoi(e) : 2; }();
+    if (strip_no && s0.iend != 0u && s0.cols >= 2 && s0.rows >= 2 && s0.width >= 4 && s0.height >= 4) {
+        const int no = strip_no == 4 ? 4 : 2;
+        const unsigned n = (unsigned)cdiv(g1.cols, PD_OW) * (unsigned)cdiv(g1.rows, no);
+        const unsigned nblk = (n + 7u) / 8u * 8u;         // (the XCD dealing walks whole groups of 8)
+        if (no == 4) ISX_LAUNCH("feed_strip", bytes, st, (k_feed_strip<M, SK, PLD, CF, 4>), dim3(nblk), dim3(64), 0, s0, g1, fc);
+        else ISX_LAUNCH("feed_strip", bytes, st, (k_feed_strip<M, SK, PLD, CF, 2>), dim3(nblk), dim3(64), 0, s0, g1, fc);
+        return ISX_OK;
+    }
+    ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, PLD, CF>), grid, dim3(512), 0, s0, g1, fc);
+    return ISX_OK;
+}
 template <int M, int SK>
 int launch_feed_pd0_t(bool planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
     if constexpr (SK == SK_S16) {
         if (narrow) {
             if constexpr (M == M_F32 || M == M_I16) {
-                if (planar) { ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, true, CF_NARROW>), grid, dim3(512), 0, s0, g1, fc); return ISX_OK; }
+                if (planar) return launch_feed_pd0_v<M, SK, true, CF_NARROW>(s0, g1, fc, grid, bytes, st);
             }
-            ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, false, CF_NARROW>), grid, dim3(512), 0, s0, g1, fc);
-            return ISX_OK;
+            return launch_feed_pd0_v<M, SK, false, CF_NARROW>(s0, g1, fc, grid, bytes, st);
         }
     }
     if constexpr (M == M_F32 || M == M_I16) {
-        if (planar) { ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, true, CF_SAME>), grid, dim3(512), 0, s0, g1, fc); return ISX_OK; }
+        if (planar) return launch_feed_pd0_v<M, SK, true, CF_SAME>(s0, g1, fc, grid, bytes, st);
     }
-    ISX_LAUNCH("feed_pd0", bytes, st, (k_feed_pd0<M, SK, false, CF_SAME>), grid, dim3(512), 0, s0, g1, fc);
-    return ISX_OK;
+    return launch_feed_pd0_v<M, SK, false, CF_SAME>(s0, g1, fc, grid, bytes, st);
 }
 int launch_feed_pd0(int prec, int sk, bool planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
     switch (prec) {

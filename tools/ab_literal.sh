@@ -14,7 +14,7 @@ for l in sys.stdin:
     p=l.split()
     if l.startswith('ms/pair'): ms=p[1]
     elif 'launches/step' in l: k[p[0]]=float(p[4])*1e3
-print(ms, ' '.join('%s %.1f' % (n, k[n]) for n in ('feed_pd0','collapse_roll','pyr_down','collapse_gather') if n in k))")
+print(ms, ' '.join('%s %.1f' % (n, k[n]) for n in ('feed_strip','feed_pd0','collapse_roll','pyr_down','collapse_gather') if n in k))")
       echo "[$v] $m $o"
     done
   done
