@@ -587,14 +587,93 @@ def case_many_tiles(rng):
     assert np.array_equal(d, od), (n, bands, prec, mode, win, mb.last_path(), np.argwhere(d != od)[:3])
 
 
+def case_fused_feed(rng):
+    """Round 5: feed() of mode 2 as ONE pass (k_feed_strip / k_feed_pd0: level 1 + the private copy out of one read of the caller's tile) with the
+    copy of a CV_16SC3 tile narrowed to CV_8UC3 while its values are bytes.  Two to four CYCLES of one blender whose tiles are all bytes, bytes but
+    for one value somewhere (an escaped segment: the cycle is widened before the last step), or full-range shorts (the blender keeps wide copies
+    from the first violation on), CV_16SC3 or CV_8UC3 tiles, random sizes and offsets (rim strips everywhere), 1-6 bands, every precision, the
+    caller's mats poisoned after feed(), now and then a column window or level introspection between feed and blend."""
+    import torch
+    n = int(rng.integers(1, 5))
+    big = bool(rng.integers(0, 3))
+    sizes = [(int(rng.integers(2, 700 if big else 90)), int(rng.integers(2, 400 if big else 80))) for _ in range(n)]
+    spread = 420 if big else 60
+    corners = [(int(rng.integers(-spread, spread)), int(rng.integers(-50, 70))) for _ in range(n)]
+    bands, prec = int(rng.integers(1, 7)), int(rng.integers(0, 3))
+    u8 = rng.integers(0, 4) == 0
+    mb = G.MultiBandBlender(False, bands, prec)
+    mb.set_deferred_level0("copy")
+    violated = False
+    for cycle in range(int(rng.integers(2, 5))):
+        kind = "bytes" if u8 else ["bytes", "bytes", "one", "full"][int(rng.integers(0, 4))]
+        ob = O.MultiBand(bands, prec)
+        mb.prepare(corners, sizes)
+        ob.prepare(corners, sizes)
+        fw, _ = mb.result_size()
+        win = None
+        if fw >= 256 and rng.integers(0, 4) == 0:
+            x0 = int(rng.integers(0, fw // 128)) * 128
+            x1 = min(x0 + int(rng.integers(1, 4)) * 128, fw + 64)
+            win = (x0, x1)
+        any_bad = False
+        for (w, h), c in zip(sizes, corners):
+            if kind == "full":
+                img = rng.integers(-32768, 32768, (h, w, 3)).astype(np.int16)
+            else:
+                img = rng.integers(0, 256, (h, w, 3)).astype(np.int16)
+                if kind == "one" and rng.integers(0, 2):
+                    img[int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, 3))] = [256, -1, 32767, -32768, 300][int(rng.integers(0, 5))]
+            any_bad = any_bad or bool(((img < 0) | (img > 255)).any())
+            mask = rng.integers(0, 256, (h, w)).astype(np.uint8)
+            mask[rng.random((h, w)) < rng.uniform(0, 0.7)] = 0
+            mask[rng.random((h, w)) < rng.uniform(0, 0.7)] = 255
+            ob.feed(img, mask, c)
+            if u8:
+                ti = torch.from_numpy(img.astype(np.uint8)).cuda()
+            else:       # a device view at an odd alignment (a 2-byte aligned row start is all the windows may assume)
+                pad, off = int(rng.integers(0, 9)), int(rng.integers(0, 4))
+                pitch = w * 3 + pad
+                buf = torch.zeros((h * pitch + off + 8,), dtype=torch.int16, device="cuda")
+                ti = buf[off:].as_strided((h, w, 3), (pitch, 3, 1))
+                ti.copy_(torch.from_numpy(img).cuda())
+            tm = torch.from_numpy(mask).cuda()
+            (mb.feed_u8 if u8 else mb.feed)(ti, tm, c)
+            ti.fill_(77 if u8 else -7), tm.fill_(99)
+        if win is None and bands <= 4 and rng.integers(0, 6) == 0:
+            lvl = int(rng.integers(0, mb.numBands() + 1))
+            gl, gw = mb.level(lvl)
+            ol, ow = ob.level(lvl)
+            assert np.array_equal(gl, ol) and np.array_equal(gw, ow), ("level", lvl)
+        if win:
+            mb.set_window(*win)
+        f32 = prec != 0 and bool(rng.integers(0, 2))
+        d, m = mb.blend(out_f32=f32)
+        if win:
+            mb.set_window(0, 0)
+        d, m = d.cpu().numpy(), m.cpu().numpy()
+        od, om = ob.blend(f32)
+        if win:
+            od, om = od[:, win[0]:win[1]], om[:, win[0]:win[1]]
+            d, m = d[:, :od.shape[1]], m[:, :om.shape[1]]
+        path = mb.feed_path()
+        assert np.array_equal(m, om), (cycle, kind)
+        assert np.array_equal(d, od), (cycle, kind, n, bands, prec, path, np.argwhere(d != od)[:3])
+        if not u8 and path["fused_tiles"] == n:
+            want = "none" if violated else ("widened" if any_bad else "confirmed")
+            assert path["narrowed"] == want, (path, want, cycle, kind)
+            violated = violated or any_bad
+
+
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls, case_many_tiles]
+         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls, case_many_tiles, case_fused_feed]
 
 
 def run(budget, seed0, verbose=True):
     """Round-robin over the case families for `budget` seconds; case n uses seed seed0 * 1000003 + n.  Returns the summary dict."""
     G.load()
     t0, n, bad, skipped = time.time(), 0, 0, 0
+    only = os.environ.get("ISX_FUZZ_ONLY", "")       # a comma-separated subset of the families (a soak of what a round changed)
+    CASES = [f for f in globals()["CASES"] if not only or f.__name__ in only.split(",")]
     counts = {f.__name__: 0 for f in CASES}
     fails = {f.__name__: 0 for f in CASES}
     failing_seeds = []
