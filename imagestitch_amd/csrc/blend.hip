@@ -907,8 +907,22 @@ struct TileSet {                 // per-tile views of one pyramid level pair, in
 static_assert(sizeof(TileSet) + 2 * sizeof(LevelBuf) + sizeof(OutMat) <= 4096, "k_collapse_gather's arguments exceed the kernel-argument limit");
 
 // PLS: the source level is PLANAR (level 1 of the deferred cycle, see load_px_planar)
+// FeedPub: blend() of a cycle with narrowed tiles (pyrdown_l0.inc) hands their violation words to the host with the FIRST launch of its chain - this
+// one, when level 1 came from feed() - instead of a launch of its own (k_feed_publish: 4 us of a 0.32 ms step); pin == nullptr: nothing to publish
+struct FeedPub { unsigned* state; int n; int* pin; int seq; };
+__device__ __forceinline__ void feed_publish_words(const FeedPub& fp) {
+    unsigned v = 0u;
+    for (int i = 0; i < fp.n; ++i) {
+        v |= __hip_atomic_load(&fp.state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fp.state[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(&fp.pin[1], v ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&fp.pin[0], fp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int M, int SK, bool PLS = false>
-__global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts) {
+__global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts, FeedPub fp) {
+    if (fp.pin != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feed_publish_words(fp);
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
@@ -1285,7 +1299,7 @@ int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st,
         }
         if (fast) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK>), grid, dim3(512), 0, ts); return ISX_OK; }
     }
-    ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts);
+    ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi<M, SK>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
     return ISX_OK;
 }
 
@@ -2103,7 +2117,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     bool g1_done = true;
     for (int t = 0; t < n; ++t) g1_done = g1_done && b->tiles[t].g1 == (g1_planar ? 2 : 1);
     if (b->narrow_pending) {
-        ISX_TRY(narrow_publish(b));
+        if (!(g1_done && L >= 2 && !all_on_side)) ISX_TRY(narrow_publish(b));      // (otherwise the level 1 -> 2 pyrDown below carries the words)
         if (!g1_done) {
             bool widened = false;
             ISX_TRY(narrow_resolve(b, &widened));
@@ -2135,9 +2149,16 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
         if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar)));
-        else if (k == 1 && g1_planar) {
-            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts);
-        } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+        else {
+            FeedPub fp{nullptr, 0, nullptr, 0};
+            if (b->narrow_pending && !b->narrow_published) {      // the violation words ride on this launch (the first of the chain: level 1 came from feed())
+                fp = FeedPub{(unsigned*)b->feed_state.p, n, b->feed_pin, ++b->feed_seq};
+                b->narrow_published = true;
+            }
+            if (k == 1 && g1_planar) {
+                if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts, fp);
+            } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts, fp);
+        }
         // the full-size level-0 kernel is behind us: from here to the last collapse step the launches are small
         if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
     }
@@ -2478,8 +2499,8 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), nt);
         if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar)));
         else if (k == 1 && g1_planar) {
-            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts);
-        } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts);
+            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
+        } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
         for (int m = 0; m < nb; ++m)
             if (k == bs[m]->mark_level && bs[m]->mark_event) ISX_HIP(hipEventRecord(bs[m]->mark_event, st));
     }
