@@ -2,13 +2,13 @@
 # Collects the measurement evidence of a round on the GPU box (run via gpurun from the repo root):
 #   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh round2 [fuzz_seconds]'
 # Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
-TAG=${1:-round4}; FUZZ=${2:-600}
+TAG=${1:-round5}; FUZZ=${2:-600}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 line() { grep "^{" | tail -1; }
 # 1. HBM traffic per kernel (two PMC passes of their own), then the default line that reads it
 python tools/measure_traffic.py $O/${TAG}_traffic.json > $O/traffic.log 2>&1
-cp $O/${TAG}_traffic.json profiles/round4_traffic.json 2>/dev/null
+cp $O/${TAG}_traffic.json profiles/round5_traffic.json 2>/dev/null      # (bench.py's fallback when rocprofv3 is not usable in a run)
 python bench.py --steps 20 --warmup 5 2>/dev/null | line > $O/${TAG}_bench_n1.json
 # 2. the same command under the kernel tracer
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -56,6 +56,12 @@ python tools/probes/roi_latency_probe.py > $O/${TAG}_roi_latency.txt 2>&1; ISX_R
 python tools/probes/literal_host_probe.py 1 > $O/${TAG}_literal_host_time.txt 2>&1
 for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== pipeline_probe $m" >> $O/${TAG}_literal_kernels.txt; python tools/pipeline_probe.py $m 2>&1 | tail -14 >> $O/${TAG}_literal_kernels.txt; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/chain_probe.hip -o /tmp/chain_probe 2>/dev/null && timeout 60 /tmp/chain_probe > $O/${TAG}_chain_by_flags.txt 2>&1
+# round 5: A13 (the in-tree linear-ramp pair blend) on the record; the drop-in legs with the fused feed switched off / without narrowing; many tiles
+python bench.py --a13 --steps 50 2>/dev/null | line > $O/${TAG}_bench_a13.json
+for v in "ISX_FEED_FUSE=0" "ISX_FEED_NARROW=0" "ISX_FEED_STRIP=0" "ISX_FEED_FUSE=1"; do for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== [$v] pipeline_probe $m" >> $O/${TAG}_feed_variants.txt; env $v python tools/pipeline_probe.py $m 2>&1 | tail -14 >> $O/${TAG}_feed_variants.txt; done; done
+b many_tiles_24 --tiles 24 --focal 9000 --yaw 0.12 --steps 6 --warmup 2
+b many_tiles_64 --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2
+ISX_VERIFY_NEVER=1 python bench.py --no-cpu-baseline --no-dropin --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_64_ISX_VERIFY_NEVER.json
 # 4b. config 5 as ONE panorama in column strips: every rank's share at 2 / 4 / 8 ranks, each alone on this GPU (no gather)
 C5="--kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3"
 mkdir -p $O/strips
