@@ -107,6 +107,42 @@ for x0, x1 in wins:
         torch.cuda.synchronize()
         bad += not torch.equal(out[:, :min(x1, fw) - x0], full[:, x0:min(x1, fw)])
 res["strips_of_a_six_tile_panorama"] = {"differing_steps": int(bad)}
+del whole
+# round 5: the reference's call sequence on device mats (mode 2: the fused feed, CV_16SC3 tiles narrowed to CV_8UC3 copies, the violation word read
+# by the host inside blend()) and the fused leg (feed_u8 in mode 2), both arithmetics - every step against the first
+for prec, name in ((_lib.PREC_F32, "f32"), (_lib.PREC_I16, "i16")):
+    p = PairStitcher(tiles(90), K, Rs, F, "cylindrical", 5, prec, 0, None, "int16", deferred="copy")
+    for leg, fn in (("literal", p.step_literal), ("fused", p.step_sync)):
+        ref = [t.clone() for t in fn()]
+        bad = 0
+        for _ in range(N // 2):
+            out, m = fn()
+            torch.cuda.synchronize()
+            bad += not (torch.equal(out, ref[0]) and torch.equal(m, ref[1]))
+        res["dropin_%s_%s" % (leg, name)] = {"differing_steps": int(bad), "feed_path": p.blender.feed_path()}
+    del p
+# ... and A13 (the seam walk as chunk maps): seam and panorama of every call against the first
+import ctypes as C  # noqa: E402
+import numpy as np  # noqa: E402
+import imagestitch_amd  # noqa: E402
+lib = imagestitch_amd.load()
+p = PairStitcher(tiles(91), K, Rs, F, "cylindrical", 5, _lib.PREC_F32, 0, None, "int16")
+p.step_sync()
+t1, t2 = (w.to(torch.float32).contiguous() for w in p.warped)
+(x1, y1), (x2, y2) = p.corners
+pr, pc = C.c_int(), C.c_int()
+_lib.check(lib.isx_blend_pair_linear_size(t1.shape[0], t1.shape[1], t2.shape[0], t2.shape[1], x1, y1, x2, y2, C.byref(pr), C.byref(pc)))
+pano = torch.empty((pr.value, pc.value, 3), dtype=torch.float32, device=dev)
+seam = np.zeros(pr.value, np.int32)
+m1, m2, mp = _lib.as_mat(t1), _lib.as_mat(t2), _lib.as_mat(pano)
+ref_p, ref_s, bad = None, None, 0
+for i in range(N // 2):
+    _lib.check(lib.isx_blend_pair_linear(C.byref(m1), C.byref(m2), x1, y1, x2, y2, C.byref(mp), seam.ctypes.data_as(_lib._IP), 0, None))
+    if ref_p is None:
+        ref_p, ref_s = pano.clone(), seam.copy()
+    else:
+        bad += not (torch.equal(pano, ref_p) and np.array_equal(seam, ref_s))
+res["a13_linear_pair"] = {"differing_calls": int(bad)}
 res["seconds"] = round(time.time() - t0, 1)
 print(json.dumps(res))
 if len(sys.argv) > 2:
