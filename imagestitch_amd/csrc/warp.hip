@@ -1213,10 +1213,12 @@ struct isx_warper {
     bool defer_verify = false;
     MatStage st_src, st_mask, st_dst, st_dmask, st_x, st_y;
     // cache of mapBackward tables, one entry per (kind, scale, roi): a rig's tiles alternate between a few ROIs
-    struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; };
+    // (round 5: 1024 entries, each with its own host copy.  With 16 entries and one shared host buffer a panorama of more than 16 tiles through
+    // one handle missed on EVERY warp - two stream synchronisations and 7 000 sinf / cosf per call: the 64-tile step was host-bound at 68 us per
+    // 27 us warp kernel, 9.8 ms against a kernel sum of 7.3, profiles/round5_many_tiles_trace.txt)
+    struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; std::vector<float> host; };
     std::vector<TabEntry> tab_cache;
     unsigned long long tab_clock = 0;
-    std::vector<float> host_tabs;
     std::vector<int> host_cand;
     float k[9], rinv[9];
     Proj proj;
@@ -1228,7 +1230,7 @@ struct isx_warper {
     std::vector<RoiEntry> roi_cache;
     bool roi_cache_on = false;
     // The spherical ROI is a scan of the source's border on the HOST (0.3 ms for an 8K tile): a pure function with no device work and
-    // no synchronisation to preserve, so its results are always remembered (per projection and source size, 32 entries).
+    // no synchronisation to preserve, so its results are always remembered (per projection and source size, 1024 entries).
     std::vector<RoiEntry> sph_memo;
 };
 
@@ -1457,7 +1459,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         if (south) { tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, 0.f); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, 0.f); }
         if (mm) { mm[0] = tl_u; mm[1] = tl_v; mm[2] = br_u; mm[3] = br_v; }
         roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
-        if (w->sph_memo.size() >= 32) w->sph_memo.erase(w->sph_memo.begin());
+        if (w->sph_memo.size() >= 1024) w->sph_memo.erase(w->sph_memo.begin());
         isx_warper::RoiEntry e;
         e.proj = w->proj; e.sw = sw; e.sh = sh;
         std::copy(w->k, w->k + 9, e.k); std::copy(w->rinv, w->rinv + 9, e.rinv);
@@ -1532,7 +1534,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     if (mm) { mm[0] = tl_uf; mm[1] = tl_vf; mm[2] = br_uf; mm[3] = br_vf; }
     roi[0] = f2i_host(tl_uf); roi[1] = f2i_host(tl_vf); roi[2] = f2i_host(br_uf); roi[3] = f2i_host(br_vf);   // W:83-86
     {
-        const size_t cap = w->roi_cache_on ? 16 : 1;
+        const size_t cap = w->roi_cache_on ? 1024 : 1;
         while (w->roi_cache.size() >= cap) w->roi_cache.erase(w->roi_cache.begin());
         isx_warper::RoiEntry e;
         memset(&e, 0, sizeof(e));
@@ -1549,7 +1551,7 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
     int mw = roi[2] - roi[0] + 1, mh = roi[3] - roi[1] + 1;
     const int mwp = (mw + 3) & ~3, mhp = (mh + 3) & ~3;   // segments padded to 16 bytes: the fused kernel loads float4
     size_t n = (size_t)2 * mwp + 2 * mhp;
-    constexpr size_t TAB_SLOTS = 16;
+    constexpr size_t TAB_SLOTS = 1024;      // (~45 KB each for a 4K tile)
     isx_warper::TabEntry* e = nullptr;
     for (auto& c : w->tab_cache)
         if (c.kind == w->kind && c.scale == w->scale && std::equal(roi, roi + 4, c.roi)) { e = &c; break; }
@@ -1558,13 +1560,13 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
             w->tab_cache.emplace_back();
             e = &w->tab_cache.back();
             e->buf.reset(new DevBuf());
-        } else {   // evict the least recently used entry (its buffer may still be read by enqueued kernels: drain first)
+        } else {   // evict the least recently used entry (its buffers may still be read by enqueued kernels / its upload: drain first)
             e = &w->tab_cache[0];
             for (auto& c : w->tab_cache) if (c.stamp < e->stamp) e = &c;
             ISX_HIP(hipStreamSynchronize(w->stream));
         }
-        w->host_tabs.assign(n, 0.f);
-        float* cs = w->host_tabs.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
+        e->host.assign(n, 0.f);
+        float* cs = e->host.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
         for (int i = 0; i < mw; ++i) {
             float u = (float)(roi[0] + i);
             u /= w->scale;                                 // W:48
@@ -1581,8 +1583,11 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
         for (int i = mw; i < mwp; ++i) { cs[i] = cs[mw - 1]; cc[i] = cc[mw - 1]; }
         for (int i = mh; i < mhp; ++i) { ra[i] = ra[mh - 1]; rb[i] = rb[mh - 1]; }
         ISX_TRY(e->buf->reserve(n * sizeof(float)));
-        ISX_HIP(hipMemcpyAsync(e->buf->p, w->host_tabs.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
-        ISX_HIP(hipStreamSynchronize(w->stream));   // host_tabs is rewritten by the next miss
+        ISX_HIP(hipMemcpyAsync(e->buf->p, e->host.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
+        // A miss is a planning-time event (1024 entries): the upload is simply waited for.  (Tried without the wait in round 5, the entry keeping its
+        // host copy alive: the world-8 rehearsal of bench.py then delivered a wrong mosaic in 4 runs of 7 - on this runtime an asynchronous copy
+        // from PAGEABLE memory is not something a kernel launched right behind it on the same stream can rely on; 8 of 8 runs pass with the wait.)
+        ISX_HIP(hipStreamSynchronize(w->stream));
         e->kind = w->kind; e->scale = w->scale; std::copy(roi, roi + 4, e->roi);
     }
     e->stamp = ++w->tab_clock;
