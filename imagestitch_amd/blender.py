@@ -118,11 +118,17 @@ class MultiBandBlender:
         return w.value, h.value
 
     def last_path(self):
-        """isx_blender_last_path: which kernels the last blend() ran - {"cycle": eager | deferred | deferred_batched | deferred_strips, "last_step": none |
+        """isx_blender_last_path: which kernels the last blend() ran - {"cycle": eager | deferred | deferred_batched | deferred_strips | deferred_table, "last_step": none |
         collapse | collapse_gather | collapse_roll}."""
         c, k = C.c_int(), C.c_int()
         check(self._lib.isx_blender_last_path(self._h, C.byref(c), C.byref(k)))
-        return {"cycle": ("eager", "deferred", "deferred_batched", "deferred_strips")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
+        return {"cycle": ("eager", "deferred", "deferred_batched", "deferred_strips", "deferred_table")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
+
+    def table_uploads(self):
+        """isx_blender_table_uploads: 3.5 KB pieces of tile tables uploaded so far (cycle deferred_table; a fixed rig uploads once)."""
+        n = C.c_longlong()
+        check(self._lib.isx_blender_table_uploads(self._h, C.byref(n)))
+        return n.value
 
     def feed_path(self):
         """isx_blender_feed_path: how the last blend()'s tiles were fed in mode 2 - {"fused_tiles": n, "narrowed": none | confirmed | widened}."""

@@ -906,6 +906,62 @@ struct TileSet {                 // per-tile views of one pyramid level pair, in
 
 static_assert(sizeof(TileSet) + 2 * sizeof(LevelBuf) + sizeof(OutMat) <= 4096, "k_collapse_gather's arguments exceed the kernel-argument limit");
 
+// ---- more than DEF_MAX tiles in one chain (round 5): the same per-tile views as a TABLE IN DEVICE MEMORY -------------------------------
+// A cycle of more than 20 tiles used to be cut into column strips of at most 20 (run_blend_deferred_strips), and tiles stacked more than 20 deep
+// over one strip fell back to the eager destination pyramid.  TileTab is TileSet with its arrays behind a pointer: one 160-byte TileDesc per
+// tile, written by the host once per launch and geometry (DevTable: only what changed since the previous blend is uploaded - nothing in the
+// steady state of a fixed rig), read by the kernels with SCALAR loads exactly as the kernel-argument segment is (a uniform index into constant
+// address space: s_load_dword*).  The kernel bodies are templates over the view type and index it with the same expressions (ts.x_tl[t],
+// ts.coarse[t].cols ...), so both forms run the same code on the same values: identical bits.
+// A wave of a collapse step must not look at every tile of a long panorama to find the two or three that reach it: the table carries, per
+// 2^gshift columns of the step's fine level, the index range [first, last) of the tiles whose rectangles meet those columns (feed order is
+// kept inside the range; tiles of the range that do not reach the wave are skipped by the same tests as before).
+struct TileDesc { Src0 s0; LevelBuf fine, coarse; int x_tl, y_tl, w, h, bx_lo, bx_hi; };
+static_assert(sizeof(TileDesc) % 16 == 0, "TileDesc records are copied and loaded in 16-byte pieces");
+#define ISX_AS4 __attribute__((address_space(4)))
+// a field of a record in constant address space, dword by dword (what is not used is never loaded; neighbours merge into s_load_dwordx2/4/8)
+template <class T>
+__device__ __forceinline__ T ld_const(const void* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    T v;
+    const ISX_AS4 unsigned* s = (const ISX_AS4 unsigned*)p;
+    unsigned* o = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = s[i];
+    return v;
+}
+template <class T, size_t OFF>
+struct TabField {        // ts.field[t] of a TileTab, by value
+    const char* base;
+    __device__ __forceinline__ T operator[](int t) const { return ld_const<T>(base + (size_t)(unsigned)t * sizeof(TileDesc) + OFF); }
+};
+struct TileTab {
+    int n, gshift, nrng, pad_;
+    const int2* rng;         // per 2^gshift fine-level columns: [first, last) tile indices
+    TabField<Src0, offsetof(TileDesc, s0)> s0;
+    TabField<LevelBuf, offsetof(TileDesc, fine)> fine;
+    TabField<LevelBuf, offsetof(TileDesc, coarse)> coarse;
+    TabField<int, offsetof(TileDesc, x_tl)> x_tl;
+    TabField<int, offsetof(TileDesc, y_tl)> y_tl;
+    TabField<int, offsetof(TileDesc, w)> w;
+    TabField<int, offsetof(TileDesc, h)> h;
+    TabField<int, offsetof(TileDesc, bx_lo)> bx_lo;
+    TabField<int, offsetof(TileDesc, bx_hi)> bx_hi;
+};
+// the tiles a block / wave that covers the fine-level columns [x0, x1) has to look at: [tb, te) narrowed (TileSet: all of them, as always)
+__device__ __forceinline__ void tile_range(const TileSet&, int, int, int&, int&) {}
+__device__ __forceinline__ void tile_range(const TileTab& ts, int x0, int x1, int& tb, int& te) {
+    if (ts.nrng <= 0) return;
+    const int b0 = min(max(x0, 0) >> ts.gshift, ts.nrng - 1), b1 = min(max(x1 - 1, 0) >> ts.gshift, ts.nrng - 1);
+    int lo = 1 << 30, hi = 0;
+    for (int b = b0; b <= b1; ++b) {
+        const int2 r = ld_const<int2>(ts.rng + b);
+        lo = min(lo, r.x); hi = max(hi, r.y);
+    }
+    tb = max(tb, min(lo, hi)); te = min(te, hi);
+    if (te < tb) te = tb;
+}
+
 // PLS: the source level is PLANAR (level 1 of the deferred cycle, see load_px_planar)
 // FeedPub: blend() of a cycle with narrowed tiles (pyrdown_l0.inc) hands their violation words to the host with the FIRST launch of its chain - this
 // one, when level 1 came from feed() - instead of a launch of its own (k_feed_publish: 4 us of a 0.32 ms step); pin == nullptr: nothing to publish
@@ -920,8 +976,8 @@ __device__ __forceinline__ void feed_publish_words(const FeedPub& fp) {
     __threadfence_system();
     __hip_atomic_store(&fp.pin[0], fp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-template <int M, int SK, bool PLS = false>
-__global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts, FeedPub fp) {
+template <int M, int SK, bool PLS, class TS>
+__device__ __forceinline__ void pyr_down_multi_body(const TS& ts, const FeedPub& fp) {
     if (fp.pin != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feed_publish_words(fp);
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
     const int t = blockIdx.z;
@@ -930,16 +986,21 @@ __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts, FeedPub fp) 
     __shared__ Px<M> hb[PD_NR][WAVE];
     pyr_down_block<M, SK, PLS>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y, hb);
 }
+template <int M, int SK, bool PLS = false>
+__global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts, FeedPub fp) { pyr_down_multi_body<M, SK, PLS>(ts, fp); }
+template <int M, int SK, bool PLS = false>
+__global__ __launch_bounds__(512) void k_pyr_down_multi_tab(TileTab ts, FeedPub fp) { pyr_down_multi_body<M, SK, PLS>(ts, fp); }
 
 // top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t})) at level-L pixel (x, y); the tile rectangles of
 // ts are those of level L - sh (the first collapse step passes its fine level, sh = 1).
-template <int M>
-__device__ __forceinline__ Px<M> top_px(const TileSet& ts, int tb, int te, int x, int y, int sh) {
+template <int M, class TS>
+__device__ __forceinline__ Px<M> top_px(const TS& ts, int tb, int te, int x, int y, int sh) {
     Px<M> d; d.c0 = 0; d.c1 = 0; d.c2 = 0; d.w = 0.f;
     for (int t = tb; t < te; ++t) {
         const int lx = x - (ts.x_tl[t] >> sh), ly = y - (ts.y_tl[t] >> sh);
-        if ((unsigned)lx < (unsigned)ts.coarse[t].cols && (unsigned)ly < (unsigned)ts.coarse[t].rows) {
-            Px<M> g = load_px<M, false>(ts.coarse[t], lx, ly);
+        const LevelBuf cl = ts.coarse[t];
+        if ((unsigned)lx < (unsigned)cl.cols && (unsigned)ly < (unsigned)cl.rows) {
+            Px<M> g = load_px<M, false>(cl, lx, ly);
             if constexpr (M == M_I16) {
                 d.c0 = wrap_s16(d.c0 + f2s_x86((float)g.c0 * g.w)); d.c1 = wrap_s16(d.c1 + f2s_x86((float)g.c1 * g.w)); d.c2 = wrap_s16(d.c2 + f2s_x86((float)g.c2 * g.w));
             } else { d.c0 = d.c0 + g.c0 * g.w; d.c1 = d.c1 + g.c1 * g.w; d.c2 = d.c2 + g.c2 * g.w; }
@@ -971,8 +1032,8 @@ __device__ unsigned long long g_phase[1024][12];
 #endif
 // The tiles [tb, te) of ts are those of ONE mosaic (all of them in a single blend; one mosaic's share in a batched launch, see
 // BatchOut): the body of a collapse step for the block (blockIdx.x, blockIdx.y) of that mosaic.
-template <int M, int SK, bool FINE0, bool TOP>
-__device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const int tb, const int te, const LevelBuf& coarse_out, const LevelBuf& fine_out, const OutMat& out) {
+template <int M, int SK, bool FINE0, bool TOP, class TS>
+__device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int te, const LevelBuf& coarse_out, const LevelBuf& fine_out, const OutMat& out) {
     using WT = typename WorkT<M>::t;
     // Tiles are taken G at a time: their coarse tiles (and, in the last round, that of out_k) are staged in ONE phase —
     // every global load of the round in flight together, the fine-level pixels included, one barrier pair per round
@@ -994,6 +1055,9 @@ __device__ __forceinline__ void collapse_gather_body(const TileSet& ts, const in
     int bxi = blockIdx.x, byi = blockIdx.y;
     if (out.grp > 0 && !xcd_block(blockIdx.x, out.grp, out.gx, out.gy, out.xmagic, bxi, byi)) return;
     const int cx0 = (bxi + out.bx0) * WAVE, cy0 = byi * UP_TY;
+    // (a TileTab: the tiles whose columns meet the block's, widened by the one coarse column the staged halo of the first step's gathered top
+    // level reaches - top_px looks tiles up on the block's coarse columns cx0 - 1 .. cx0 + WAVE; a TileSet: all tiles, as given)
+    tile_range(ts, 2 * cx0 - (TOP ? 2 : 0), 2 * cx0 + 2 * WAVE + (TOP ? 2 : 0), tb, te);
     PT_DECL;
     // float work types: the accumulators and every stencil operation on (b, g) / (r, -) register pairs (packed fp32, see pyr_up_2x2_pk)
     constexpr bool PK = M != M_I16;
@@ -1267,6 +1331,11 @@ template <int M, int SK, bool FINE0, bool TOP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     collapse_gather_body<M, SK, FINE0, TOP>(ts, 0, ts.n, coarse_out, fine_out, out);
 }
+// ... its tiles in a device-resident table (more than DEF_MAX of them)
+template <int M, int SK, bool FINE0, bool TOP = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather_tab(TileTab ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+    collapse_gather_body<M, SK, FINE0, TOP>(ts, 0, ts.n, coarse_out, fine_out, out);
+}
 
 // Several mosaics per launch (isx_blender_blend_batch: independent pairs of one rig - BASELINE configs 3 and 4 - share every launch of
 // the chain, so that its launch-latency-bound small levels run at P times the waves): blockIdx.z is the mosaic, ts holds the tiles of
@@ -1288,10 +1357,125 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 #include "pyrdown_l0.inc"
 #include "collapse_top.inc"
 
+template <int M, int SK>
+int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar = false);
+
+// ---- host side of the tile tables (TileTab / TopTab) ---------------------------------------------------------------------------------------
+// DevTable: a device buffer that mirrors host-built tables.  Uploads travel in KERNEL ARGUMENTS (k_tab_write: 3.5 KB per launch) - in stream
+// order behind the kernels that still read the old contents, with no pinned staging buffer whose lifetime would have to be tracked and no host
+// synchronisation - and only for the chunks that differ from what the device already holds: a fixed rig re-uses the tables of its previous
+// blend() as they are (same geometry, same buffers), so the steady state uploads nothing.
+constexpr size_t TAB_CH = 3584;
+struct TabChunk { unsigned char b[TAB_CH]; };
+__global__ __launch_bounds__(256) void k_tab_write(TabChunk c, unsigned char* dst, int n) {
+    const int i = (int)threadIdx.x * 16;
+    if (i < n) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(c.b + i);
+}
+struct DevTable {
+    DevBuf buf;
+    std::vector<unsigned char> mirror;      // what the device holds (after everything enqueued on `st` so far)
+    std::vector<unsigned> known;            // per TAB_CH chunk: the bytes from its start that the mirror vouches for
+    hipStream_t st = nullptr;
+    long long uploads = 0;                  // chunks uploaded so far (introspection: the steady state adds none)
+    // `bytes` (a multiple of 16) at offset `off` (a multiple of TAB_CH); *dev = where they lie
+    int put(hipStream_t s, size_t off, const unsigned char* src, size_t bytes, const unsigned char** dev) {
+        const size_t need = off + (bytes + TAB_CH - 1) / TAB_CH * TAB_CH;
+        if (need > buf.cap || s != st) {
+            if (need > buf.cap) ISX_TRY(buf.reserve(std::max(need + need / 2, (size_t)64 * TAB_CH)));      // (hipFree waits for the kernels that read the old table)
+            mirror.assign(buf.cap, 0); known.assign(buf.cap / TAB_CH + 1, 0u); st = s;
+        }
+        for (size_t o = 0; o < bytes; o += TAB_CH) {
+            const size_t len = std::min(TAB_CH, bytes - o), c = (off + o) / TAB_CH;
+            if (known[c] >= len && memcmp(mirror.data() + off + o, src + o, len) == 0) continue;
+            TabChunk ch;
+            memcpy(ch.b, src + o, len);
+            memcpy(mirror.data() + off + o, src + o, len);
+            known[c] = std::max(known[c], (unsigned)len);
+            hipLaunchKernelGGL(k_tab_write, dim3(1), dim3(256), 0, s, ch, (unsigned char*)buf.p + off + o, (int)len);
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(ISX_ERR_HIP, "launch of tab_write failed: %s", hipGetErrorString(le));
+            ++uploads;
+        }
+        *dev = (const unsigned char*)buf.p + off;
+        return ISX_OK;
+    }
+};
+// One launch's tiles: in the kernel arguments up to DEF_MAX (TileSet), as a device table beyond (TileTab).  `td` = one TileDesc per tile;
+// gshift / range_cols: the index ranges per 2^gshift columns of the launch's fine level (range_cols wide); range_cols = 0: none (kernels that
+// take their tile from the grid).  `slot` numbers the launches of a chain: each has its own stretch of the table.
+struct TileViews { bool tab = false; TileSet ts; TileTab tt; };
+inline void tileset_of(const std::vector<TileDesc>& td, TileSet* ts) {
+    memset(ts, 0, sizeof(*ts));
+    ts->n = (int)td.size();
+    for (int t = 0; t < ts->n; ++t) {
+        const TileDesc& e = td[(size_t)t];
+        ts->s0[t] = e.s0; ts->fine[t] = e.fine; ts->coarse[t] = e.coarse;
+        ts->x_tl[t] = e.x_tl; ts->y_tl[t] = e.y_tl; ts->w[t] = e.w; ts->h[t] = e.h; ts->bx_lo[t] = e.bx_lo; ts->bx_hi[t] = e.bx_hi;
+    }
+}
+// index ranges [first, last) of the tiles whose columns [x, x + w) meet each stretch of 2^gshift columns; *deepest = the longest range
+inline void tile_ranges(const int* xs, const int* ws, int n, int gshift, int range_cols, std::vector<int2>* rng, int* deepest) {
+    const int nr = std::max(1, (range_cols + (1 << gshift) - 1) >> gshift);
+    rng->assign((size_t)nr, make_int2(1 << 30, 0));
+    for (int t = 0; t < n; ++t) {
+        if (ws[t] <= 0 || xs[t] + ws[t] <= 0) continue;
+        const int b0 = std::min(std::max(xs[t], 0) >> gshift, nr - 1), b1 = std::min((xs[t] + ws[t] - 1) >> gshift, nr - 1);
+        for (int q = b0; q <= b1; ++q) { int2& r = (*rng)[(size_t)q]; r.x = std::min(r.x, t); r.y = std::max(r.y, t + 1); }
+    }
+    int deep = 0;
+    for (auto& r : *rng) { if (r.y <= r.x) r = make_int2(0, 0); deep = std::max(deep, r.y - r.x); }
+    if (deepest) *deepest = deep;
+}
+struct TabScratch { std::vector<unsigned char> img; std::vector<int2> rng; std::vector<int> xs, ws; };
+inline size_t tab_slot_stride(int n, int range_cols_max) {
+    const size_t bytes = (size_t)n * std::max(sizeof(TileDesc), sizeof(TopDesc)) + ((size_t)range_cols_max / 32 + 4) * sizeof(int2) + 64;
+    return (bytes + TAB_CH - 1) / TAB_CH * TAB_CH;
+}
+inline int make_views(DevTable* tab, TabScratch* sc, hipStream_t st, int slot, size_t stride, const std::vector<TileDesc>& td, int gshift, int range_cols, TileViews* v) {
+    const int n = (int)td.size();
+    v->tab = n > DEF_MAX;
+    if (!v->tab) { tileset_of(td, &v->ts); return ISX_OK; }
+    const size_t dbytes = (size_t)n * sizeof(TileDesc);
+    size_t rbytes = 0;
+    if (range_cols > 0) {
+        sc->xs.resize((size_t)n); sc->ws.resize((size_t)n);
+        for (int t = 0; t < n; ++t) { sc->xs[(size_t)t] = td[(size_t)t].x_tl; sc->ws[(size_t)t] = td[(size_t)t].w; }
+        tile_ranges(sc->xs.data(), sc->ws.data(), n, gshift, range_cols, &sc->rng, nullptr);
+        rbytes = (sc->rng.size() * sizeof(int2) + 15) & ~(size_t)15;
+    }
+    ISX_CHECK_ARG(dbytes + rbytes <= stride, ISX_ERR_INTERNAL, "tile table: %zu bytes exceed the slot's %zu", dbytes + rbytes, stride);
+    sc->img.assign(dbytes + rbytes, 0);
+    memcpy(sc->img.data(), td.data(), dbytes);
+    if (rbytes) memcpy(sc->img.data() + dbytes, sc->rng.data(), sc->rng.size() * sizeof(int2));
+    const unsigned char* dev = nullptr;
+    ISX_TRY(tab->put(st, (size_t)slot * stride, sc->img.data(), dbytes + rbytes, &dev));
+    TileTab& tt = v->tt;
+    memset(&tt, 0, sizeof(tt));
+    tt.n = n; tt.gshift = gshift; tt.nrng = range_cols > 0 ? (int)sc->rng.size() : 0;
+    tt.rng = range_cols > 0 ? (const int2*)(dev + dbytes) : nullptr;
+    const char* base = (const char*)dev;
+    tt.s0.base = base; tt.fine.base = base; tt.coarse.base = base; tt.x_tl.base = base; tt.y_tl.base = base; tt.w.base = base; tt.h.base = base;
+    tt.bx_lo.base = base; tt.bx_hi.base = base;
+    return ISX_OK;
+}
+
 // level 0 -> 1 of every recorded tile: CV_8UC3 and CV_16SC3 tiles through k_pyr_down0 (ISX_PD0=0: the general kernel, for A/B runs)
 // planar: level 1 is written as 12-byte image records + a weight plane (ts.coarse[t].wgt set by the caller; k_pyr_down0 only)
 template <int M, int SK>
-int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar = false) {
+int launch_pyr_down0(const TileViews& v, dim3 grid, double bytes, hipStream_t st, bool planar = false) {
+    if (!v.tab) return launch_pyr_down0<M, SK>(v.ts, grid, bytes, st, planar);
+    static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
+    if constexpr (SK == SK_U8 || SK == SK_S16) {
+        if constexpr (M == M_F32 || M == M_I16) {
+            if (planar) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0_tab<M, SK, true>), grid, dim3(512), 0, v.tt); return ISX_OK; }
+        }
+        if (fast) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0_tab<M, SK>), grid, dim3(512), 0, v.tt); return ISX_OK; }
+    }
+    ISX_LAUNCH("pyr_down_l0", bytes, st, (k_pyr_down_multi_tab<M, SK>), grid, dim3(512), 0, v.tt, FeedPub{nullptr, 0, nullptr, 0});
+    return ISX_OK;
+}
+template <int M, int SK>
+int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar) {
     static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
     if constexpr (SK == SK_U8 || SK == SK_S16) {
         if constexpr (M == M_F32 || M == M_I16) {
@@ -1606,6 +1790,10 @@ struct isx_blender {
     LevelBuf dst[MAX_LEVELS];
     DevBuf dst_arena, tile_arena;
     DevBuf out_arena;                    // I16, deferred cycle: the collapsed levels out_k as 16-byte register records
+    DevTable tab;                        // deferred cycle of more than DEF_MAX tiles: the launches' tile tables in device memory (TileTab)
+    TabScratch tab_sc;
+    std::vector<TileDesc> td;            // one launch's tiles, host side (reused)
+    std::vector<TopDesc> tpd;
     MatStage st_img, st_mask, st_out, st_outmask;
     MatStage st_other;                   // isx_blender_feed_dilated: the warped mask that is AND-ed in (W:299)
     DevBuf dil_mask;                     // ... the dilated & AND-ed mask of an eager / Feather / NO feed (recorded tiles keep theirs per tile)
@@ -1615,7 +1803,8 @@ struct isx_blender {
     std::vector<int4> fed;
     bool cleared = false;
     // deferred level 0: tiles recorded by feed(), consumed by blend()
-    // fused feed (k_feed_pd0, deferred mode 2): g1 = 0 level 1 not produced yet, 1 produced by feed() as 16-byte records, 2 produced PLANAR;
+    // fused feed (k_feed_pd0, deferred mode 2): g1 = 0 level 1 not produced yet, 1 produced by feed() as 16-byte records, 2 produced PLANAR, 3 produced by
+    // feed() but since rewritten on a window's columns in another layout (to be produced again);
     // narrow != 0: a CV_16SC3 tile whose private copy was written as CV_8UC3 (sk = SK_U8, fed_sk = SK_S16) with escape segments in `wide`
     struct TileRec { Src0 s0; int sk; LevelBuf g[MAX_LEVELS]; int x_tl, y_tl, width, height;
                      int fed_sk = 0, g1 = 0, narrow = 0; unsigned char* wide = nullptr; size_t wide_step = 0; unsigned char* chunk = nullptr; int nbx = 0; };
@@ -1982,8 +2171,41 @@ inline int roll_max_tiles(const TileSet& ts, const LevelBuf& coarse, int cx_lo, 
         }
     return most;
 }
+// the same for any number of tiles (TileDesc records at the fine level): per left edge of a tile's strip rectangle, the tiles over that strip
+// column, and among them the deepest overlap of their strip-row intervals; stops as soon as more than `cap` tiles meet (the callers ask "at
+// most 2?", "at most 3?")
+inline int roll_max_tiles(const std::vector<TileDesc>& td, const LevelBuf& coarse, int cx_lo, int cx_hi, int R, int cap) {
+    const int nsx = cdiv(cx_hi - cx_lo, RL_CW), nsy = cdiv(coarse.rows, R), n = (int)td.size();
+    std::vector<int4> r;
+    r.reserve((size_t)n);
+    for (int t = 0; t < n; ++t) {
+        const TileDesc& e = td[(size_t)t];
+        const int fx0 = e.x_tl - 2 * cx_lo, fx1 = fx0 + e.w, fy0 = e.y_tl, fy1 = fy0 + e.h;
+        if (fx1 <= 0 || fy1 <= 0) continue;
+        const int a = fx0 > 0 ? fx0 / (2 * RL_CW) : 0, b = std::min(nsx - 1, (fx1 - 1) / (2 * RL_CW));
+        const int c = fy0 > 0 ? fy0 / (2 * R) : 0, d = std::min(nsy - 1, (fy1 - 1) / (2 * R));
+        if (a > b || c > d) continue;
+        r.push_back(make_int4(a, b, c, d));
+    }
+    std::sort(r.begin(), r.end(), [](const int4& p, const int4& q) { return p.x < q.x; });
+    int most = 0;
+    std::vector<int2> over;
+    for (size_t i = 0; i < r.size(); ++i) {
+        if (i > 0 && r[i].x == r[i - 1].x) continue;
+        const int px = r[i].x;
+        over.clear();
+        for (size_t j = 0; j < r.size() && r[j].x <= px; ++j) if (r[j].y >= px) over.push_back(make_int2(r[j].z, r[j].w));
+        for (size_t j = 0; j < over.size(); ++j) {       // deepest point of the row intervals lies at a top edge
+            int cnt = 0;
+            for (size_t q = 0; q < over.size(); ++q) cnt += (over[q].x <= over[j].x && over[j].x <= over[q].y) ? 1 : 0;
+            most = std::max(most, cnt);
+            if (most > cap) return most;
+        }
+    }
+    return most;
+}
 template <int M, int SK, int R, int MAXT>
-int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& coarse, OutMat o, int cx_lo, int cx_hi, double bytes, bool* done) {
+int launch_collapse_roll_r(hipStream_t st, const TileViews& v, const LevelBuf& coarse, OutMat o, int cx_lo, int cx_hi, double bytes, bool* done) {
     const int nsx = cdiv(cx_hi - cx_lo, RL_CW), nsy = cdiv(coarse.rows, R), nby = cdiv(nsy, ROLL_WAVES);
     if (nsx <= 0 || nsy <= 0) return ISX_OK;
     static const int band_mode = [] { const char* e = getenv("ISX_ROLL_BAND"); return e ? atoi(e) : 1; }();
@@ -1992,50 +2214,60 @@ int launch_collapse_roll_r(hipStream_t st, const TileSet& ts, const LevelBuf& co
     o.bx0 = 0; o.grp = grp; o.gx = nsx; o.gy = nby; o.xmagic = xcd_magic(grp, nsx);
     o.band = band_mode ? cdiv(nby, 8) : 0;
     const unsigned nblk = o.band ? xcd_band_blocks(grp, nsx, nby) : xcd_grid_blocks(grp, nsx, nby);
-    ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll<M, SK, R, MAXT>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, ts, coarse, o, cx_lo);
+    if (v.tab) {      // (the table form is instantiated for two-row strips only)
+        if constexpr (R == 2) ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll_tab<M, SK, R, MAXT>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, v.tt, coarse, o, cx_lo);
+        else return ISX_OK;
+    } else ISX_LAUNCH("collapse_roll", bytes, st, (k_collapse_roll<M, SK, R, MAXT>), dim3(nblk), dim3(64 * ROLL_WAVES), 0, v.ts, coarse, o, cx_lo);
     *done = true;
     return ISX_OK;
 }
 // which instantiation runs the last step: 0 = none (k_collapse_gather), else 10 R + MAXT
 template <int SK>
-int roll_variant(const TileSet& ts, const LevelBuf& coarse, int cx_lo, int cx_hi) {
+int roll_variant(const std::vector<TileDesc>& td, const LevelBuf& coarse, int cx_lo, int cx_hi) {
     static const int mode = [] { const char* e = getenv("ISX_ROLL"); return e ? atoi(e) : 1; }();
     static const int rsel = [] { const char* e = getenv("ISX_ROLL_R"); return e ? atoi(e) : 2; }();      // rows per wave (tuning runs only)
     if constexpr (SK == SK_U8 || SK == SK_S16) {
         if (!mode || coarse.cols < 2 || (unsigned long long)coarse.rows * coarse.cols * 16ull >= (1ull << 32)) return 0;
-        for (int t = 0; t < ts.n; ++t)
-            if (ts.coarse[t].cols < 2 || ts.s0[t].cols < 2 || ts.s0[t].rows < 2 || ts.s0[t].iend == 0u ||      // iend != 0: a CV_8UC3 / CV_16SC3 tile below 2 GiB, 32-bit offsets
-                (unsigned long long)ts.coarse[t].rows * ts.coarse[t].cols * 16ull >= (1ull << 32)) return 0;
+        for (const TileDesc& e : td)
+            if (e.coarse.cols < 2 || e.s0.cols < 2 || e.s0.rows < 2 || e.s0.iend == 0u ||      // iend != 0: a CV_8UC3 / CV_16SC3 tile below 2 GiB, 32-bit offsets
+                (unsigned long long)e.coarse.rows * e.coarse.cols * 16ull >= (1ull << 32)) return 0;
+        const bool big = td.size() > (size_t)DEF_MAX;      // a device table: two-row strips or k_collapse_gather
         if (cdiv(cx_hi - cx_lo, RL_CW) <= 0 || coarse.rows <= 0) return 0;
         // two rows per wave while at most two tiles reach a strip (a pair, a row of tiles with narrow overlaps); a third slot
         // for panoramas whose tiles overlap their second neighbours (BASELINE config 5); k_collapse_gather beyond that
         // ... and two rows with a third slot (round 4: 4 waves per SIMD instead of 5, still faster than one-row strips - config 5's last step
         // 0.704 -> 0.654 ms; ISX_ROLL_R23=0: the one-row form, for A/B runs)
         static const bool r23 = [] { const char* e = getenv("ISX_ROLL_R23"); return !(e && e[0] == '0'); }();
-        const int most2 = rsel != 1 ? roll_max_tiles(ts, coarse, cx_lo, cx_hi, 2) : 99;
+        const int most2 = (rsel != 1 || big) ? roll_max_tiles(td, coarse, cx_lo, cx_hi, 2, 3) : 99;
         if (most2 <= 2) return 22;
-        if (r23 && most2 <= 3) return 23;
-        const int most = roll_max_tiles(ts, coarse, cx_lo, cx_hi, 1);
+        if ((r23 || big) && most2 <= 3) return 23;
+        if (big) return 0;
+        const int most = roll_max_tiles(td, coarse, cx_lo, cx_hi, 1, 3);
         if (most <= 2) return 12;
         if (most <= 3) return 13;
     }
     return 0;
 }
 template <int M, int SK>
-int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileSet& ts, const LevelBuf& coarse, const OutMat& o, int cx_lo, int cx_hi, double bytes, int variant, bool* done) {
+int launch_collapse_roll(isx_blender* b, hipStream_t st, const TileViews& v, const LevelBuf& coarse, const OutMat& o, int cx_lo, int cx_hi, double bytes, int variant, bool* done) {
     *done = false;
     if constexpr (SK == SK_U8 || SK == SK_S16) {
         switch (variant) {
-            case 22: return launch_collapse_roll_r<M, SK, 2, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
-            case 23: return launch_collapse_roll_r<M, SK, 2, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
-            case 12: return launch_collapse_roll_r<M, SK, 1, 2>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
-            case 13: return launch_collapse_roll_r<M, SK, 1, 3>(st, ts, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 22: return launch_collapse_roll_r<M, SK, 2, 2>(st, v, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 23: return launch_collapse_roll_r<M, SK, 2, 3>(st, v, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 12: return launch_collapse_roll_r<M, SK, 1, 2>(st, v, coarse, o, cx_lo, cx_hi, bytes, done);
+            case 13: return launch_collapse_roll_r<M, SK, 1, 3>(st, v, coarse, o, cx_lo, cx_hi, bytes, done);
             default: break;
         }
     }
     return ISX_OK;
 }
 
+// timing-only ablations of the small-level tail (tools/probes/tail_ablation.sh; wrong pixels): 1 = the pyrDown launches of levels >= 2 as one block
+// per tile, 2 = k_collapse_top as one block, 4 = those launches not issued at all - what any fusion of them could at most give
+#ifndef ISX_TAIL_ABL
+#define ISX_TAIL_ABL 0
+#endif
 // blend() of a fully deferred cycle: Gaussian chains of all tiles, top gather, gathering collapse chain
 template <int M, int SK>
 int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
@@ -2056,19 +2288,23 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         od[0].img = nullptr;
         d = od;
     }
+    // One TileDesc per tile and launch (b->td, reused); make_views() hands them to the kernel - in its arguments up to DEF_MAX tiles, as a device
+    // table beyond.  Every launch of the chain has its own slot of the table: L pyrDown levels, the top launch, L collapse steps.
+    std::vector<TileDesc>& td = b->td;
     auto base = [&](int k_fine) {   // tile rectangles at level k_fine
-        TileSet ts;
-        memset(&ts, 0, sizeof(ts));
-        ts.n = n;
+        td.resize((size_t)n);
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
-            ts.s0[t] = r.s0;
-            ts.x_tl[t] = r.x_tl >> k_fine; ts.y_tl[t] = r.y_tl >> k_fine;
-            ts.w[t] = r.g[k_fine].cols; ts.h[t] = r.g[k_fine].rows;
-            ts.bx_lo[t] = 0; ts.bx_hi[t] = 1 << 30;
+            TileDesc& e = td[(size_t)t];
+            memset(&e, 0, sizeof(e));
+            e.s0 = r.s0;
+            e.x_tl = r.x_tl >> k_fine; e.y_tl = r.y_tl >> k_fine;
+            e.w = r.g[k_fine].cols; e.h = r.g[k_fine].rows;
+            e.bx_lo = 0; e.bx_hi = 1 << 30;
         }
-        return ts;
     };
+    const size_t tab_stride = tab_slot_stride(n, d[0].cols);
+    auto views = [&](int slot, int gshift, int range_cols, TileViews* v) { return make_views(&b->tab, &b->tab_sc, st, slot, tab_stride, td, gshift, range_cols, v); };
     // Column window (see step 3): the columns of every level the window's pixels depend on, need_k, and from them the columns of the
     // tiles' Gaussian levels that have to be PRODUCED: prod_L = need_L, prod_k = need_k widened by what pyrDown reads for prod_{k+1}
     // (columns 2c - 2 .. 2c + 2).  A tile's chain runs only the blocks that hold them; the rest of its levels keeps whatever it held.
@@ -2096,9 +2332,9 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         static const bool top_on0 = [] { const char* e = getenv("ISX_TOP"); return !(e && e[0] == '0'); }();
         static const bool out12_on = [] { const char* e = getenv("ISX_OUT12"); return !(e && e[0] == '0'); }();
         static const bool g1p_on = [] { const char* e = getenv("ISX_G1P"); return !(e && e[0] == '0'); }();
-        TileSet ts1 = base(0);
-        for (int t = 0; t < n; ++t) { ts1.fine[t] = b->tiles[t].g[0]; ts1.coarse[t] = b->tiles[t].g[1]; }
-        roll_var = roll_variant<SK>(ts1, d[1], need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols));
+        base(0);
+        for (int t = 0; t < n; ++t) { td[(size_t)t].fine = b->tiles[t].g[0]; td[(size_t)t].coarse = b->tiles[t].g[1]; }
+        roll_var = roll_variant<SK>(td, d[1], need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols));
         const int D0 = std::min(TOP_DMAX, L - 1);
         const bool lvl1_by_gather = !(top_on0 && D0 >= 2) || L - D0 >= 2;
         rec12 = roll_var != 0 && lvl1_by_gather && out12_on;
@@ -2129,35 +2365,52 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
             continue;
         }
-        TileSet ts = base(k);
+        base(k);
         int maxc = 0, maxr = 0;
         double bytes = 0.0;
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
-            ts.fine[t] = r.g[k]; ts.coarse[t] = r.g[k + 1];
-            if (g1_planar && k == 0) ts.coarse[t] = planar_of(r.g[1]);
-            if (g1_planar && k == 1) ts.fine[t] = planar_of(r.g[1]);
+            TileDesc& e = td[(size_t)t];
+            e.fine = r.g[k]; e.coarse = r.g[k + 1];
+            if (g1_planar && k == 0) e.coarse = planar_of(r.g[1]);
+            if (g1_planar && k == 1) e.fine = planar_of(r.g[1]);
             maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
             double share = 1.0;
             if (windowed) {   // the tile's columns of level k + 1 inside prod_{k+1}, as block columns of its own grid
                 const int x_t = r.x_tl >> (k + 1), nbx = cdiv(r.g[k + 1].cols, PD_OW);
                 const int c0 = std::max(prod_lo[k + 1] - x_t, 0), c1 = std::min(prod_hi[k + 1] - x_t, r.g[k + 1].cols);
-                ts.bx_lo[t] = c1 > c0 ? c0 / PD_OW : 0; ts.bx_hi[t] = c1 > c0 ? cdiv(c1, PD_OW) : 0;
-                share = (double)(ts.bx_hi[t] - ts.bx_lo[t]) / nbx;
+                e.bx_lo = c1 > c0 ? c0 / PD_OW : 0; e.bx_hi = c1 > c0 ? cdiv(c1, PD_OW) : 0;
+                share = (double)(e.bx_hi - e.bx_lo) / nbx;
             }
             bytes += share * ((double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec));
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
-        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar)));
-        else {
+        if ((ISX_TAIL_ABL & 1) && k >= 2) grid = dim3(1, 1, n);
+        if ((ISX_TAIL_ABL & 4) && k >= 2) continue;
+        TileViews v;
+        ISX_TRY(views(k, 0, 0, &v));
+        if (k == 0) {
+            ISX_TRY((launch_pyr_down0<M, SK>(v, grid, bytes, st, g1_planar)));
+            // Level 1 of these tiles now holds what THIS chain wants, on the columns this chain needs.  A tile whose level 1 came from feed() (g1 = 1 / 2)
+            // no longer has it whole in that layout when only a window's columns were rewritten (3 = fused-fed, level 1 to be produced again): a later
+            // column strip of the same cycle that shares the tile (run_blend_deferred_strips) must not take it for done.  (Found by the fuzzer in round 5:
+            // 35 tiles, two bands, a strip with more than three tiles over one place took k_collapse_gather and 16-byte records, its neighbour read the
+            // shared tile's planar level 1 behind it.)
+            for (int t = 0; t < n; ++t)
+                if (b->tiles[t].g1 != 0) b->tiles[t].g1 = windowed ? 3 : (g1_planar ? 2 : 1);
+        } else {
             FeedPub fp{nullptr, 0, nullptr, 0};
             if (b->narrow_pending && !b->narrow_published) {      // the violation words ride on this launch (the first of the chain: level 1 came from feed())
                 fp = FeedPub{(unsigned*)b->feed_state.p, n, b->feed_pin, ++b->feed_seq};
                 b->narrow_published = true;
             }
             if (k == 1 && g1_planar) {
-                if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts, fp);
-            } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts, fp);
+                if constexpr (M == M_F32 || M == M_I16) {
+                    if (v.tab) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi_tab<M, SK_LEVEL, true>), grid, dim3(512), 0, v.tt, fp);
+                    else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, v.ts, fp);
+                }
+            } else if (v.tab) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi_tab<M, SK_LEVEL>), grid, dim3(512), 0, v.tt, fp);
+            else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, v.ts, fp);
         }
         // the full-size level-0 kernel is behind us: from here to the last collapse step the launches are small
         if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
@@ -2180,44 +2433,85 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         static const bool top_on = [] { const char* e = getenv("ISX_TOP"); return !(e && e[0] == '0'); }();
         const int D = std::min(TOP_DMAX, L - 1), kout = L - D;
         if (top_on && D >= 2) {
-            TopTiles tt;
-            memset(&tt, 0, sizeof(tt));
-            tt.n = n; tt.D = D;
+            std::vector<TopDesc>& tp = b->tpd;
+            tp.resize((size_t)n);
             double bytes = (double)d[kout].rows * d[kout].cols * alg_d_rgb(prec);
             for (int t = 0; t < n; ++t) {
                 const isx_blender::TileRec& r = b->tiles[t];
-                tt.x_tl[t] = r.x_tl >> kout; tt.y_tl[t] = r.y_tl >> kout; tt.w[t] = r.g[kout].cols; tt.h[t] = r.g[kout].rows;
+                TopDesc& e = tp[(size_t)t];
+                memset(&e, 0, sizeof(e));
+                e.x_tl = r.x_tl >> kout; e.y_tl = r.y_tl >> kout; e.w = r.g[kout].cols; e.h = r.g[kout].rows;
                 for (int i = 0; i <= D; ++i) {
-                    tt.g[t][i] = r.g[kout + i].img;
+                    e.g[i] = r.g[kout + i].img;
                     // every level once as a fine level (record + weight; the top one as the gathered top), every level but the output's once as a pyrUp source
                     bytes += (double)r.g[kout + i].rows * r.g[kout + i].cols * (alg_g(prec) + (i > 0 ? alg_g_rgb(prec) : 0.0));
                 }
             }
             const int gx_all = cdiv(d[kout].cols, TOP_BW);
             const int bx_lo = need_lo[kout] / TOP_BW, bx_hi = std::min(cdiv(need_hi[kout], TOP_BW), gx_all);
-            const dim3 grid(bx_hi - bx_lo, cdiv(d[kout].rows, TOP_BH));
-            ISX_LAUNCH("collapse_top", bytes * (double)(bx_hi - bx_lo) / gx_all, st, (k_collapse_top<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
+            dim3 grid(bx_hi - bx_lo, cdiv(d[kout].rows, TOP_BH));
+            if (ISX_TAIL_ABL & 2) grid = dim3(1, 1);
+            bytes *= (double)(bx_hi - bx_lo) / gx_all;
+            if (ISX_TAIL_ABL & 4) {
+            } else if (n <= DEF_MAX) {
+                TopTiles tt;
+                memset(&tt, 0, sizeof(tt));
+                tt.n = n; tt.D = D;
+                for (int t = 0; t < n; ++t) {
+                    const TopDesc& e = tp[(size_t)t];
+                    tt.x_tl[t] = e.x_tl; tt.y_tl[t] = e.y_tl; tt.w[t] = e.w; tt.h[t] = e.h;
+                    for (int i = 0; i <= D; ++i) tt.g[t][i] = e.g[i];
+                }
+                ISX_LAUNCH("collapse_top", bytes, st, (k_collapse_top<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
+            } else {
+                // the tiles a block has to look at: its cone widens, level by level, by less than 3 * 2^D output-level columns on either side
+                TabScratch& sc = b->tab_sc;
+                const int m = 3 << D;
+                sc.xs.resize((size_t)n); sc.ws.resize((size_t)n);
+                for (int t = 0; t < n; ++t) { sc.xs[(size_t)t] = tp[(size_t)t].x_tl - m; sc.ws[(size_t)t] = tp[(size_t)t].w + 2 * m; }
+                int gsh = 0;
+                while ((1 << gsh) < TOP_BW) ++gsh;
+                static_assert((TOP_BW & (TOP_BW - 1)) == 0, "one range per block column");
+                tile_ranges(sc.xs.data(), sc.ws.data(), n, gsh, d[kout].cols, &sc.rng, nullptr);
+                const size_t dbytes = (size_t)n * sizeof(TopDesc), rbytes = (sc.rng.size() * sizeof(int2) + 15) & ~(size_t)15;
+                ISX_CHECK_ARG(dbytes + rbytes <= tab_stride, ISX_ERR_INTERNAL, "tile table: %zu bytes exceed the slot's %zu", dbytes + rbytes, tab_stride);
+                sc.img.assign(dbytes + rbytes, 0);
+                memcpy(sc.img.data(), tp.data(), dbytes);
+                memcpy(sc.img.data() + dbytes, sc.rng.data(), sc.rng.size() * sizeof(int2));
+                const unsigned char* dev = nullptr;
+                ISX_TRY(b->tab.put(st, (size_t)L * tab_stride, sc.img.data(), dbytes + rbytes, &dev));
+                TopTab tt;
+                memset(&tt, 0, sizeof(tt));
+                tt.n = n; tt.D = D; tt.nrng = (int)sc.rng.size(); tt.rng = (const int2*)(dev + dbytes);
+                const char* bs = (const char*)dev;
+                tt.x_tl.base = bs; tt.y_tl.base = bs; tt.w.base = bs; tt.h.base = bs; tt.g.base = bs;
+                ISX_LAUNCH("collapse_top", bytes, st, (k_collapse_top_tab<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
+            }
             k_first = kout;
         }
     }
     // one collapse step; SKC = the tiles' type as the LAST step reads them (the steps above it read pyramid levels only)
     auto step = [&](int k, auto SKC) -> int {
         constexpr int SKL = decltype(SKC)::value;
-        TileSet ts = base(k - 1);
+        base(k - 1);
         const int gx_all = cdiv(d[k].cols, WAVE);
         const int bx_lo = need_lo[k - 1] / (2 * WAVE), bx_hi = std::min(cdiv(need_hi[k - 1], 2 * WAVE), gx_all);
         const double frac = (double)(bx_hi - bx_lo) / gx_all;                                  // share of the level this launch works on
         double bytes = k == L ? 0.0 : (double)d[k].rows * d[k].cols * alg_d_rgb(prec);      // out_k as pyrUp source (k = L: gathered from G_L)
         for (int t = 0; t < n; ++t) {
             const isx_blender::TileRec& r = b->tiles[t];
-            ts.fine[t] = r.g[k - 1]; ts.coarse[t] = r.g[k];
-            if (g1_planar && k == 2) ts.fine[t] = planar_of(r.g[1]);
-            if (g1_planar && k == 1) ts.coarse[t] = planar_of(r.g[1]);
+            TileDesc& e = td[(size_t)t];
+            e.fine = r.g[k - 1]; e.coarse = r.g[k];
+            if (g1_planar && k == 2) e.fine = planar_of(r.g[1]);
+            if (g1_planar && k == 1) e.coarse = planar_of(r.g[1]);
             if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;                        // + the weights of G_L
             bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? src_px_bytes(SKL) + 1.0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
                    + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
         }
         dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
+        // (index ranges per 128 columns of the step's fine level = one block of k_collapse_gather; a strip of k_collapse_roll spans two)
+        TileViews v;
+        ISX_TRY(views(L + 1 + k, 7, d[k - 1].cols, &v));
         OutMat o = out;
         o.bx0 = bx_lo;
         o.rec12 = (rec12 && k <= 2) ? 1 : 0;      // k = 2 writes out_1, k = 1 reads it
@@ -2236,17 +2530,23 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
                 bool done = false;
                 OutMat o1 = out;
                 o1.rec12 = rec12 ? 1 : 0;
-                ISX_TRY((launch_collapse_roll<M, SKL>(b, st, ts, d[1], o1, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, roll_var, &done)));
+                ISX_TRY((launch_collapse_roll<M, SKL>(b, st, v, d[1], o1, need_lo[0] / 2, std::min((need_hi[0] + 1) / 2, d[1].cols), bytes, roll_var, &done)));
                 ISX_CHECK_ARG(done || !(rec12 || g1_planar), ISX_ERR_STATE, "blend: the last step's kernel was planned as k_collapse_roll and did not run");
                 if (done) { b->path_last = 3; return ISX_OK; }
             }
             b->path_last = 2;
-            if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SKL, true, true>), grid, dim3(256), 0, ts, d[1], d[0], o);
-            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SKL, true, false>), grid, dim3(256), 0, ts, d[1], d[0], o);
+            if (v.tab) {
+                if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather_tab<M, SKL, true, true>), grid, dim3(256), 0, v.tt, d[1], d[0], o);
+                else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather_tab<M, SKL, true, false>), grid, dim3(256), 0, v.tt, d[1], d[0], o);
+            } else if (k == L) ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SKL, true, true>), grid, dim3(256), 0, v.ts, d[1], d[0], o);
+            else ISX_LAUNCH("collapse_gather_final", bytes, st, (k_collapse_gather<M, SKL, true, false>), grid, dim3(256), 0, v.ts, d[1], d[0], o);
         } else {
             bytes = (bytes + (double)d[k - 1].rows * d[k - 1].cols * alg_d_rgb(prec)) * frac;  // + out_{k-1}
-            if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, true>), grid, dim3(256), 0, ts, d[k], d[k - 1], o);
-            else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, false>), grid, dim3(256), 0, ts, d[k], d[k - 1], o);
+            if (v.tab) {
+                if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather_tab<M, SK_U8, false, true>), grid, dim3(256), 0, v.tt, d[k], d[k - 1], o);
+                else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather_tab<M, SK_U8, false, false>), grid, dim3(256), 0, v.tt, d[k], d[k - 1], o);
+            } else if (k == L) ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, true>), grid, dim3(256), 0, v.ts, d[k], d[k - 1], o);
+            else ISX_LAUNCH("collapse_gather", bytes, st, (k_collapse_gather<M, SK_U8, false, false>), grid, dim3(256), 0, v.ts, d[k], d[k - 1], o);
         }
         return ISX_OK;
     };
@@ -2346,6 +2646,8 @@ int run_blend_deferred_strips(isx_blender* b, const OutMat& out, bool* done) {
         b->win_x0 = wins[j].first; b->win_x1 = wins[j].second;
         rc = run_blend_deferred<M>(b, o);
         last = std::max(last, b->path_last);
+        if (b->tiles.size() == idx.size())      // what the strip's chain did to the state of its tiles' level 1 (see the level-0 launch there)
+            for (size_t i = 0; i < idx.size(); ++i) all[(size_t)idx[i]].g1 = b->tiles[i].g1;
     }
     b->tiles.swap(all);
     b->chain_on_side.swap(on_side);
@@ -2363,6 +2665,28 @@ int run_blend(isx_blender* b, const OutMat& out) {
     LevelBuf* d = b->dst;
     if (b->level0_pending) {
         if (b->tiles.size() <= (size_t)DEF_MAX) return run_blend_deferred<M>(b, out);
+        // More than DEF_MAX tiles (round 5): ONE chain over all of them, their descriptors in a device table (TileTab; cycle 4 in isx_blender_last_path).
+        // ISX_TAB=0: round 4's column strips of at most DEF_MAX tiles (run_blend_deferred_strips), ISX_STRIPS=0 as well: the eager cycle (A/B runs).
+        // One guard of the int16 arithmetic leans on the tile count: a sum of CV_8UC3 Laplacians (+-255 each) cannot wrap a short while at most 128
+        // tiles meet in a pixel - k_collapse_gather's last step does not issue the wrap for them - so a cycle with a deeper stack than that over
+        // some 128 columns takes the strips / the eager cycle as before.
+        const char* tab_env = getenv("ISX_TAB");       // (read per call: the tests switch it inside one process)
+        const bool tab_on = !(tab_env && tab_env[0] == '0');
+        bool tab_ok = tab_on;
+        if (tab_ok && M == M_I16) {
+            TabScratch& sc = b->tab_sc;
+            const int n = (int)b->tiles.size();
+            sc.xs.resize((size_t)n); sc.ws.resize((size_t)n);
+            for (int t = 0; t < n; ++t) { sc.xs[(size_t)t] = b->tiles[(size_t)t].x_tl; sc.ws[(size_t)t] = b->tiles[(size_t)t].width; }
+            int deepest = 0;
+            tile_ranges(sc.xs.data(), sc.ws.data(), n, 7, d[0].cols, &sc.rng, &deepest);
+            tab_ok = deepest <= 128;
+        }
+        if (tab_ok) {
+            ISX_TRY(run_blend_deferred<M>(b, out));
+            b->path_cycle = 4;
+            return ISX_OK;
+        }
         static const bool strips_on = [] { const char* e = getenv("ISX_STRIPS"); return !(e && e[0] == '0'); }();    // ISX_STRIPS=0: the eager cycle, as before round 4 (A/B runs)
         bool done = false;
         if (strips_on) ISX_TRY(run_blend_deferred_strips<M>(b, out, &done));
@@ -3139,6 +3463,12 @@ int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) ISX_ENTRY 
     if (last_step) *last_step = b->type == ISX_BLEND_MULTI_BAND ? b->path_last : 0;
     return ISX_OK;
 } ISX_EXIT("isx_blender_last_path")
+
+int isx_blender_table_uploads(isx_blender* b, long long* pieces) ISX_ENTRY {
+    ISX_CHECK_ARG(b != nullptr && pieces != nullptr, ISX_ERR_INVALID, "isx_blender_table_uploads: null argument");
+    *pieces = b->tab.uploads;
+    return ISX_OK;
+} ISX_EXIT("isx_blender_table_uploads")
 
 int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_feed_path: null blender");

@@ -69,7 +69,7 @@ def model_bytes(src_px, warped_px, tile_base_px, mosaic_px, precision, num_bands
 
 class PairStitcher:
     """The n >= 2 tiles of one mosaic (normally a pair) -> one blended mosaic, buffers resident in HBM (torch CUDA
-    tensors).  At most 20 tiles stay on the deferred blender cycle (isx_blender_set_deferred_level0)."""
+    tensors), on the deferred blender cycle (isx_blender_set_deferred_level0; more than 20 tiles: their descriptors in a device table)."""
 
     def __init__(self, imgs, K, Rs, scale, kind="cylindrical", num_bands=5, precision=_lib.PREC_F32,
                  device=0, stream=None, out_dtype="int16", deferred=True, interleave=False, verify_at=1, window=None, tile_type="u8"):

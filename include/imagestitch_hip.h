@@ -243,10 +243,10 @@ int isx_blender_feed_dilated(isx_blender* b, const isx_mat* img, const isx_mat* 
  * feed()/feed_u8() must stay valid and unmodified until blend() returns (OpenCV's feed() consumes
  * its inputs immediately — the reference clears the fed images before blend(), W:305-308 — so this
  * is not the default).  Host mats are staged in per-tile device buffers owned by the blender:
- * nothing changes for them.  A launch's arguments hold 20 tiles: a cycle of more tiles (up to 4096, one type) is blended in column strips
- * that at most 20 tiles reach, each by the same chain and bit-identical to the whole blend (isx_blender_last_path: cycle 3); when some
- * 128-column strip is reached by more than 20 tiles, when a tile of another type is fed, and when isx_blender_debug_level is called,
- * the recorded tiles are replayed through the eager path.
+ * nothing changes for them.  A launch's arguments hold 20 tiles: a cycle of more tiles (up to 4096, one type) runs the same chain with the
+ * tiles' descriptors in a table in device memory (isx_blender_last_path: cycle 4; round 4's column strips of at most 20 tiles, cycle 3, remain
+ * as ISX_TAB=0), bit-identical; when a tile of another type is fed, when isx_blender_debug_level is called, and for an int16 cycle of CV_8UC3
+ * tiles stacked more than 128 deep over one place, the recorded tiles are replayed through the eager path.
  * on = 2 keeps OpenCV's contract: feed() takes a private copy of every DEVICE mat it records, so the caller may release or overwrite
  * the fed mats as soon as feed() returns - the drop-in mode for callers written against cv::detail::Blender (W:286-308).  For CV_8UC3
  * and CV_16SC3 tiles that copy is a by-product of the pass that builds level 1 of the tile's pyramid (one read of the caller's mats per
@@ -277,10 +277,14 @@ int isx_blender_set_window(isx_blender* b, int x0, int x1);
 int isx_blender_result_size(isx_blender* b, int* width, int* height);
 /* Which code path the last isx_blender_blend / _blend_batch of a multi-band blender took - the fast kernels have limits (tile type, tiles
  * per place, tile count: DESIGN.md §3) and nothing else says which side of them a blend ran on.  cycle: 0 eager (the destination pyramid),
- * 1 deferred, 2 deferred inside a batched chain, 3 deferred in column strips (more than 20 recorded tiles: the library cuts the result into
- * strips that at most 20 tiles reach and runs the deferred chain per strip - bit-identical to the whole blend); last_step: the kernel of the last collapse step - 0 none (a 0-band blend), 1 k_collapse,
- * 2 k_collapse_gather, 3 k_collapse_roll.  Either pointer may be NULL.                                                          */
+ * 1 deferred, 2 deferred inside a batched chain, 3 deferred in column strips (ISX_TAB=0 and more than 20 recorded tiles: the library cuts the
+ * result into strips that at most 20 tiles reach and runs the deferred chain per strip - bit-identical to the whole blend), 4 deferred with the
+ * tiles in a device-resident table (more than 20 recorded tiles: one chain over all of them); last_step: the kernel of the last collapse step -
+ * 0 none (a 0-band blend), 1 k_collapse, 2 k_collapse_gather, 3 k_collapse_roll.  Either pointer may be NULL.                    */
 int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step);
+/* Introspection of cycle 4: how many 3.5 KB pieces of tile tables this blender has uploaded so far.  They travel in kernel arguments, in
+ * stream order, and only where they differ from what the device holds: a fixed rig uploads on its first blend() and never again.      */
+int isx_blender_table_uploads(isx_blender* b, long long* pieces);
 /* How the tiles of the last isx_blender_blend were FED in mode 2 (isx_blender_set_deferred_level0 = 2, OpenCV's contract W:302-308).
  * fused_tiles: tiles whose feed() was ONE pass over the caller's CV_8UC3 / CV_16SC3 device mats - level 1 of the tile's pyramid and the
  * private copy out of the same read (round 5; 0: host mats, other tile types, ISX_FEED_FUSE=0).  narrowed: 0 = no private copy was

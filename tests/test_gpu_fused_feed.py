@@ -164,14 +164,24 @@ def test_more_than_twenty_fused_tiles_and_windows(gpu, oracle):
     n = 24
     corners = [(90 * i, int(rng.integers(-6, 7))) for i in range(n)]
     sizes = [(160, 120 + int(rng.integers(0, 9))) for _ in range(n)]
-    for kind in ("bytes", "one"):
-        tiles = _tiles(rng, sizes, kind)
-        od, om = _oracle_blend(oracle, 3, I16, corners, sizes, tiles)
-        mb = gpu.MultiBandBlender(False, 3, I16)
-        mb.set_deferred_level0("copy")
-        d, m = _gpu_blend(gpu, mb, I16, corners, sizes, tiles)
-        assert mb.last_path()["cycle"] == "deferred_strips"
-        assert np.array_equal(m, om) and np.array_equal(d, od), kind
+    import os
+    old_tab = os.environ.get("ISX_TAB")
+    try:
+        for tab in ("1", "0"):      # round 5: one chain over a device-resident table of the tiles; ISX_TAB=0: round 4's column strips
+            os.environ["ISX_TAB"] = tab
+            for kind in ("bytes", "one"):
+                tiles = _tiles(rng, sizes, kind)
+                od, om = _oracle_blend(oracle, 3, I16, corners, sizes, tiles)
+                mb = gpu.MultiBandBlender(False, 3, I16)
+                mb.set_deferred_level0("copy")
+                d, m = _gpu_blend(gpu, mb, I16, corners, sizes, tiles)
+                assert mb.last_path()["cycle"] == ("deferred_table" if tab == "1" else "deferred_strips")
+                assert np.array_equal(m, om) and np.array_equal(d, od), (kind, tab)
+    finally:
+        if old_tab is None:
+            os.environ.pop("ISX_TAB", None)
+        else:
+            os.environ["ISX_TAB"] = old_tab
     # a caller's window over a pair
     import torch
     corners, sizes = LAYOUTS["wide"]

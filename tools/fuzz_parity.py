@@ -544,6 +544,8 @@ def case_many_tiles(rng):
         x += int(w * rng.uniform(0.0, 0.9))         # 0: a tile over its neighbour (many over one place)
     bands, prec = int(rng.integers(1, 6)), int(rng.integers(0, 3))
     mode = [True, "copy"][int(rng.integers(0, 2))]
+    # round 5: one chain over a device-resident table of the tiles (default); one case in three runs round 4's column strips (ISX_TAB=0, read per blend)
+    os.environ["ISX_TAB"] = "0" if rng.integers(0, 3) == 0 else "1"
     mb = G.MultiBandBlender(False, bands, prec)
     mb.set_deferred_level0(mode)
     ob = O.MultiBand(bands, prec)
@@ -579,6 +581,8 @@ def case_many_tiles(rng):
         if win and "more than 20 tiles reach" in str(e):
             return "skip"
         raise
+    finally:
+        os.environ.pop("ISX_TAB", None)
     d, m = d.cpu().numpy(), m.cpu().numpy()
     od, om = ob.blend(f32)
     if win:
