@@ -59,6 +59,10 @@ for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== pipeline_probe $m" 
 # round 5: A13 (the in-tree linear-ramp pair blend) on the record; the drop-in legs with the fused feed switched off / without narrowing; many tiles
 python bench.py --a13 --steps 50 2>/dev/null | line > $O/${TAG}_bench_a13.json
 for v in "ISX_FEED_FUSE=0" "ISX_FEED_NARROW=0" "ISX_FEED_STRIP=0" "ISX_FEED_FUSE=1"; do for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== [$v] pipeline_probe $m" >> $O/${TAG}_feed_variants.txt; env $v python tools/pipeline_probe.py $m 2>&1 | tail -14 >> $O/${TAG}_feed_variants.txt; done; done
+bash tools/probes/tail_ablation.sh run > $O/${TAG}_tail_ablation.txt 2>&1      # (needs tmp_ab/libtail*.so: bash tools/probes/tail_ablation.sh build, here)
+bash tools/trace_many_tiles.sh ${TAG}_t64 --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 > $O/${TAG}_many_tiles_trace.txt 2>&1
+ISX_TAB=0 python bench.py --no-cpu-baseline --no-dropin --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_64_ISX_TAB_0.json
+ISX_TAB=0 python bench.py --no-cpu-baseline --no-dropin --tiles 24 --focal 9000 --yaw 0.12 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_24_ISX_TAB_0.json
 b many_tiles_24 --tiles 24 --focal 9000 --yaw 0.12 --steps 6 --warmup 2
 b many_tiles_64 --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2
 ISX_VERIFY_NEVER=1 python bench.py --no-cpu-baseline --no-dropin --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_64_ISX_VERIFY_NEVER.json
