@@ -1356,6 +1356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 #include "collapse_roll.inc"
 #include "pyrdown_l0.inc"
 #include "collapse_top.inc"
+#include "collapse_top2.inc"
 
 template <int M, int SK>
 int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar = false);
@@ -1384,13 +1385,18 @@ struct DevTable {
             if (need > buf.cap) ISX_TRY(buf.reserve(std::max(need + need / 2, (size_t)64 * TAB_CH)));      // (hipFree waits for the kernels that read the old table)
             mirror.assign(buf.cap, 0); known.assign(buf.cap / TAB_CH + 1, 0u); st = s;
         }
+        // A stream that is being captured into a hipGraph: the graph must hold the table's writes itself (a replay may come after another blend of
+        // this blender changed the table), and what a capture enqueues has not happened: nothing is skipped and nothing is vouched for afterwards.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s != nullptr && hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+        const bool capturing = cap == hipStreamCaptureStatusActive;
         for (size_t o = 0; o < bytes; o += TAB_CH) {
             const size_t len = std::min(TAB_CH, bytes - o), c = (off + o) / TAB_CH;
-            if (known[c] >= len && memcmp(mirror.data() + off + o, src + o, len) == 0) continue;
+            if (!capturing && known[c] >= len && memcmp(mirror.data() + off + o, src + o, len) == 0) continue;
             TabChunk ch;
             memcpy(ch.b, src + o, len);
             memcpy(mirror.data() + off + o, src + o, len);
-            known[c] = std::max(known[c], (unsigned)len);
+            known[c] = capturing ? 0u : std::max(known[c], (unsigned)len);
             hipLaunchKernelGGL(k_tab_write, dim3(1), dim3(256), 0, s, ch, (unsigned char*)buf.p + off + o, (int)len);
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(ISX_ERR_HIP, "launch of tab_write failed: %s", hipGetErrorString(le));
@@ -2341,6 +2347,14 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         g1_planar = roll_var != 0 && lvl1_by_gather && g1p_on && (M == M_F32 || M == M_I16);
     }
     auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + (size_t)g.rows * g.cols * 12u); return g; };
+    // A pair with three fused top steps: k_collapse_top2 (collapse_top2.inc) rebuilds the tiles' level L itself, out of the one read of level L - 1
+    // it makes anyway - the pyrDown launch that produces level L is not issued.  ISX_TOP2=0: k_collapse_top behind that launch (A/B runs).
+    bool use_top2 = false;
+    {
+        static const bool top_on2 = [] { const char* e = getenv("ISX_TOP"); return !(e && e[0] == '0'); }();
+        static const bool top2_on = [] { const char* e = getenv("ISX_TOP2"); return !(e && e[0] == '0'); }();
+        use_top2 = top_on2 && top2_on && n <= 2 && std::min(TOP_DMAX, L - 1) == 3;
+    }
     // 1. Gaussian chains: one launch per level for all tiles.  (Per-tile chains on side streams, started
     //    by feed() to overlap with the next tile's VALU-bound warp, were measured: no gain — a kernel that
     //    fills every wave slot leaves nothing for a concurrent one — so the simpler form stays.)
@@ -2387,6 +2401,10 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
         if ((ISX_TAIL_ABL & 1) && k >= 2) grid = dim3(1, 1, n);
         if ((ISX_TAIL_ABL & 4) && k >= 2) continue;
+        if (use_top2 && k == L - 1) {       // level L is rebuilt inside k_collapse_top2
+            if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
+            continue;
+        }
         TileViews v;
         ISX_TRY(views(k, 0, 0, &v));
         if (k == 0) {
@@ -2462,7 +2480,8 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
                     tt.x_tl[t] = e.x_tl; tt.y_tl[t] = e.y_tl; tt.w[t] = e.w; tt.h[t] = e.h;
                     for (int i = 0; i <= D; ++i) tt.g[t][i] = e.g[i];
                 }
-                ISX_LAUNCH("collapse_top", bytes, st, (k_collapse_top<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
+                if (use_top2) ISX_LAUNCH("collapse_top", bytes, st, (k_collapse_top2<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
+                else ISX_LAUNCH("collapse_top", bytes, st, (k_collapse_top<M>), grid, dim3(256), 0, tt, d[kout], bx_lo, d[L].rows, d[L].cols);
             } else {
                 // the tiles a block has to look at: its cone widens, level by level, by less than 3 * 2^D output-level columns on either side
                 TabScratch& sc = b->tab_sc;

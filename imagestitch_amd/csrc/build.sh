@@ -16,7 +16,7 @@ pids=()
 for f in isx_core.cpp imgio.cpp jpegdec.cpp seamfind.cpp gather.cpp warp.hip blend.hip prep.hip linear_blend.hip seam.hip; do
     [ -f "$f" ] || continue
     o=build/${f%.*}.o
-    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ isx_internal.hpp -nt "$o" ] || [ isx_device.hpp -nt "$o" ] || [ collapse_roll.inc -nt "$o" ] || [ pyrdown_l0.inc -nt "$o" ] || [ ../../include/imagestitch_hip.h -nt "$o" ] || [ build.sh -nt "$o" ] || [ collapse_top.inc -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ isx_internal.hpp -nt "$o" ] || [ isx_device.hpp -nt "$o" ] || [ collapse_roll.inc -nt "$o" ] || [ collapse_top2.inc -nt "$o" ] || [ pyrdown_l0.inc -nt "$o" ] || [ ../../include/imagestitch_hip.h -nt "$o" ] || [ build.sh -nt "$o" ] || [ collapse_top.inc -nt "$o" ]; then
         $HIPCC $FLAGS -x hip -c "$f" -o "$o" &
         pids+=($!)
     fi

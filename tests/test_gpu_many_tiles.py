@@ -215,3 +215,40 @@ def test_the_table_is_uploaded_once_for_a_fixed_rig(gpu, oracle):
         assert np.array_equal(m.cpu().numpy(), om) and np.array_equal(d.cpu().numpy(), od)
         ups.append(mb.table_uploads())
     assert ups[0] > 0 and ups[1] == ups[0] and ups[2] == ups[0] and ups[3] > ups[2], ups
+
+
+def test_a_table_cycle_captured_as_a_hipgraph_survives_another_blend(gpu, oracle):
+    """A planned step of 24 tiles captured into a hipGraph: the graph holds the writes of its tile tables (a capture uploads every piece and vouches
+    for none), so a replay equals the eager step even after another cycle of the same blender - other corners - rewrote the tables in between."""
+    import torch
+    from imagestitch_amd import synth
+    from imagestitch_amd.pipeline import MosaicStitcher
+    K, Rs = synth.camera_ring(640, 360, 1800.0, 24, 0.17)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    imgs = [torch.randint(0, 256, (360, 640, 3), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(24)]
+    p = MosaicStitcher(imgs, K, Rs, 1800.0, "cylindrical", 4, F32, 0, None, "int16")
+    ref = [t.clone() for t in p.step()]
+    assert p.blender.last_path()["cycle"] == "deferred_table"
+    p.capture()
+    out, m = p.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref[0]) and torch.equal(m, ref[1])
+    # another cycle of the same blender, the tiles moved: its tables overwrite the captured step's in device memory
+    corners = [(c[0] + 2 * i, c[1]) for i, c in enumerate(p.corners)]
+    with torch.cuda.stream(p.gstream):
+        p.blender.prepare(corners, p.sizes)
+        for i in range(24):
+            p.blender.feed_u8(p.warped[i], p.seam[i], corners[i])
+        d2, m2 = p.blender.blend(out_f32=True)
+    torch.cuda.synchronize()
+    ob = oracle.MultiBand(4, F32)
+    ob.prepare(corners, p.sizes)
+    for i in range(24):
+        ob.feed(p.warped[i].cpu().numpy().astype(np.int16), p.seam[i].cpu().numpy(), corners[i])
+    od, om = ob.blend(True)
+    assert np.array_equal(d2.cpu().numpy(), od) and np.array_equal(m2.cpu().numpy(), om)
+    out, m = p.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref[0]) and torch.equal(m, ref[1])
+    p.check_plan()

@@ -48,6 +48,7 @@ b s16_tiles_i16 --tile-type s16 --precision i16
 b steps100 --steps 100
 b no_preflight --preflight-ms 0
 ISX_TOP=0 python bench.py --no-cpu-baseline --no-dropin --steps 100 2>/dev/null | line > $O/${TAG}_bench_steps100_ISX_TOP0.json
+ISX_TOP2=0 python bench.py --no-cpu-baseline --no-dropin --steps 100 2>/dev/null | line > $O/${TAG}_bench_steps100_ISX_TOP2_0.json
 python tools/probes/ramp_probe.py > $O/${TAG}_clock_ramp.txt 2>&1
 python tools/probes/fusion_probe.py > $O/${TAG}_n3_fusions.txt 2>&1
 python tools/probes/graph_probe.py > $O/${TAG}_graph_vs_eager.txt 2>&1
@@ -65,7 +66,6 @@ ISX_TAB=0 python bench.py --no-cpu-baseline --no-dropin --tiles 64 --focal 24000
 ISX_TAB=0 python bench.py --no-cpu-baseline --no-dropin --tiles 24 --focal 9000 --yaw 0.12 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_24_ISX_TAB_0.json
 b many_tiles_24 --tiles 24 --focal 9000 --yaw 0.12 --steps 6 --warmup 2
 b many_tiles_64 --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2
-ISX_VERIFY_NEVER=1 python bench.py --no-cpu-baseline --no-dropin --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_64_ISX_VERIFY_NEVER.json
 # 4b. config 5 as ONE panorama in column strips: every rank's share at 2 / 4 / 8 ranks, each alone on this GPU (no gather)
 C5="--kind spherical --tiles 8 --width 7680 --height 4320 --focal 6000 --yaw 0.275 --bands 7 --precision f16acc32 --steps 10 --warmup 3"
 mkdir -p $O/strips

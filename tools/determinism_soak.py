@@ -121,6 +121,27 @@ for prec, name in ((_lib.PREC_F32, "f32"), (_lib.PREC_I16, "i16")):
             bad += not (torch.equal(out, ref[0]) and torch.equal(m, ref[1]))
         res["dropin_%s_%s" % (leg, name)] = {"differing_steps": int(bad), "feed_path": p.blender.feed_path()}
     del p
+# ... a 26-tile panorama: ONE chain over the device-resident tile table (cycle deferred_table), every step against the first and against round 4's
+# column strips of the same panorama (ISX_TAB=0, read per blend)
+K26, R26 = synth.camera_ring(1280, 720, 4000.0, 26, 0.16)
+gen.manual_seed(26)
+t26 = [torch.randint(0, 256, (720, 1280, 3), dtype=torch.uint8, device=dev, generator=gen) for _ in range(26)]
+p = MosaicStitcher(t26, K26, R26, 4000.0, "cylindrical", 5, _lib.PREC_F32, 0, None, "int16")
+os.environ["ISX_TAB"] = "0"
+ref_strips = [t.clone() for t in p.step()]
+path_strips = p.blender.last_path()["cycle"]
+os.environ.pop("ISX_TAB")
+ref = [t.clone() for t in p.step()]
+bad = int(not (torch.equal(ref[0], ref_strips[0]) and torch.equal(ref[1], ref_strips[1])))
+ups = p.blender.table_uploads()
+for _ in range(N // 3):
+    out, m = p.step()
+    torch.cuda.synchronize()
+    bad += not (torch.equal(out, ref[0]) and torch.equal(m, ref[1]))
+p.check_plan()
+res["tile_table_26_tiles"] = {"differing_steps": int(bad), "cycle": p.blender.last_path()["cycle"], "cycle_with_ISX_TAB_0": path_strips,
+                              "table_pieces_uploaded_after_the_first_step": int(p.blender.table_uploads() - ups)}
+del p
 # ... and A13 (the seam walk as chunk maps): seam and panorama of every call against the first
 import ctypes as C  # noqa: E402
 import numpy as np  # noqa: E402
