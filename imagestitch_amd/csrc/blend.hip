@@ -1378,13 +1378,18 @@ struct DevTable {
     std::vector<unsigned> known;            // per TAB_CH chunk: the bytes from its start that the mirror vouches for
     hipStream_t st = nullptr;
     long long uploads = 0;                  // chunks uploaded so far (introspection: the steady state adds none)
-    // `bytes` (a multiple of 16) at offset `off` (a multiple of TAB_CH); *dev = where they lie
-    int put(hipStream_t s, size_t off, const unsigned char* src, size_t bytes, const unsigned char** dev) {
-        const size_t need = off + (bytes + TAB_CH - 1) / TAB_CH * TAB_CH;
-        if (need > buf.cap || s != st) {
-            if (need > buf.cap) ISX_TRY(buf.reserve(std::max(need + need / 2, (size_t)64 * TAB_CH)));      // (hipFree waits for the kernels that read the old table)
+    // room for a whole chain's slots before its first put(): growing in the middle of a chain would work (hipFree waits for the kernels that read
+    // the old table) but stall the chain once per growth
+    int ensure(hipStream_t s, size_t total) {
+        if (total > buf.cap || s != st) {
+            if (total > buf.cap) ISX_TRY(buf.reserve(std::max(total + total / 2, (size_t)64 * TAB_CH)));
             mirror.assign(buf.cap, 0); known.assign(buf.cap / TAB_CH + 1, 0u); st = s;
         }
+        return ISX_OK;
+    }
+    // `bytes` (a multiple of 16) at offset `off` (a multiple of TAB_CH); *dev = where they lie
+    int put(hipStream_t s, size_t off, const unsigned char* src, size_t bytes, const unsigned char** dev) {
+        ISX_TRY(ensure(s, off + (bytes + TAB_CH - 1) / TAB_CH * TAB_CH));
         // A stream that is being captured into a hipGraph: the graph must hold the table's writes itself (a replay may come after another blend of
         // this blender changed the table), and what a capture enqueues has not happened: nothing is skipped and nothing is vouched for afterwards.
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -2310,6 +2315,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         }
     };
     const size_t tab_stride = tab_slot_stride(n, d[0].cols);
+    if (n > DEF_MAX) ISX_TRY(b->tab.ensure(st, (size_t)(2 * L + 2) * tab_stride));
     auto views = [&](int slot, int gshift, int range_cols, TileViews* v) { return make_views(&b->tab, &b->tab_sc, st, slot, tab_stride, td, gshift, range_cols, v); };
     // Column window (see step 3): the columns of every level the window's pixels depend on, need_k, and from them the columns of the
     // tiles' Gaussian levels that have to be PRODUCED: prod_L = need_L, prod_k = need_k widened by what pyrDown reads for prod_{k+1}
