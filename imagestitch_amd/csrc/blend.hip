@@ -154,25 +154,45 @@ __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const 
 // 12-byte records at L.img and its weight in a float plane at L.wgt (inside the same allocation: 12 n + 4 n bytes).  The last collapse
 // step reads the image channels of level 1 only (pyrUp never reads a coarse weight): with 16-byte records it fetched the weights' 4 bytes
 // per pixel for nothing (14.8 MB per 4K pair); pyrDown of level 1 and the level-1 collapse step read both parts, as many bytes as before.
+// Round 5: in OpenCV's int16 arithmetic the dense records are what OpenCV's own levels are - three SHORTS, 6 bytes (every Gaussian level of a
+// CV_16S pyramid and every collapsed level fits a short: pyrDown's weights sum to 256, restoreImageFromLaplacePyr saturates) - instead of the three
+// ints of the register record: the last collapse step and the level-1 step move 6 bytes less per level-1 pixel and source.  A record is read as
+// one 8-byte load at a 2-byte aligned address (two bytes into its neighbour / the weight plane behind the image plane: inside the allocation).
 typedef unsigned u32x3_rec __attribute__((ext_vector_type(3), aligned(4)));
+typedef unsigned u32x2_rec2 __attribute__((ext_vector_type(2), aligned(2)));
+typedef unsigned u32_rec2 __attribute__((aligned(2)));
+template <int M> constexpr unsigned dense_rec() { return M == M_I16 ? 6u : 12u; }
+// where the weight plane of a planar level starts (bytes from L.img): behind the dense image records, dword aligned
+inline __host__ __device__ size_t planar_wgt_offset(int prec, int rows, int cols) {
+    return ((size_t)rows * cols * (prec == M_I16 ? 6u : 12u) + 3u) & ~(size_t)3u;
+}
 template <int M>
 __device__ __forceinline__ Px<M> load_px_planar(const LevelBuf& L, int x, int y) {
     static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
-    const u32x3_rec v = *(const u32x3_rec*)((const char*)L.img + (size_t)i * 12u);
     Px<M> p;
-    if constexpr (M == M_I16) { p.c0 = (int)v.x; p.c1 = (int)v.y; p.c2 = (int)v.z; }
-    else { p.c0 = __uint_as_float(v.x); p.c1 = __uint_as_float(v.y); p.c2 = __uint_as_float(v.z); }
+    if constexpr (M == M_I16) {
+        const u32x2_rec2 v = *(const u32x2_rec2*)((const char*)L.img + (size_t)i * 6u);
+        p.c0 = (int)(short)(v.x & 0xffffu); p.c1 = (int)(short)(v.x >> 16); p.c2 = (int)(short)(v.y & 0xffffu);
+    } else {
+        const u32x3_rec v = *(const u32x3_rec*)((const char*)L.img + (size_t)i * 12u);
+        p.c0 = __uint_as_float(v.x); p.c1 = __uint_as_float(v.y); p.c2 = __uint_as_float(v.z);
+    }
     p.w = L.wgt[i];
     return p;
 }
-// the image channels of a register record as a dense 12-byte record (planar tile levels; out_1 in 12-byte records, OutMat::rec12)
+// the image channels of a register record as a dense record (planar tile levels; out_1 in dense records, OutMat::rec12): 12 bytes, int16: 6
 template <int M>
 __device__ __forceinline__ void store_rgb12(const LevelBuf& L, unsigned i, const Px<M>& p) {
-    u32x3_rec v;
-    if constexpr (M == M_I16) { v.x = (unsigned)p.c0; v.y = (unsigned)p.c1; v.z = (unsigned)p.c2; }
-    else { v.x = __float_as_uint(p.c0); v.y = __float_as_uint(p.c1); v.z = __float_as_uint(p.c2); }
-    *(u32x3_rec*)((char*)L.img + (size_t)i * 12u) = v;
+    if constexpr (M == M_I16) {
+        char* q = (char*)L.img + (size_t)i * 6u;
+        *(u32_rec2*)q = ((unsigned)p.c0 & 0xffffu) | ((unsigned)p.c1 << 16);
+        *(unsigned short*)(q + 4) = (unsigned short)p.c2;
+    } else {
+        u32x3_rec v;
+        v.x = __float_as_uint(p.c0); v.y = __float_as_uint(p.c1); v.z = __float_as_uint(p.c2);
+        *(u32x3_rec*)((char*)L.img + (size_t)i * 12u) = v;
+    }
 }
 template <int M>
 __device__ __forceinline__ void store_px_planar(const LevelBuf& L, int x, int y, const Px<M>& p) {
@@ -2352,7 +2372,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         rec12 = roll_var != 0 && lvl1_by_gather && out12_on;
         g1_planar = roll_var != 0 && lvl1_by_gather && g1p_on && (M == M_F32 || M == M_I16);
     }
-    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + (size_t)g.rows * g.cols * 12u); return g; };
+    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols)); return g; };
     // A pair with three fused top steps: k_collapse_top2 (collapse_top2.inc) rebuilds the tiles' level L itself, out of the one read of level L - 1
     // it makes anyway - the pyrDown launch that produces level L is not issued.  ISX_TOP2=0: k_collapse_top behind that launch (A/B runs).
     bool use_top2 = false;
@@ -2831,7 +2851,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
     static const bool out12_on = [] { const char* e = getenv("ISX_OUT12"); return !(e && e[0] == '0'); }();
     static const bool g1p_on = [] { const char* e = getenv("ISX_G1P"); return !(e && e[0] == '0'); }();
     const bool rec12 = roll_ok && out12_on, g1_planar = roll_ok && g1p_on && (M == M_F32 || M == M_I16);
-    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + (size_t)g.rows * g.cols * 12u); return g; };
+    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols)); return g; };
     // 1. Gaussian chains: one launch per level for every tile of every mosaic
     for (int k = 0; k < L; ++k) {
         TileSet ts = base(k);
@@ -3287,7 +3307,7 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
         const int D0 = std::min(TOP_DMAX, L - 1);
         const bool planar = L >= 2 && (!(top_on0 && D0 >= 2) || L - D0 >= 2) && g1p_on && roll_on && (b->prec == M_F32 || b->prec == M_I16);
         LevelBuf g1 = g[1];
-        if (planar) g1.wgt = (float*)((char*)g1.img + (size_t)g1.rows * g1.cols * 12u);
+        if (planar) g1.wgt = (float*)((char*)g1.img + planar_wgt_offset(b->prec, g1.rows, g1.cols));
         const double bytes = (double)height * width * (src_px_bytes(sk) + 1.0) + (double)g[1].rows * g[1].cols * alg_g(b->prec) + (double)img->rows * img->cols * ((double)ipx + 1.0);
         ISX_TRY(launch_feed_pd0(b->prec, sk, planar, narrow, s0, g1, fc, dim3(nbx, cdiv(g[1].rows, PD_TY)), bytes, b->stream));
         rec.g1 = planar ? 2 : 1;
