@@ -194,6 +194,27 @@ __device__ __forceinline__ void store_rgb12(const LevelBuf& L, unsigned i, const
         *(u32x3_rec*)((char*)L.img + (size_t)i * 12u) = v;
     }
 }
+// A tile level that is planar or not - known only when the kernel runs (L.wgt != nullptr, uniform) - read WITHOUT a branch: the image channels as one
+// 12-byte load at the record's address (a 2-byte aligned address for int16's 6-byte dense records, whose other 6 bytes belong to the neighbour or the
+// plane behind) and the weight as one dword from wherever it lies.  A branch between the two forms, even a uniform one, makes the compiler drain
+// the loads in front of it: the level-1 step waited for eight round trips per round, one after the other (round 5).
+typedef unsigned u32x3_rec2 __attribute__((ext_vector_type(3), aligned(2)));
+template <int M>
+__device__ __forceinline__ Px<M> load_px_tile(const LevelBuf& L, int x, int y) {
+    static_assert(M == M_F32 || M == M_I16, "16-byte register records or their planar form");
+    const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
+    const bool pl = L.wgt != nullptr;
+    const char* ip = (const char*)L.img + (size_t)i * (pl ? dense_rec<M>() : 16u);
+    const float* wp = pl ? L.wgt + i : (const float*)(ip + 12);
+    const u32x3_rec2 v = *(const u32x3_rec2*)ip;
+    Px<M> p;
+    if constexpr (M == M_I16) {
+        const int d0 = (int)(short)(v.x & 0xffffu), d1 = (int)(short)(v.x >> 16), d2 = (int)(short)(v.y & 0xffffu);
+        p.c0 = pl ? d0 : (int)v.x; p.c1 = pl ? d1 : (int)v.y; p.c2 = pl ? d2 : (int)v.z;
+    } else { p.c0 = __uint_as_float(v.x); p.c1 = __uint_as_float(v.y); p.c2 = __uint_as_float(v.z); }
+    p.w = *wp;
+    return p;
+}
 template <int M>
 __device__ __forceinline__ void store_px_planar(const LevelBuf& L, int x, int y, const Px<M>& p) {
     static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
@@ -1170,9 +1191,30 @@ __device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int t
                 }
             }
         }
+        if constexpr (!FINE0) {
+            // The thread's 2 x 2 fine pixels of each tile of the round, loaded with NO branch around them (round 5): a lane that owns no pixel of
+            // the tile - and every lane of a block the tile does not reach - reads the tile's pixels (0..1, 0..1) instead (one cache line per load
+            // for the whole wave) and never uses them.  Behind `if (mine[s])` each tile's eight loads were drained before the next tile's were issued.
+            if (te > tb) {
+#pragma unroll
+                for (int s = 0; s < G; ++s) {
+                    const int t = min(t0 + s, te - 1);
+                    const int fx = mine[s] ? 2 * (lx0[s] + lane) : 0, fy = mine[s] ? 2 * (ly0[s] + wv) : 0;
+                    const LevelBuf fl = ts.fine[t];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        if constexpr (M == M_F32 || M == M_I16) {      // planar level 1 or 16-byte records (block-uniform): one branch-free form
+                            gg[s][dy][0] = load_px_tile<M>(fl, fx, fy + dy); gg[s][dy][1] = load_px_tile<M>(fl, fx + 1, fy + dy);
+                        } else {
+                            gg[s][dy][0] = load_px<M, false>(fl, fx, fy + dy); gg[s][dy][1] = load_px<M, false>(fl, fx + 1, fy + dy);
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < G; ++s)
-            if (!wfast[s] && mine[s]) {   // the thread's 2x2 fine pixels of this tile
+            if (FINE0 && !wfast[s] && mine[s]) {   // the thread's 2x2 level-0 pixels of this tile
                 const int t = t0 + s, lcx = lx0[s] + lane, lcy = ly0[s] + wv;
                 Src0 s0;
                 if constexpr (FINE0) {
@@ -1183,15 +1225,6 @@ __device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int t
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     if constexpr (FINE0) rw[s][dy] = src0_pair_issue<SK>(s0, 2 * lcx, 2 * lcy + dy);
-                    else {
-                        if constexpr (M == M_F32 || M == M_I16) {
-                            if (ts.fine[t].wgt != nullptr) {     // planar level 1 (block-uniform)
-                                gg[s][dy][0] = load_px_planar<M>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px_planar<M>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy);
-                                continue;
-                            }
-                        }
-                        gg[s][dy][0] = load_px<M, false>(ts.fine[t], 2 * lcx, 2 * lcy + dy); gg[s][dy][1] = load_px<M, false>(ts.fine[t], 2 * lcx + 1, 2 * lcy + dy);
-                    }
                 }
             }
         if constexpr (!DMA_T || !DMA_O) {

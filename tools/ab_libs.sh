@@ -9,7 +9,7 @@ for r in $(seq 1 ${REPS:-2}); do
     e=$(python bench.py --no-cpu-baseline --no-dropin --no-live-traffic "$@" 2>/dev/null | grep "^{" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms_one_step']
-print(d['value'], d['ms_per_step'], 'final(serialised)', (k.get('collapse_roll') or k.get('collapse_gather_final') or {}).get('ms'), 'dominant', d['roofline']['kernel'], d['roofline']['avg_launch_ms'], 'warp', (k.get('warp_tile') or k.get('warp_img_mask') or {}).get('ms'), 'pd0', (k.get('pyr_down0') or k.get('pyr_down_l0') or {}).get('ms'), 'pd', (k.get('pyr_down') or {}).get('ms'), 'top', (k.get('collapse_top') or {}).get('ms'))")
+print(d['value'], d['ms_per_step'], 'final(serialised)', (k.get('collapse_roll') or k.get('collapse_gather_final') or {}).get('ms'), 'dominant', d['roofline']['kernel'], d['roofline']['avg_launch_ms'], 'warp', (k.get('warp_tile') or k.get('warp_img_mask') or {}).get('ms'), 'pd0', (k.get('pyr_down0') or k.get('pyr_down_l0') or {}).get('ms'), 'pd', (k.get('pyr_down') or {}).get('ms'), 'mid', (k.get('collapse_gather') or {}).get('ms'), 'top', (k.get('collapse_top') or {}).get('ms'))")
     echo "[$v] $e"
   done
 done
