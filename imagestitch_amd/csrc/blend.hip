@@ -1151,6 +1151,23 @@ __device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int t
         const bool later_round = rnd > 0;
         ++rnd;
         Px<M> sv[G + 1][2];                                // staging registers of whatever is not staged by DMA
+        // register-staged coarse tiles of a level step (fp16 tile levels): no branch around the loads either (see the fine pixels below) - a tile
+        // that does not reach the block, and the threads past the tile's last entry, read one of its pixels that nothing will use
+        constexpr bool SV_FLAT = !DMA_T && !FINE0;
+        if constexpr (SV_FLAT) {
+            if (te > tb) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = min((int)threadIdx.x + 256 * it, NCT - 1);
+                    const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
+#pragma unroll
+                    for (int s = 0; s < G; ++s) {
+                        const int gx = touch[s] ? min(max(lx0[s] - 1 + rx, 0), ccl[s] - 1) : 0, gy = touch[s] ? up_row_map<M>(ly0[s] - 1 + ry, crw[s]) : 0;
+                        sv[s][it] = load_px_rgb<M, false>(ts.coarse[min(t0 + s, te - 1)], gx, gy);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int i = threadIdx.x + 256 * it;
@@ -1158,7 +1175,7 @@ __device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int t
                 const int ry = i / (WAVE + 2), rx = i - ry * (WAVE + 2);
 #pragma unroll
                 for (int s = 0; s < G; ++s)
-                    if (touch[s]) {
+                    if (!SV_FLAT && touch[s]) {
                         const int gx = min(max(lx0[s] - 1 + rx, 0), ccl[s] - 1), gy = up_row_map<M>(ly0[s] - 1 + ry, crw[s]);
                         if constexpr (DMA_T) glds16((const float4*)cimg[s] + (__umul24((unsigned)gy, (unsigned)ccl[s]) + (unsigned)gx), &ct[b0 + s][0][0] + (i - lane));
                         else sv[s][it] = load_px_rgb<M, false>(ts.coarse[t0 + s], gx, gy);
