@@ -100,6 +100,7 @@ _SIGS = {
     "isx_blender_feed_u8": [C.c_void_p, _MP, _MP, C.c_int, C.c_int],
     "isx_blender_result_size": [C.c_void_p, _IP, _IP],
     "isx_blender_last_path": [C.c_void_p, _IP, _IP],
+    "isx_blender_level1_format": [C.c_void_p, _IP],
     "isx_blender_table_uploads": [C.c_void_p, C.POINTER(C.c_longlong)],
     "isx_blender_feed_path": [C.c_void_p, _IP, _IP],
     "isx_blender_blend": [C.c_void_p, _MP, _MP],

@@ -124,6 +124,12 @@ class MultiBandBlender:
         check(self._lib.isx_blender_last_path(self._h, C.byref(c), C.byref(k)))
         return {"cycle": ("eager", "deferred", "deferred_batched", "deferred_strips", "deferred_table")[c.value], "last_step": ("none", "collapse", "collapse_gather", "collapse_roll")[k.value]}
 
+    def level1_format(self):
+        """isx_blender_level1_format: layout of the tiles' level 1 in the last deferred blend() - records | planar | planar_q8."""
+        f = C.c_int()
+        check(self._lib.isx_blender_level1_format(self._h, C.byref(f)))
+        return ("records", "planar", "planar_q8")[f.value]
+
     def table_uploads(self):
         """isx_blender_table_uploads: 3.5 KB pieces of tile tables uploaded so far (cycle deferred_table; a fixed rig uploads once)."""
         n = C.c_longlong()

@@ -162,18 +162,28 @@ typedef unsigned u32x3_rec __attribute__((ext_vector_type(3), aligned(4)));
 typedef unsigned u32x2_rec2 __attribute__((ext_vector_type(2), aligned(2)));
 typedef unsigned u32_rec2 __attribute__((aligned(2)));
 template <int M> constexpr unsigned dense_rec() { return M == M_I16 ? 6u : 12u; }
+// Q8 (round 5, fp32 pyramids over CV_8UC3 tiles): level 1 of such a tile is pyrDown of integers 0..255 - (sum of 25 products with weights that add
+// up to 256) / 256, every step exact in fp32 - so each channel is k / 256 with k <= 65280: the dense record holds the three k as unsigned SHORTS,
+// 6 bytes instead of 12, and the float is rebuilt exactly ((float)k * 2^-8).  Level 1 is written once and read three times per step (pyrDown to
+// level 2, the level-1 collapse step, the last step's pyrUp source): 24 bytes less per level-1 pixel and tile, 89 MB of a 4K pair's 716.  The weight
+// plane stays fp32 (a mask may hold any value / 255).  Chosen by run_blend_deferred_t when the chain itself produces level 1 (ISX_G1Q8=0: off).
 // where the weight plane of a planar level starts (bytes from L.img): behind the dense image records, dword aligned
-inline __host__ __device__ size_t planar_wgt_offset(int prec, int rows, int cols) {
-    return ((size_t)rows * cols * (prec == M_I16 ? 6u : 12u) + 3u) & ~(size_t)3u;
+inline __host__ __device__ size_t planar_wgt_offset(int prec, int rows, int cols, bool q8 = false) {
+    return ((size_t)rows * cols * ((prec == M_I16 || q8) ? 6u : 12u) + 3u) & ~(size_t)3u;
 }
-template <int M>
+__device__ __forceinline__ float q8_f(unsigned k) { return (float)k * (1.f / 256.f); }
+template <int M, bool Q8 = false>
 __device__ __forceinline__ Px<M> load_px_planar(const LevelBuf& L, int x, int y) {
     static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
+    static_assert(!Q8 || M == M_F32, "Q8 records: fp32 pyramids");
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
     Px<M> p;
     if constexpr (M == M_I16) {
         const u32x2_rec2 v = *(const u32x2_rec2*)((const char*)L.img + (size_t)i * 6u);
         p.c0 = (int)(short)(v.x & 0xffffu); p.c1 = (int)(short)(v.x >> 16); p.c2 = (int)(short)(v.y & 0xffffu);
+    } else if constexpr (Q8) {
+        const u32x2_rec2 v = *(const u32x2_rec2*)((const char*)L.img + (size_t)i * 6u);
+        p.c0 = q8_f(v.x & 0xffffu); p.c1 = q8_f(v.x >> 16); p.c2 = q8_f(v.y & 0xffffu);
     } else {
         const u32x3_rec v = *(const u32x3_rec*)((const char*)L.img + (size_t)i * 12u);
         p.c0 = __uint_as_float(v.x); p.c1 = __uint_as_float(v.y); p.c2 = __uint_as_float(v.z);
@@ -182,12 +192,17 @@ __device__ __forceinline__ Px<M> load_px_planar(const LevelBuf& L, int x, int y)
     return p;
 }
 // the image channels of a register record as a dense record (planar tile levels; out_1 in dense records, OutMat::rec12): 12 bytes, int16: 6
-template <int M>
+template <int M, bool Q8 = false>
 __device__ __forceinline__ void store_rgb12(const LevelBuf& L, unsigned i, const Px<M>& p) {
     if constexpr (M == M_I16) {
         char* q = (char*)L.img + (size_t)i * 6u;
         *(u32_rec2*)q = ((unsigned)p.c0 & 0xffffu) | ((unsigned)p.c1 << 16);
         *(unsigned short*)(q + 4) = (unsigned short)p.c2;
+    } else if constexpr (Q8) {      // (exact: see Q8 above)
+        const unsigned k0 = (unsigned)(p.c0 * 256.f), k1 = (unsigned)(p.c1 * 256.f), k2 = (unsigned)(p.c2 * 256.f);
+        char* q = (char*)L.img + (size_t)i * 6u;
+        *(u32_rec2*)q = k0 | (k1 << 16);
+        *(unsigned short*)(q + 4) = (unsigned short)k2;
     } else {
         u32x3_rec v;
         v.x = __float_as_uint(p.c0); v.y = __float_as_uint(p.c1); v.z = __float_as_uint(p.c2);
@@ -200,26 +215,28 @@ __device__ __forceinline__ void store_rgb12(const LevelBuf& L, unsigned i, const
 // the loads in front of it: the level-1 step waited for eight round trips per round, one after the other (round 5).
 typedef unsigned u32x3_rec2 __attribute__((ext_vector_type(3), aligned(2)));
 template <int M>
-__device__ __forceinline__ Px<M> load_px_tile(const LevelBuf& L, int x, int y) {
+__device__ __forceinline__ Px<M> load_px_tile(const LevelBuf& L, int x, int y, bool q8 = false) {      // q8 (uniform): a planar level in Q8 records
     static_assert(M == M_F32 || M == M_I16, "16-byte register records or their planar form");
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
     const bool pl = L.wgt != nullptr;
-    const char* ip = (const char*)L.img + (size_t)i * (pl ? dense_rec<M>() : 16u);
+    const char* ip = (const char*)L.img + (size_t)i * (pl ? (q8 ? 6u : dense_rec<M>()) : 16u);
     const float* wp = pl ? L.wgt + i : (const float*)(ip + 12);
     const u32x3_rec2 v = *(const u32x3_rec2*)ip;
     Px<M> p;
     if constexpr (M == M_I16) {
         const int d0 = (int)(short)(v.x & 0xffffu), d1 = (int)(short)(v.x >> 16), d2 = (int)(short)(v.y & 0xffffu);
         p.c0 = pl ? d0 : (int)v.x; p.c1 = pl ? d1 : (int)v.y; p.c2 = pl ? d2 : (int)v.z;
-    } else { p.c0 = __uint_as_float(v.x); p.c1 = __uint_as_float(v.y); p.c2 = __uint_as_float(v.z); }
+    } else {
+        p.c0 = q8 ? q8_f(v.x & 0xffffu) : __uint_as_float(v.x); p.c1 = q8 ? q8_f(v.x >> 16) : __uint_as_float(v.y); p.c2 = q8 ? q8_f(v.y & 0xffffu) : __uint_as_float(v.z);
+    }
     p.w = *wp;
     return p;
 }
-template <int M>
+template <int M, bool Q8 = false>
 __device__ __forceinline__ void store_px_planar(const LevelBuf& L, int x, int y, const Px<M>& p) {
     static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
-    store_rgb12<M>(L, i, p);
+    store_rgb12<M, Q8>(L, i, p);
     L.wgt[i] = p.w;
 }
 
@@ -403,7 +420,7 @@ constexpr int PD_NR = 2 * PD_TY + 3;
 constexpr int PD_OW = WAVE - 2;
 constexpr int PD_WAVES = 8;
 
-template <int M, bool PLD = false> __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv);
+template <int M, int PLD = 0> __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv);
 
 // pyrDown's row filter at one output column: c = pixel 2x, l1 / r1 = pixels 2x - 1 / 2x + 1, l2 / r2 = pixels 2x - 2 / 2x + 2;
 // tap5's association, the float precisions on (b, g) / (r, w) register pairs (packed fp32, each half rounded on its own)
@@ -429,7 +446,7 @@ __device__ __forceinline__ Px<M> pyr_down_row5(const Px<M>& c, const Px<M>& l1, 
 // The row phase of a block: NR input rows starting at row `row0` of the source level (each through REFLECT_101), row-filtered for the
 // output column `ox` of this lane, into hb[0 .. NR).  (pyr_down_block: NR = NR rows from 2 oy0 - 2; the fused level-0 + level-1 kernel
 // of pyrdown_l0.inc: 41 rows.)
-template <int M, int SK, int NR, bool PLS = false>
+template <int M, int SK, int NR, int PLS = 0>
 __device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& src, int ox, int row0, Px<M> (*hb)[WAVE]) {
     constexpr int RPW = (NR + PD_WAVES - 1) / PD_WAVES;
     const int sw = (SK == SK_LEVEL) ? src.cols : s0.width;
@@ -449,8 +466,8 @@ __device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& sr
                 if (cB == cA + 1) rw[i] = src0_pair_issue<SK>(s0, cA, iy);
                 else rw[i].fast = false;
             } else if constexpr (PLS) {
-                A[i] = load_px_planar<M>(src, cA, iy);
-                B[i] = load_px_planar<M>(src, cB, iy);
+                A[i] = load_px_planar<M, PLS == 2>(src, cA, iy);
+                B[i] = load_px_planar<M, PLS == 2>(src, cB, iy);
             } else {
                 A[i] = load_px<M, false>(src, cA, iy);
                 B[i] = load_px<M, false>(src, cB, iy);
@@ -472,7 +489,7 @@ __device__ __forceinline__ void pyr_down_rows(const Src0& s0, const LevelBuf& sr
     }
 }
 
-template <int M, int SK, bool PLS = false, bool PLD = false>
+template <int M, int SK, int PLS = 0, int PLD = 0>
 __device__ __forceinline__ void pyr_down_block(const Src0& s0, const LevelBuf& src, const LevelBuf& dst, int bx, int by, Px<M> (*hb)[WAVE]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ox = bx * PD_OW + lane - 1, oy0 = by * PD_TY;
@@ -504,7 +521,7 @@ __device__ __forceinline__ Px<M> pyr_down_col5(const Px<M>& r0, const Px<M>& r1,
 }
 
 // the column filter of a block out of the row-filtered rows in LDS (after the block's barrier)
-template <int M, bool PLD>
+template <int M, int PLD>
 __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelBuf& dst, int ox, int oy0, int lane, int wv) {
     const int dw = dst.cols, dh = dst.rows;
     if (lane == 0 || lane == 63 || ox >= dw) return;
@@ -513,7 +530,7 @@ __device__ __forceinline__ void pyr_down_columns(Px<M> (*hb)[WAVE], const LevelB
         int ty = wv + PD_WAVES * i, oy = oy0 + ty;
         if (oy >= dh) break;
         const Px<M> o = pyr_down_col5<M>(hb[2 * ty][lane], hb[2 * ty + 1][lane], hb[2 * ty + 2][lane], hb[2 * ty + 3][lane], hb[2 * ty + 4][lane]);
-        if constexpr (PLD) store_px_planar<M>(dst, ox, oy, o);
+        if constexpr (PLD != 0) store_px_planar<M, PLD == 2>(dst, ox, oy, o);
         else store_px<M, false>(dst, ox, oy, o);
     }
 }
@@ -938,6 +955,7 @@ constexpr int DEF_MAX = 20;     // kernel arguments hold one TileSet: 20 tiles k
 constexpr int DEF_REC_MAX = 4096;   // tiles a deferred cycle records; with more than DEF_MAX of them blend() works in column strips (run_blend_deferred_strips)
 struct TileSet {                 // per-tile views of one pyramid level pair, indexed by the (uniform) tile id
     int n;
+    int q8;                      // the tiles' planar level 1 holds Q8 records (load_px_planar; read by the level-1 collapse step and the last step)
     Src0 s0[DEF_MAX];            // level-0 view (used where the fine / source level is level 0)
     LevelBuf fine[DEF_MAX];      // G_{k-1,t}  (unused when the fine level is level 0)
     LevelBuf coarse[DEF_MAX];    // G_{k,t}
@@ -977,7 +995,7 @@ struct TabField {        // ts.field[t] of a TileTab, by value
     __device__ __forceinline__ T operator[](int t) const { return ld_const<T>(base + (size_t)(unsigned)t * sizeof(TileDesc) + OFF); }
 };
 struct TileTab {
-    int n, gshift, nrng, pad_;
+    int n, gshift, nrng, q8;      // q8: as TileSet::q8
     const int2* rng;         // per 2^gshift fine-level columns: [first, last) tile indices
     TabField<Src0, offsetof(TileDesc, s0)> s0;
     TabField<LevelBuf, offsetof(TileDesc, fine)> fine;
@@ -1003,7 +1021,7 @@ __device__ __forceinline__ void tile_range(const TileTab& ts, int x0, int x1, in
     if (te < tb) te = tb;
 }
 
-// PLS: the source level is PLANAR (level 1 of the deferred cycle, see load_px_planar)
+// PLS: the source level is PLANAR (level 1 of the deferred cycle, see load_px_planar); 2: in Q8 records
 // FeedPub: blend() of a cycle with narrowed tiles (pyrdown_l0.inc) hands their violation words to the host with the FIRST launch of its chain - this
 // one, when level 1 came from feed() - instead of a launch of its own (k_feed_publish: 4 us of a 0.32 ms step); pin == nullptr: nothing to publish
 struct FeedPub { unsigned* state; int n; int* pin; int seq; };
@@ -1017,7 +1035,7 @@ __device__ __forceinline__ void feed_publish_words(const FeedPub& fp) {
     __threadfence_system();
     __hip_atomic_store(&fp.pin[0], fp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-template <int M, int SK, bool PLS, class TS>
+template <int M, int SK, int PLS, class TS>
 __device__ __forceinline__ void pyr_down_multi_body(const TS& ts, const FeedPub& fp) {
     if (fp.pin != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feed_publish_words(fp);
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
@@ -1027,9 +1045,9 @@ __device__ __forceinline__ void pyr_down_multi_body(const TS& ts, const FeedPub&
     __shared__ Px<M> hb[PD_NR][WAVE];
     pyr_down_block<M, SK, PLS>(ts.s0[t], ts.fine[t], dst, blockIdx.x, blockIdx.y, hb);
 }
-template <int M, int SK, bool PLS = false>
+template <int M, int SK, int PLS = 0>
 __global__ __launch_bounds__(512) void k_pyr_down_multi(TileSet ts, FeedPub fp) { pyr_down_multi_body<M, SK, PLS>(ts, fp); }
-template <int M, int SK, bool PLS = false>
+template <int M, int SK, int PLS = 0>
 __global__ __launch_bounds__(512) void k_pyr_down_multi_tab(TileTab ts, FeedPub fp) { pyr_down_multi_body<M, SK, PLS>(ts, fp); }
 
 // top level of the pyramid: out_L = norm(SUM_t cast(G_{L,t} * W_{L,t})) at level-L pixel (x, y); the tile rectangles of
@@ -1221,7 +1239,7 @@ __device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int t
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy) {
                         if constexpr (M == M_F32 || M == M_I16) {      // planar level 1 or 16-byte records (block-uniform): one branch-free form
-                            gg[s][dy][0] = load_px_tile<M>(fl, fx, fy + dy); gg[s][dy][1] = load_px_tile<M>(fl, fx + 1, fy + dy);
+                            gg[s][dy][0] = load_px_tile<M>(fl, fx, fy + dy, ts.q8 != 0); gg[s][dy][1] = load_px_tile<M>(fl, fx + 1, fy + dy, ts.q8 != 0);
                         } else {
                             gg[s][dy][0] = load_px<M, false>(fl, fx, fy + dy); gg[s][dy][1] = load_px<M, false>(fl, fx + 1, fy + dy);
                         }
@@ -1429,7 +1447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M 
 #include "collapse_top2.inc"
 
 template <int M, int SK>
-int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar = false);
+int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, int planar = 0);
 
 // ---- host side of the tile tables (TileTab / TopTab) ---------------------------------------------------------------------------------------
 // DevTable: a device buffer that mirrors host-built tables.  Uploads travel in KERNEL ARGUMENTS (k_tab_write: 3.5 KB per launch) - in stream
@@ -1543,12 +1561,16 @@ inline int make_views(DevTable* tab, TabScratch* sc, hipStream_t st, int slot, s
 // level 0 -> 1 of every recorded tile: CV_8UC3 and CV_16SC3 tiles through k_pyr_down0 (ISX_PD0=0: the general kernel, for A/B runs)
 // planar: level 1 is written as 12-byte image records + a weight plane (ts.coarse[t].wgt set by the caller; k_pyr_down0 only)
 template <int M, int SK>
-int launch_pyr_down0(const TileViews& v, dim3 grid, double bytes, hipStream_t st, bool planar = false) {
+int launch_pyr_down0(const TileViews& v, dim3 grid, double bytes, hipStream_t st, int planar = 0) {      // planar: 0 records, 1 planar, 2 planar in Q8 records
     if (!v.tab) return launch_pyr_down0<M, SK>(v.ts, grid, bytes, st, planar);
     static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
     if constexpr (SK == SK_U8 || SK == SK_S16) {
+        if constexpr (M == M_F32 && SK == SK_U8) {
+            if (planar == 2) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0_tab<M, SK, 2>), grid, dim3(512), 0, v.tt); return ISX_OK; }
+        }
+        ISX_CHECK_ARG(planar != 2, ISX_ERR_INTERNAL, "pyr_down0: Q8 records asked of a kernel that has none");
         if constexpr (M == M_F32 || M == M_I16) {
-            if (planar) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0_tab<M, SK, true>), grid, dim3(512), 0, v.tt); return ISX_OK; }
+            if (planar) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0_tab<M, SK, 1>), grid, dim3(512), 0, v.tt); return ISX_OK; }
         }
         if (fast) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0_tab<M, SK>), grid, dim3(512), 0, v.tt); return ISX_OK; }
     }
@@ -1556,11 +1578,15 @@ int launch_pyr_down0(const TileViews& v, dim3 grid, double bytes, hipStream_t st
     return ISX_OK;
 }
 template <int M, int SK>
-int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, bool planar) {
+int launch_pyr_down0(const TileSet& ts, dim3 grid, double bytes, hipStream_t st, int planar) {
     static const bool fast = [] { const char* e = getenv("ISX_PD0"); return !(e && e[0] == '0'); }();
     if constexpr (SK == SK_U8 || SK == SK_S16) {
+        if constexpr (M == M_F32 && SK == SK_U8) {
+            if (planar == 2) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK, 2>), grid, dim3(512), 0, ts); return ISX_OK; }
+        }
+        ISX_CHECK_ARG(planar != 2, ISX_ERR_INTERNAL, "pyr_down0: Q8 records asked of a kernel that has none");
         if constexpr (M == M_F32 || M == M_I16) {
-            if (planar) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK, true>), grid, dim3(512), 0, ts); return ISX_OK; }
+            if (planar) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK, 1>), grid, dim3(512), 0, ts); return ISX_OK; }
         }
         if (fast) { ISX_LAUNCH("pyr_down0", bytes, st, (k_pyr_down0<M, SK>), grid, dim3(512), 0, ts); return ISX_OK; }
     }
@@ -1917,7 +1943,7 @@ struct isx_blender {
     // which code path the last blend() took (isx_blender_last_path): the fast kernels have limits, and a caller / a bench line should be
     // able to say which side of them it ran on.  cycle: 0 eager, 1 deferred, 2 deferred as part of a batched chain; last: the kernel of
     // the last collapse step - 0 none (a 0-band blend, Feather, NO), 1 k_collapse, 2 k_collapse_gather, 3 k_collapse_roll
-    int path_cycle = 0, path_last = 0;
+    int path_cycle = 0, path_last = 0, path_g1 = 0;      // path_g1: layout of the tiles' level 1 in the last blend (isx_blender_level1_format)
     int path_fused = 0, path_narrow = 0;   // isx_blender_feed_path: tiles of the last blend() that came through k_feed_pd0; 0 none narrowed, 1 narrowed copies confirmed, 2 widened
     std::vector<hipStream_t> side;
     std::vector<hipEvent_t> ev_ready, ev_done;
@@ -2422,7 +2448,18 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         rec12 = roll_var != 0 && lvl1_by_gather && out12_on;
         g1_planar = roll_var != 0 && lvl1_by_gather && g1p_on && (M == M_F32 || M == M_I16);
     }
-    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols)); return g; };
+    // Level 1 in Q8 records (load_px_planar): fp32 pyramids over CV_8UC3 tiles whose level 1 THIS chain produces (tiles that came through the
+    // fused feed hold a level 1 written by feed(), narrowed copies may turn out to be CV_16SC3 tiles after all: both keep the 12-byte records)
+    bool g1_q8 = false;
+    if constexpr (M == M_F32 && SK == SK_U8) {
+        static const bool q8_on = [] { const char* e = getenv("ISX_G1Q8"); return !(e && e[0] == '0'); }();
+        bool side = b->chain_on_side.size() >= (size_t)n;       // (chains launched by feed() wrote 16-byte records: all_on_side below)
+        for (int t = 0; t < n && side; ++t) side = b->chain_on_side[t] != 0;
+        g1_q8 = g1_planar && q8_on && !b->narrow_pending && !side;
+        for (int t = 0; t < n && g1_q8; ++t) g1_q8 = b->tiles[t].g1 == 0 && b->tiles[t].fed_sk == SK_U8;
+    }
+    const double g1_b = g1_q8 ? 10.0 : alg_g(prec), g1_rgb_b = g1_q8 ? 6.0 : alg_g_rgb(prec);      // algorithmic bytes of a level-1 record / its image channels
+    auto planar_of = [g1_q8](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols, g1_q8)); return g; };
     // A pair with three fused top steps: k_collapse_top2 (collapse_top2.inc) rebuilds the tiles' level L itself, out of the one read of level L - 1
     // it makes anyway - the pyrDown launch that produces level L is not issued.  ISX_TOP2=0: k_collapse_top behind that launch (A/B runs).
     bool use_top2 = false;
@@ -2437,6 +2474,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     bool all_on_side = b->chain_on_side.size() >= (size_t)n;
     for (int t = 0; t < n && all_on_side; ++t) all_on_side = b->chain_on_side[t] != 0;
     if (all_on_side) { ISX_TRY(join_side_streams(b)); g1_planar = false; }     // (chains launched by feed() wrote 16-byte records)
+    b->path_g1 = g1_planar ? (g1_q8 ? 2 : 1) : 0;
     // Level 1 of tiles that came through the fused feed (k_feed_pd0) exists already, in the layout feed() expected this chain to want; when every
     // tile has it, whole and in that layout, the level-0 launch is skipped.  Otherwise level 1 is produced here from the private copies - whose type
     // must be known for that: the narrowed copies are confirmed first (a widened cycle re-enters as a cycle of CV_16SC3 tiles).
@@ -2472,7 +2510,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
                 e.bx_lo = c1 > c0 ? c0 / PD_OW : 0; e.bx_hi = c1 > c0 ? cdiv(c1, PD_OW) : 0;
                 share = (double)(e.bx_hi - e.bx_lo) / nbx;
             }
-            bytes += share * ((double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec));
+            bytes += share * ((double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : (k == 1 ? g1_b : alg_g(prec))) + (double)r.g[k + 1].rows * r.g[k + 1].cols * (k == 0 ? g1_b : alg_g(prec)));
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
         if ((ISX_TAIL_ABL & 1) && k >= 2) grid = dim3(1, 1, n);
@@ -2484,7 +2522,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         TileViews v;
         ISX_TRY(views(k, 0, 0, &v));
         if (k == 0) {
-            ISX_TRY((launch_pyr_down0<M, SK>(v, grid, bytes, st, g1_planar)));
+            ISX_TRY((launch_pyr_down0<M, SK>(v, grid, bytes, st, g1_planar ? (g1_q8 ? 2 : 1) : 0)));
             // Level 1 of these tiles now holds what THIS chain wants, on the columns this chain needs.  A tile whose level 1 came from feed() (g1 = 1 / 2)
             // no longer has it whole in that layout when only a window's columns were rewritten (3 = fused-fed, level 1 to be produced again): a later
             // column strip of the same cycle that shares the tile (run_blend_deferred_strips) must not take it for done.  (Found by the fuzzer in round 5:
@@ -2498,10 +2536,15 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
                 fp = FeedPub{(unsigned*)b->feed_state.p, n, b->feed_pin, ++b->feed_seq};
                 b->narrow_published = true;
             }
-            if (k == 1 && g1_planar) {
+            if (k == 1 && g1_q8) {
+                if constexpr (M == M_F32) {
+                    if (v.tab) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi_tab<M, SK_LEVEL, 2>), grid, dim3(512), 0, v.tt, fp);
+                    else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, 2>), grid, dim3(512), 0, v.ts, fp);
+                }
+            } else if (k == 1 && g1_planar) {
                 if constexpr (M == M_F32 || M == M_I16) {
-                    if (v.tab) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi_tab<M, SK_LEVEL, true>), grid, dim3(512), 0, v.tt, fp);
-                    else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, v.ts, fp);
+                    if (v.tab) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi_tab<M, SK_LEVEL, 1>), grid, dim3(512), 0, v.tt, fp);
+                    else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, 1>), grid, dim3(512), 0, v.ts, fp);
                 }
             } else if (v.tab) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi_tab<M, SK_LEVEL>), grid, dim3(512), 0, v.tt, fp);
             else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, v.ts, fp);
@@ -2600,13 +2643,14 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             if (g1_planar && k == 2) e.fine = planar_of(r.g[1]);
             if (g1_planar && k == 1) e.coarse = planar_of(r.g[1]);
             if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;                        // + the weights of G_L
-            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? src_px_bytes(SKL) + 1.0 : alg_g(prec))   // G_{k-1,t} (level 0: the tile + mask)
-                   + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);                        // G_{k,t} as pyrUp source
+            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? src_px_bytes(SKL) + 1.0 : (k == 2 ? g1_b : alg_g(prec)))   // G_{k-1,t} (level 0: the tile + mask)
+                   + (double)r.g[k].rows * r.g[k].cols * (k == 1 ? g1_rgb_b : alg_g_rgb(prec));         // G_{k,t} as pyrUp source
         }
         dim3 grid(bx_hi - bx_lo, cdiv(d[k].rows, UP_TY));
         // (index ranges per 128 columns of the step's fine level = one block of k_collapse_gather; a strip of k_collapse_roll spans two)
         TileViews v;
         ISX_TRY(views(L + 1 + k, 7, d[k - 1].cols, &v));
+        v.ts.q8 = v.tt.q8 = (g1_q8 && k <= 2) ? 1 : 0;      // k = 2 reads level 1 as its fine level, k = 1 as its pyrUp source
         OutMat o = out;
         o.bx0 = bx_lo;
         o.rec12 = (rec12 && k <= 2) ? 1 : 0;      // k = 2 writes out_1, k = 1 reads it
@@ -3558,6 +3602,12 @@ int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) ISX_ENTRY 
     if (last_step) *last_step = b->type == ISX_BLEND_MULTI_BAND ? b->path_last : 0;
     return ISX_OK;
 } ISX_EXIT("isx_blender_last_path")
+
+int isx_blender_level1_format(isx_blender* b, int* format) ISX_ENTRY {
+    ISX_CHECK_ARG(b != nullptr && format != nullptr, ISX_ERR_INVALID, "isx_blender_level1_format: null argument");
+    *format = (b->type == ISX_BLEND_MULTI_BAND && b->path_cycle != 0 && b->path_cycle != 2) ? b->path_g1 : 0;
+    return ISX_OK;
+} ISX_EXIT("isx_blender_level1_format")
 
 int isx_blender_table_uploads(isx_blender* b, long long* pieces) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr && pieces != nullptr, ISX_ERR_INVALID, "isx_blender_table_uploads: null argument");

@@ -282,6 +282,10 @@ int isx_blender_result_size(isx_blender* b, int* width, int* height);
  * tiles in a device-resident table (more than 20 recorded tiles: one chain over all of them); last_step: the kernel of the last collapse step -
  * 0 none (a 0-band blend), 1 k_collapse, 2 k_collapse_gather, 3 k_collapse_roll.  Either pointer may be NULL.                    */
 int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step);
+/* Layout of level 1 of the tiles' Gaussian pyramids in the last deferred isx_blender_blend (an internal buffer; reported because the step's
+ * byte count depends on it): 0 = 16-byte records, 1 = planar (12-byte image records, int16: 6, + a weight plane), 2 = planar with the image
+ * channels as three unsigned shorts (fp32 pyramids over CV_8UC3 tiles: level 1 is k / 256 exactly, DESIGN.md §3 "Round 5").               */
+int isx_blender_level1_format(isx_blender* b, int* format);
 /* Introspection of cycle 4: how many 3.5 KB pieces of tile tables this blender has uploaded so far.  They travel in kernel arguments, in
  * stream order, and only where they differ from what the device holds: a fixed rig uploads on its first blend() and never again.      */
 int isx_blender_table_uploads(isx_blender* b, long long* pieces);

@@ -1,6 +1,7 @@
 """Prints one sha256 per blend of a fixed set of deferred multi-band cycles (single and batched, the three precisions, CV_8UC3 and
 CV_16SC3 tiles, 2 / 5 / 7 bands, a column window).  tests/test_gpu_level1_formats.py runs it twice - with the library's defaults and with
-ISX_OUT12=0 ISX_G1P=0 (level 1 in 16-byte records, the layout before round 4's last change) - and compares the lines."""
+ISX_OUT12=0 ISX_G1P=0 (level 1 in 16-byte records, the layout before round 4's last change; ISX_G1Q8=0: planar level 1 without round 5's
+Q8 records) - and compares the lines.  The `fmt` lines say which layout each single blend ran with."""
 import hashlib
 import os
 import sys
@@ -52,6 +53,7 @@ for prec in (0, 1, 2):
                 d, m = mb.blend(out_f32=(prec != 0))
                 lp = mb.last_path()
                 print("single", prec, int(s16), bands, ri, lp["cycle"], lp["last_step"], digest(d, m))
+                print("fmt", prec, int(s16), bands, ri, mb.level1_format())
     # the batched chain: three mosaics of one rig shape
     bl, ds, ms, keep = [], [], [], []
     for q in range(3):
