@@ -1910,7 +1910,7 @@ struct isx_blender {
     std::vector<int4> fed;
     bool cleared = false;
     // deferred level 0: tiles recorded by feed(), consumed by blend()
-    // fused feed (k_feed_pd0, deferred mode 2): g1 = 0 level 1 not produced yet, 1 produced by feed() as 16-byte records, 2 produced PLANAR, 3 produced by
+    // fused feed (k_feed_pd0, deferred mode 2): g1 = 0 level 1 not produced yet, 1 produced by feed() as 16-byte records, 2 produced PLANAR, 4 PLANAR in Q8 records, 3 produced by
     // feed() but since rewritten on a window's columns in another layout (to be produced again);
     // narrow != 0: a CV_16SC3 tile whose private copy was written as CV_8UC3 (sk = SK_U8, fed_sk = SK_S16) with escape segments in `wide`
     struct TileRec { Src0 s0; int sk; LevelBuf g[MAX_LEVELS]; int x_tl, y_tl, width, height;
@@ -2018,7 +2018,7 @@ double covered_px(const isx_blender* b, int x, int y, int w, int h) {
 }
 
 // k_feed_pd0 / k_feed_strip for (precision, tile type, level-1 layout, copy format)
-template <int M, int SK, bool PLD, int CF>
+template <int M, int SK, int PLD, int CF>
 int launch_feed_pd0_v(const Src0& s0, const LevelBuf& g1, FeedCopy fc, dim3 grid, double bytes, hipStream_t st) {
     // single-wave strips for the whole level (k_feed_strip) unless the tile is too small for its window scheme; ISX_FEED_STRIP=0: the block kernel
     // (A/B runs), 4: four output rows per strip instead of two
@@ -2035,21 +2035,30 @@ int launch_feed_pd0_v(const Src0& s0, const LevelBuf& g1, FeedCopy fc, dim3 grid
     return ISX_OK;
 }
 template <int M, int SK>
-int launch_feed_pd0_t(bool planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
+int launch_feed_pd0_t(int planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
+    // planar = 2: level 1 in Q8 records (load_px_planar) - fp32 pyramids over CV_8UC3 tiles and over CV_16SC3 tiles that are being narrowed (if those
+    // turn out not to be bytes the cycle is widened and its level 1 produced again, run_blend_deferred_t)
+    ISX_CHECK_ARG(planar != 2 || (M == M_F32 && (SK == SK_U8 || narrow)), ISX_ERR_INTERNAL, "feed: Q8 records asked of a kernel that has none");
     if constexpr (SK == SK_S16) {
         if (narrow) {
-            if constexpr (M == M_F32 || M == M_I16) {
-                if (planar) return launch_feed_pd0_v<M, SK, true, CF_NARROW>(s0, g1, fc, grid, bytes, st);
+            if constexpr (M == M_F32) {
+                if (planar == 2) return launch_feed_pd0_v<M, SK, 2, CF_NARROW>(s0, g1, fc, grid, bytes, st);
             }
-            return launch_feed_pd0_v<M, SK, false, CF_NARROW>(s0, g1, fc, grid, bytes, st);
+            if constexpr (M == M_F32 || M == M_I16) {
+                if (planar) return launch_feed_pd0_v<M, SK, 1, CF_NARROW>(s0, g1, fc, grid, bytes, st);
+            }
+            return launch_feed_pd0_v<M, SK, 0, CF_NARROW>(s0, g1, fc, grid, bytes, st);
         }
     }
-    if constexpr (M == M_F32 || M == M_I16) {
-        if (planar) return launch_feed_pd0_v<M, SK, true, CF_SAME>(s0, g1, fc, grid, bytes, st);
+    if constexpr (M == M_F32 && SK == SK_U8) {
+        if (planar == 2) return launch_feed_pd0_v<M, SK, 2, CF_SAME>(s0, g1, fc, grid, bytes, st);
     }
-    return launch_feed_pd0_v<M, SK, false, CF_SAME>(s0, g1, fc, grid, bytes, st);
+    if constexpr (M == M_F32 || M == M_I16) {
+        if (planar) return launch_feed_pd0_v<M, SK, 1, CF_SAME>(s0, g1, fc, grid, bytes, st);
+    }
+    return launch_feed_pd0_v<M, SK, 0, CF_SAME>(s0, g1, fc, grid, bytes, st);
 }
-int launch_feed_pd0(int prec, int sk, bool planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
+int launch_feed_pd0(int prec, int sk, int planar, bool narrow, const Src0& s0, const LevelBuf& g1, const FeedCopy& fc, dim3 grid, double bytes, hipStream_t st) {
     switch (prec) {
         case M_I16: return sk == SK_U8 ? launch_feed_pd0_t<M_I16, SK_U8>(planar, narrow, s0, g1, fc, grid, bytes, st) : launch_feed_pd0_t<M_I16, SK_S16>(planar, narrow, s0, g1, fc, grid, bytes, st);
         case M_F32: return sk == SK_U8 ? launch_feed_pd0_t<M_F32, SK_U8>(planar, narrow, s0, g1, fc, grid, bytes, st) : launch_feed_pd0_t<M_F32, SK_S16>(planar, narrow, s0, g1, fc, grid, bytes, st);
@@ -2448,15 +2457,18 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         rec12 = roll_var != 0 && lvl1_by_gather && out12_on;
         g1_planar = roll_var != 0 && lvl1_by_gather && g1p_on && (M == M_F32 || M == M_I16);
     }
-    // Level 1 in Q8 records (load_px_planar): fp32 pyramids over CV_8UC3 tiles whose level 1 THIS chain produces (tiles that came through the
-    // fused feed hold a level 1 written by feed(), narrowed copies may turn out to be CV_16SC3 tiles after all: both keep the 12-byte records)
+    // Level 1 in Q8 records (load_px_planar): fp32 pyramids over tiles of bytes - the caller's CV_8UC3 tiles, their private copies, narrowed copies of
+    // CV_16SC3 tiles (if those turn out not to be bytes the cycle is widened: level 1 is produced again, see narrow_resolve's callers below)
     bool g1_q8 = false;
     if constexpr (M == M_F32 && SK == SK_U8) {
         static const bool q8_on = [] { const char* e = getenv("ISX_G1Q8"); return !(e && e[0] == '0'); }();
         bool side = b->chain_on_side.size() >= (size_t)n;       // (chains launched by feed() wrote 16-byte records: all_on_side below)
         for (int t = 0; t < n && side; ++t) side = b->chain_on_side[t] != 0;
-        g1_q8 = g1_planar && q8_on && !b->narrow_pending && !side;
-        for (int t = 0; t < n && g1_q8; ++t) g1_q8 = b->tiles[t].g1 == 0 && b->tiles[t].fed_sk == SK_U8;
+        g1_q8 = g1_planar && q8_on && !side;
+        for (int t = 0; t < n && g1_q8; ++t) {      // (SK_U8: the caller's CV_8UC3 tiles, private CV_8UC3 copies, narrowed copies of CV_16SC3 tiles)
+            const int s = b->tiles[t].g1;
+            g1_q8 = s == 0 || s == 3 || s == 4;      // a level 1 that feed() wrote in another layout keeps that layout
+        }
     }
     const double g1_b = g1_q8 ? 10.0 : alg_g(prec), g1_rgb_b = g1_q8 ? 6.0 : alg_g_rgb(prec);      // algorithmic bytes of a level-1 record / its image channels
     auto planar_of = [g1_q8](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols, g1_q8)); return g; };
@@ -2479,7 +2491,8 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
     // tile has it, whole and in that layout, the level-0 launch is skipped.  Otherwise level 1 is produced here from the private copies - whose type
     // must be known for that: the narrowed copies are confirmed first (a widened cycle re-enters as a cycle of CV_16SC3 tiles).
     bool g1_done = true;
-    for (int t = 0; t < n; ++t) g1_done = g1_done && b->tiles[t].g1 == (g1_planar ? 2 : 1);
+    const int g1_state = g1_planar ? (g1_q8 ? 4 : 2) : 1;
+    for (int t = 0; t < n; ++t) g1_done = g1_done && b->tiles[t].g1 == g1_state;
     if (b->narrow_pending) {
         if (!(g1_done && L >= 2 && !all_on_side)) ISX_TRY(narrow_publish(b));      // (otherwise the level 1 -> 2 pyrDown below carries the words)
         if (!g1_done) {
@@ -2529,7 +2542,7 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             // 35 tiles, two bands, a strip with more than three tiles over one place took k_collapse_gather and 16-byte records, its neighbour read the
             // shared tile's planar level 1 behind it.)
             for (int t = 0; t < n; ++t)
-                if (b->tiles[t].g1 != 0) b->tiles[t].g1 = windowed ? 3 : (g1_planar ? 2 : 1);
+                if (b->tiles[t].g1 != 0) b->tiles[t].g1 = windowed ? 3 : g1_state;
         } else {
             FeedPub fp{nullptr, 0, nullptr, 0};
             if (b->narrow_pending && !b->narrow_published) {      // the violation words ride on this launch (the first of the chain: level 1 came from feed())
@@ -2697,6 +2710,10 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
             ISX_TRY(narrow_resolve(b, &widened));
             if constexpr (SK == SK_U8) {
                 if (widened) {      // (the roll variant was chosen on the tiles' geometry, which widening does not change)
+                    if (g1_q8) {        // the chain above read a level 1 in Q8 records that feed() wrote from shorts that were not bytes: all of it again
+                        for (int t = 0; t < n; ++t) if (b->tiles[t].g1 != 0) b->tiles[t].g1 = 3;
+                        return run_blend_deferred_t<M, SK_S16>(b, out);
+                    }
                     if (roll_var != 0) {
                         bool ok = true;
                         for (int t = 0; t < n; ++t) ok = ok && b->tiles[t].s0.iend != 0u;
@@ -2945,7 +2962,16 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
     static const bool out12_on = [] { const char* e = getenv("ISX_OUT12"); return !(e && e[0] == '0'); }();
     static const bool g1p_on = [] { const char* e = getenv("ISX_G1P"); return !(e && e[0] == '0'); }();
     const bool rec12 = roll_ok && out12_on, g1_planar = roll_ok && g1p_on && (M == M_F32 || M == M_I16);
-    auto planar_of = [](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols)); return g; };
+    bool g1_q8 = false;      // level 1 in Q8 records, as in run_blend_deferred_t
+    if constexpr (M == M_F32 && SK == SK_U8) {
+        static const bool q8_on = [] { const char* e = getenv("ISX_G1Q8"); return !(e && e[0] == '0'); }();
+        g1_q8 = g1_planar && q8_on;
+        for (int m = 0; m < nb && g1_q8; ++m) g1_q8 = !bs[m]->narrow_pending;
+        for (int t = 0; t < nt && g1_q8; ++t) g1_q8 = tile_rec(t).g1 == 0 && tile_rec(t).fed_sk == SK_U8;
+    }
+    for (int m = 0; m < nb; ++m) bs[m]->path_g1 = g1_planar ? (g1_q8 ? 2 : 1) : 0;
+    const double g1_b = g1_q8 ? 10.0 : alg_g(prec), g1_rgb_b = g1_q8 ? 6.0 : alg_g_rgb(prec);
+    auto planar_of = [g1_q8](LevelBuf g) { g.wgt = (float*)((char*)g.img + planar_wgt_offset(M, g.rows, g.cols, g1_q8)); return g; };
     // 1. Gaussian chains: one launch per level for every tile of every mosaic
     for (int k = 0; k < L; ++k) {
         TileSet ts = base(k);
@@ -2957,12 +2983,14 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
             if (g1_planar && k == 0) ts.coarse[t] = planar_of(r.g[1]);
             if (g1_planar && k == 1) ts.fine[t] = planar_of(r.g[1]);
             maxc = std::max(maxc, r.g[k + 1].cols); maxr = std::max(maxr, r.g[k + 1].rows);
-            bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : alg_g(prec)) + (double)r.g[k + 1].rows * r.g[k + 1].cols * alg_g(prec);
+            bytes += (double)r.g[k].rows * r.g[k].cols * (k == 0 ? gin0 : (k == 1 ? g1_b : alg_g(prec))) + (double)r.g[k + 1].rows * r.g[k + 1].cols * (k == 0 ? g1_b : alg_g(prec));
         }
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), nt);
-        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar)));
-        else if (k == 1 && g1_planar) {
-            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, true>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
+        if (k == 0) ISX_TRY((launch_pyr_down0<M, SK>(ts, grid, bytes, st, g1_planar ? (g1_q8 ? 2 : 1) : 0)));
+        else if (k == 1 && g1_q8) {
+            if constexpr (M == M_F32) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, 2>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
+        } else if (k == 1 && g1_planar) {
+            if constexpr (M == M_F32 || M == M_I16) ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL, 1>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
         } else ISX_LAUNCH("pyr_down", bytes, st, (k_pyr_down_multi<M, SK_LEVEL>), grid, dim3(512), 0, ts, FeedPub{nullptr, 0, nullptr, 0});
         for (int m = 0; m < nb; ++m)
             if (k == bs[m]->mark_level && bs[m]->mark_event) ISX_HIP(hipEventRecord(bs[m]->mark_event, st));
@@ -2970,6 +2998,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
     // 2. collapse chain, the mosaic as grid.z
     for (int k = L; k >= 1; --k) {
         TileSet ts = base(k - 1);
+        ts.q8 = (g1_q8 && k <= 2) ? 1 : 0;
         BatchOut bo;
         memset(&bo, 0, sizeof(bo));
         std::copy(first, first + nb + 1, bo.first);
@@ -2981,7 +3010,7 @@ int run_blend_batch_t(isx_blender** bs, int nb, const OutMat* outs) {
             if (g1_planar && k == 2) ts.fine[t] = planar_of(r.g[1]);
             if (g1_planar && k == 1) ts.coarse[t] = planar_of(r.g[1]);
             if (k == L) bytes += (double)r.g[k].rows * r.g[k].cols * 4.0;
-            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : alg_g(prec)) + (double)r.g[k].rows * r.g[k].cols * alg_g_rgb(prec);
+            bytes += (double)r.g[k - 1].rows * r.g[k - 1].cols * (k == 1 ? gin0 : (k == 2 ? g1_b : alg_g(prec))) + (double)r.g[k].rows * r.g[k].cols * (k == 1 ? g1_rgb_b : alg_g_rgb(prec));
         }
         for (int m = 0; m < nb; ++m) {
             bo.coarse_out[m] = d[m][k]; bo.fine_out[m] = d[m][k - 1]; bo.out[m] = outs[m];
@@ -3400,11 +3429,15 @@ int do_feed(isx_blender* b, const isx_mat* img, const isx_mat* mask, int tl_x, i
         static const bool roll_on = [] { const char* e = getenv("ISX_ROLL"); return !(e && atoi(e) == 0); }();
         const int D0 = std::min(TOP_DMAX, L - 1);
         const bool planar = L >= 2 && (!(top_on0 && D0 >= 2) || L - D0 >= 2) && g1p_on && roll_on && (b->prec == M_F32 || b->prec == M_I16);
+        // ... in Q8 records (load_px_planar) where the tile is bytes: CV_8UC3, or CV_16SC3 being narrowed (a violated cycle is widened and produces
+        // its level 1 again)
+        static const bool q8_on = [] { const char* e = getenv("ISX_G1Q8"); return !(e && e[0] == '0'); }();
+        const bool q8 = planar && q8_on && b->prec == M_F32 && (sk == SK_U8 || narrow);
         LevelBuf g1 = g[1];
-        if (planar) g1.wgt = (float*)((char*)g1.img + planar_wgt_offset(b->prec, g1.rows, g1.cols));
-        const double bytes = (double)height * width * (src_px_bytes(sk) + 1.0) + (double)g[1].rows * g[1].cols * alg_g(b->prec) + (double)img->rows * img->cols * ((double)ipx + 1.0);
-        ISX_TRY(launch_feed_pd0(b->prec, sk, planar, narrow, s0, g1, fc, dim3(nbx, cdiv(g[1].rows, PD_TY)), bytes, b->stream));
-        rec.g1 = planar ? 2 : 1;
+        if (planar) g1.wgt = (float*)((char*)g1.img + planar_wgt_offset(b->prec, g1.rows, g1.cols, q8));
+        const double bytes = (double)height * width * (src_px_bytes(sk) + 1.0) + (double)g[1].rows * g[1].cols * (q8 ? 10.0 : alg_g(b->prec)) + (double)img->rows * img->cols * ((double)ipx + 1.0);
+        ISX_TRY(launch_feed_pd0(b->prec, sk, planar ? (q8 ? 2 : 1) : 0, narrow, s0, g1, fc, dim3(nbx, cdiv(g[1].rows, PD_TY)), bytes, b->stream));
+        rec.g1 = planar ? (q8 ? 4 : 2) : 1;
         rec.sk = narrow ? SK_U8 : sk;
         s0 = src0_of(fc.cimg, ipitch, narrow ? ISX_8UC3 : img->type, fc.cmask, mpitch);
         if (narrow) { ++b->narrow_pending; b->narrow_published = false; }
@@ -3605,7 +3638,7 @@ int isx_blender_last_path(isx_blender* b, int* cycle, int* last_step) ISX_ENTRY 
 
 int isx_blender_level1_format(isx_blender* b, int* format) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr && format != nullptr, ISX_ERR_INVALID, "isx_blender_level1_format: null argument");
-    *format = (b->type == ISX_BLEND_MULTI_BAND && b->path_cycle != 0 && b->path_cycle != 2) ? b->path_g1 : 0;
+    *format = (b->type == ISX_BLEND_MULTI_BAND && b->path_cycle != 0) ? b->path_g1 : 0;
     return ISX_OK;
 } ISX_EXIT("isx_blender_level1_format")
 
