@@ -135,6 +135,13 @@ __device__ __forceinline__ Px<M> load_px_rgb(const LevelBuf& L, int x, int y) {
     } else return load_px<M, DST>(L, x, y);
 }
 
+// ISX_NT_G (A/B builds): bit 0 - the tiles' level-1 records (store_rgb12 / store_px_planar), bit 1 - every 16-byte level record (store_px) stored
+// non-temporally (written through as the kernel runs instead of left dirty in L2 for the end-of-kernel write-back)
+#ifndef ISX_NT_G
+#define ISX_NT_G 0
+#endif
+template <class T>
+__device__ __forceinline__ void st_g(T* p, const T& v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 template <int M, bool DST>
 __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const Px<M>& p) {
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
@@ -146,7 +153,8 @@ __device__ __forceinline__ void store_px(const LevelBuf& L, int x, int y, const 
     } else if constexpr (M == M_F16 && !DST) {
         ((ushort4*)L.img)[i] = make_ushort4(f2h_bits(p.c0), f2h_bits(p.c1), f2h_bits(p.c2), f2h_bits(p.w));
     } else {
-        ((float4*)L.img)[i] = make_float4(p.c0, p.c1, p.c2, p.w);
+        if (ISX_NT_G & 2) { typedef float f4v __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(f4v{p.c0, p.c1, p.c2, p.w}, (f4v*)L.img + i); }
+        else ((float4*)L.img)[i] = make_float4(p.c0, p.c1, p.c2, p.w);
     }
 }
 
@@ -201,12 +209,12 @@ __device__ __forceinline__ void store_rgb12(const LevelBuf& L, unsigned i, const
     } else if constexpr (Q8) {      // (exact: see Q8 above)
         const unsigned k0 = (unsigned)(p.c0 * 256.f), k1 = (unsigned)(p.c1 * 256.f), k2 = (unsigned)(p.c2 * 256.f);
         char* q = (char*)L.img + (size_t)i * 6u;
-        *(u32_rec2*)q = k0 | (k1 << 16);
-        *(unsigned short*)(q + 4) = (unsigned short)k2;
+        st_g((u32_rec2*)q, (u32_rec2)(k0 | (k1 << 16)), (ISX_NT_G & 1) != 0);
+        st_g((unsigned short*)(q + 4), (unsigned short)k2, (ISX_NT_G & 1) != 0);
     } else {
         u32x3_rec v;
         v.x = __float_as_uint(p.c0); v.y = __float_as_uint(p.c1); v.z = __float_as_uint(p.c2);
-        *(u32x3_rec*)((char*)L.img + (size_t)i * 12u) = v;
+        st_g((u32x3_rec*)((char*)L.img + (size_t)i * 12u), v, (ISX_NT_G & 1) != 0);
     }
 }
 // A tile level that is planar or not - known only when the kernel runs (L.wgt != nullptr, uniform) - read WITHOUT a branch: the image channels as one
@@ -237,7 +245,7 @@ __device__ __forceinline__ void store_px_planar(const LevelBuf& L, int x, int y,
     static_assert(M == M_F32 || M == M_I16, "planar tile levels: 16-byte register records only");
     const unsigned i = __umul24((unsigned)y, (unsigned)L.cols) + (unsigned)x;
     store_rgb12<M, Q8>(L, i, p);
-    L.wgt[i] = p.w;
+    st_g(&L.wgt[i], p.w, (ISX_NT_G & 1) != 0);
 }
 
 // level-0 pixel of the tile pyramid at padded coordinates (x, y) in [0,width) x [0,height)
