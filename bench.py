@@ -911,6 +911,9 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 5),
                     "alg_bytes_per_launch": int(bytes_per_launch), "launches": e["launches"], "bracketed_every": SAMPLE}
+            if pairs[0].blender.level1_format() == "planar_q8":
+                roof["bytes_note"] = ("level 1 of the tiles' fp32 pyramids is k / 256 exactly and held as three unsigned shorts (Q8 records, DESIGN.md 2): "
+                                      "6 bytes per level-1 pixel and tile where fp32 records took 12; ISX_G1Q8=0 restores those")
         pair_ms = dt / args.steps / args.pairs * 1e3
         # the whole step against HBM: the kernels' own algorithmic bytes (every input read once, every output written once) and, when
         # the PMC passes ran, the fabric bytes they actually moved, both over the measured step time
@@ -959,7 +962,7 @@ def main():
                     "tiles_this_rank": pairs[0].active} if strips else {}),
                 "pairs_per_gpu": args.pairs, "tile_type": args.tile_type,
                 # which side of the fast kernels' limits this run was on (isx_blender_last_path): deferred | eager cycle, the kernel of the last collapse step
-                "path": pairs[0].blender.last_path(), "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "path": dict(pairs[0].blender.last_path(), level1=pairs[0].blender.level1_format()), "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
             # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them

@@ -79,6 +79,29 @@ def test_c_and_numpy_pyramids_agree(oracle, shape):
         assert np.array_equal(oracle.pyr_up(arr), N.pyr_up(arr))
 
 
+@pytest.mark.parametrize("shape", [(37, 53), (64, 64), (5, 3), (2, 9)])
+def test_fp32_level1_of_bytes_is_a_multiple_of_one_256th(oracle, shape):
+    """What the product's Q8 records lean on (blend.hip load_px_planar): in fp32, pyrDown of integers 0..255 is k / 256 with an integer
+    k <= 255 * 256 - exactly, in both restatements - so three unsigned shorts hold a level-1 pixel and (float)k * 2^-8 gives it back bit for bit.
+    (Level 2 is NOT: it needs 24 bits per channel; the extremes - all 255, alternating 0 / 255 - are in the set.)"""
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    h, w = shape
+    imgs = [rng.integers(0, 256, (h, w, 3)), np.full((h, w, 3), 255), (np.indices((h, w)).sum(0) % 2 * 255)[..., None].repeat(3, 2),
+            rng.integers(0, 2, (h, w, 3)) * 255]
+    not_q8 = 0
+    for img in imgs:
+        a = img.astype(np.float32)
+        for down in (oracle.pyr_down, N.pyr_down):
+            g1 = down(a)
+            k = g1 * np.float32(256)
+            assert np.array_equal(k, np.rint(k)) and k.min() >= 0 and k.max() <= 255 * 256, (shape, down.__module__)
+            back = k.astype(np.uint16).astype(np.float32) * np.float32(1 / 256)
+            assert np.array_equal(back.view(np.uint32), g1.view(np.uint32))
+            g2 = down(g1) * np.float32(256)
+            not_q8 += int(not np.array_equal(g2, np.rint(g2)))
+    assert not_q8 > 0 or h * w < 200          # (the argument stops at level 1; tiny images can fall on the grid by accident)
+
+
 def test_c_and_numpy_remap_agree(oracle):
     rng = np.random.default_rng(1)
     src = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
