@@ -103,6 +103,7 @@ _SIGS = {
     "isx_blender_level1_format": [C.c_void_p, _IP],
     "isx_blender_table_uploads": [C.c_void_p, C.POINTER(C.c_longlong)],
     "isx_blender_feed_path": [C.c_void_p, _IP, _IP],
+    "isx_blender_set_narrow_copies": [C.c_void_p, C.c_int],
     "isx_blender_blend": [C.c_void_p, _MP, _MP],
     "isx_blender_blend_batch": [C.POINTER(C.c_void_p), C.c_int, _MP, _MP],
     "isx_blender_debug_level": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _IP, _IP],
@@ -123,6 +124,7 @@ _SIGS = {
     "isx_gather_p2p_wait": [C.c_void_p, C.c_void_p],
     "isx_gather_p2p_synchronize": [C.c_void_p],
     "isx_selftest_division": [C.c_int, C.c_int, C.c_ulonglong, _IP],
+    "isx_selftest_roi_host": [C.c_int, C.c_float, _F9, _F9, C.c_int, C.c_int, C.c_int, _IP, _F9],
     "isx_selftest_exception_barrier": [C.c_int],
     "isx_profile_enable": [C.c_int],
     "isx_profile_reset": [],

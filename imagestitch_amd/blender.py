@@ -136,6 +136,11 @@ class MultiBandBlender:
         check(self._lib.isx_blender_table_uploads(self._h, C.byref(n)))
         return n.value
 
+    def set_narrow_copies(self, on=True):
+        """isx_blender_set_narrow_copies: False = private copies of CV_16SC3 tiles stay CV_16SC3 and blend() never waits for the GPU
+        (with narrowed copies - the default - it polls one pinned word the first launch of its chain publishes)."""
+        check(self._lib.isx_blender_set_narrow_copies(self._h, 1 if on else 0))
+
     def feed_path(self):
         """isx_blender_feed_path: how the last blend()'s tiles were fed in mode 2 - {"fused_tiles": n, "narrowed": none | confirmed | widened}."""
         f, n = C.c_int(), C.c_int()

@@ -997,10 +997,27 @@ __device__ __forceinline__ T ld_const(const void* p) {
     for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = s[i];
     return v;
 }
+// A pointer that was LOADED (from the table) is a generic pointer to the compiler, and generic pointers make FLAT loads - counted on lgkmcnt as
+// well as vmcnt, so every LDS wait of a kernel drains them too (collapse_roll.inc, gcp / ROLL_G, tells the same story about pointers that went
+// through an asm statement).  Pointers that arrive in the kernel arguments (TileSet) are known to be global.  The table's pointers are said to
+// be global where they are loaded: a round trip through address space 1 that the optimiser cannot fold away (a plain cast pair is folded, and
+// __builtin_assume(!is_shared && !is_private) is not picked up: both measured) - the two halves go through v_readfirstlane, which is free for a
+// value that already sits in scalar registers (a tile index is wave-uniform by construction and its descriptor comes from s_load; where the
+// compiler cannot see that, inside a per-lane branch, it is two instructions) and from whose result the address-space inference types every
+// access behind it (round 6: 10 - 54 flat_load per *_tab kernel before, none after; tools/isa_flat.py, tests/test_isa_flat.py).
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T*)(__attribute__((address_space(1))) T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void mark_global(int&) {}
+__device__ __forceinline__ void mark_global(Src0& s) { s.img = as_global(s.img); s.mask = as_global(s.mask); s.img_al = as_global(s.img_al); s.mask_al = as_global(s.mask_al); }
+__device__ __forceinline__ void mark_global(LevelBuf& l) { l.img = as_global(l.img); l.wgt = as_global(l.wgt); }
 template <class T, size_t OFF>
 struct TabField {        // ts.field[t] of a TileTab, by value
     const char* base;
-    __device__ __forceinline__ T operator[](int t) const { return ld_const<T>(base + (size_t)(unsigned)t * sizeof(TileDesc) + OFF); }
+    __device__ __forceinline__ T operator[](int t) const { T v = ld_const<T>(base + (size_t)(unsigned)t * sizeof(TileDesc) + OFF); mark_global(v); return v; }
 };
 struct TileTab {
     int n, gshift, nrng, q8;      // q8: as TileSet::q8
@@ -1033,19 +1050,25 @@ __device__ __forceinline__ void tile_range(const TileTab& ts, int x0, int x1, in
 // FeedPub: blend() of a cycle with narrowed tiles (pyrdown_l0.inc) hands their violation words to the host with the FIRST launch of its chain - this
 // one, when level 1 came from feed() - instead of a launch of its own (k_feed_publish: 4 us of a 0.32 ms step); pin == nullptr: nothing to publish
 struct FeedPub { unsigned* state; int n; int* pin; int seq; };
+// run by the whole first wave of block 0 (lanes stride the words; a table cycle may hold 4096 tiles: one thread did n dependent atomic loads
+// and stores while the host polled - ADVICE r5)
 __device__ __forceinline__ void feed_publish_words(const FeedPub& fp) {
+    const int lane = threadIdx.x & 63;
     unsigned v = 0u;
-    for (int i = 0; i < fp.n; ++i) {
+    for (int i = lane; i < fp.n; i += 64) {
         v |= __hip_atomic_load(&fp.state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&fp.state[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(&fp.pin[1], v ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    __hip_atomic_store(&fp.pin[0], fp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool any = __ballot(v != 0u) != 0ull;
+    if (lane == 0) {
+        __hip_atomic_store(&fp.pin[1], any ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&fp.pin[0], fp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 template <int M, int SK, int PLS, class TS>
 __device__ __forceinline__ void pyr_down_multi_body(const TS& ts, const FeedPub& fp) {
-    if (fp.pin != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feed_publish_words(fp);
+    if (fp.pin != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) feed_publish_words(fp);
     // blockIdx.z = tile; ts.fine = source level (or s0 when SK != SK_LEVEL), ts.coarse = destination level
     const int t = blockIdx.z;
     const LevelBuf dst = ts.coarse[t];
@@ -1472,6 +1495,9 @@ struct DevTable {
     DevBuf buf;
     std::vector<unsigned char> mirror;      // what the device holds (after everything enqueued on `st` so far)
     std::vector<unsigned> known;            // per TAB_CH chunk: the bytes from its start that the mirror vouches for
+    std::vector<unsigned char> baked;       // per chunk: a hipGraph holds a write of it (sticky): a replay rewrites the device's copy at a time the
+                                            // host does not see, so the mirror never vouches for that chunk again (capture A, eager B,
+                                            // replay A, eager B - the second eager blend compared equal to the mirror and skipped its upload)
     hipStream_t st = nullptr;
     long long uploads = 0;                  // chunks uploaded so far (introspection: the steady state adds none)
     // room for a whole chain's slots before its first put(): growing in the middle of a chain would work (hipFree waits for the kernels that read
@@ -1479,7 +1505,7 @@ struct DevTable {
     int ensure(hipStream_t s, size_t total) {
         if (total > buf.cap || s != st) {
             if (total > buf.cap) ISX_TRY(buf.reserve(std::max(total + total / 2, (size_t)64 * TAB_CH)));
-            mirror.assign(buf.cap, 0); known.assign(buf.cap / TAB_CH + 1, 0u); st = s;
+            mirror.assign(buf.cap, 0); known.assign(buf.cap / TAB_CH + 1, 0u); baked.assign(buf.cap / TAB_CH + 1, 0); st = s;
         }
         return ISX_OK;
     }
@@ -1493,11 +1519,12 @@ struct DevTable {
         const bool capturing = cap == hipStreamCaptureStatusActive;
         for (size_t o = 0; o < bytes; o += TAB_CH) {
             const size_t len = std::min(TAB_CH, bytes - o), c = (off + o) / TAB_CH;
-            if (!capturing && known[c] >= len && memcmp(mirror.data() + off + o, src + o, len) == 0) continue;
+            if (capturing) baked[c] = 1;
+            if (!capturing && !baked[c] && known[c] >= len && memcmp(mirror.data() + off + o, src + o, len) == 0) continue;
             TabChunk ch;
             memcpy(ch.b, src + o, len);
             memcpy(mirror.data() + off + o, src + o, len);
-            known[c] = capturing ? 0u : std::max(known[c], (unsigned)len);
+            known[c] = (capturing || baked[c]) ? 0u : std::max(known[c], (unsigned)len);
             hipLaunchKernelGGL(k_tab_write, dim3(1), dim3(256), 0, s, ch, (unsigned char*)buf.p + off + o, (int)len);
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(ISX_ERR_HIP, "launch of tab_write failed: %s", hipGetErrorString(le));
@@ -3655,6 +3682,13 @@ int isx_blender_table_uploads(isx_blender* b, long long* pieces) ISX_ENTRY {
     *pieces = b->tab.uploads;
     return ISX_OK;
 } ISX_EXIT("isx_blender_table_uploads")
+
+int isx_blender_set_narrow_copies(isx_blender* b, int on) ISX_ENTRY {
+    ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_set_narrow_copies: null blender");
+    ISX_CHECK_ARG(b->tiles.empty() || b->tiles[0].narrow == 0 || on != 0, ISX_ERR_STATE, "isx_blender_set_narrow_copies: a cycle with narrowed tiles is open (call it before the first feed)");
+    b->narrow_off = on == 0;
+    return ISX_OK;
+} ISX_EXIT("isx_blender_set_narrow_copies")
 
 int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed) ISX_ENTRY {
     ISX_CHECK_ARG(b != nullptr, ISX_ERR_INVALID, "isx_blender_feed_path: null blender");

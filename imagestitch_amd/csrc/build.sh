@@ -21,6 +21,11 @@ for f in isx_core.cpp imgio.cpp jpegdec.cpp seamfind.cpp gather.cpp warp.hip ble
         pids+=($!)
     fi
 done
+# host-only code (no HIP): detectResultRoi's border scan on the caller's thread, AVX2 behind a run-time CPU check (function target attributes)
+if [ ! -f build/roihost.o ] || [ roihost.cpp -nt build/roihost.o ] || [ build.sh -nt build/roihost.o ]; then
+    ${CXX:-g++} -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -c roihost.cpp -o build/roihost.o &
+    pids+=($!)
+fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o libimagestitch_hip.so build/*.o -ldl -Wl,-rpath,/opt/rocm/lib
 echo "built $(pwd)/libimagestitch_hip.so"

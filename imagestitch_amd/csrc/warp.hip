@@ -22,10 +22,15 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
+#include <cstring>
 #include <new>
 
 using namespace isx;
 using namespace isxd;
+
+// roihost.cpp (plain C++, AVX2 where the CPU has it): detectResultRoi's border pixels ranked on the caller's thread
+extern "C" int isx_roi_border_host(const float r_kinv[9], int spherical, int sw, int sh, int* cand_xy, int cap, float* scratch, int isa);
 
 namespace {
 
@@ -1216,10 +1221,14 @@ struct isx_warper {
     // (round 5: 1024 entries, each with its own host copy.  With 16 entries and one shared host buffer a panorama of more than 16 tiles through
     // one handle missed on EVERY warp - two stream synchronisations and 7 000 sinf / cosf per call: the 64-tile step was host-bound at 68 us per
     // 27 us warp kernel, 9.8 ms against a kernel sum of 7.3, profiles/round5_many_tiles_trace.txt)
-    struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; std::vector<float> host; };
-    std::vector<TabEntry> tab_cache;
+    struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; unsigned long long key; size_t bytes; };
+    std::vector<TabEntry> tab_cache;       // slots are reused, never erased: tab_index holds positions
+    std::unordered_multimap<unsigned long long, size_t> tab_index;   // hash of (kind, scale, roi) -> slot (no linear scan of 1024 entries per warp)
+    size_t tab_bytes = 0;                  // device bytes the entries' tables hold: bounded (TAB_BYTES), not only their number
+    std::vector<float> tab_host;           // staging of the one table being built (its upload is waited for)
     unsigned long long tab_clock = 0;
     std::vector<int> host_cand;
+    std::vector<float> host_scratch;      // the host border scan's stand-ins (roihost.cpp)
     float k[9], rinv[9];
     Proj proj;
     hipStream_t roi_stream = nullptr;  // the synchronous ROI scans' stream (roi_stream_of)
@@ -1370,7 +1379,50 @@ int roi_stream_of(isx_warper* w, hipStream_t* out) {
 // The synchronous border scan (k_roi_border_pin) on the ROI stream, its candidates in w->host_cand when this returns: one launch, then the
 // caller's thread polls the sequence number the kernel publishes in pinned memory (ISX_ROI_POLL=0: the round-3 form - kernel, copy, re-arm
 // kernel, hipStreamSynchronize - for A/B runs).
+// detectResultRoi's answer from the candidates of a scan: mapForward with the host's libm on exactly those (W:72-86; spherical:
+// detectResultRoiByBorder's truncation of the border's extrema, then OpenCV's two pole tests)
+void roi_from_candidates(const Proj& p, const float k[9], const float rinv[9], int sw, int sh, const int* cand, int n, int roi[4], float mm_out[4]) {
+    float tl_u = std::numeric_limits<float>::max(), tl_v = tl_u, br_u = -tl_u, br_v = -tl_u;     // W:66-69
+    for (int i = 0; i < n; ++i) {
+        float u, v;
+        map_forward_host(p, (float)cand[2 * i], (float)cand[2 * i + 1], u, v);
+        tl_u = (std::min)(tl_u, u); tl_v = (std::min)(tl_v, v);                                  // W:77-78
+        br_u = (std::max)(br_u, u); br_v = (std::max)(br_v, v);
+    }
+    if (p.kind == ISX_WARP_SPHERICAL) {
+        tl_u = (float)f2i_host(tl_u); tl_v = (float)f2i_host(tl_v); br_u = (float)f2i_host(br_u); br_v = (float)f2i_host(br_v);
+        bool north, south;
+        sph_poles(k, rinv, sw, sh, &north, &south);
+        if (north) {
+            const float pv = (float)(3.1415926535897932384626433832795 * p.scale);
+            tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, pv); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, pv);
+        }
+        if (south) { tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, 0.f); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, 0.f); }
+    }
+    mm_out[0] = tl_u; mm_out[1] = tl_v; mm_out[2] = br_u; mm_out[3] = br_v;
+    roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);   // W:83-86
+}
+
+// Round 6: the ranking runs on the caller's thread (roihost.cpp: no launch, nothing to queue behind, nothing to wait for - the scan reads the
+// projection and the source size only); ISX_ROI_HOST=0 restores the device forms below for A/B runs and for their tests.
+int border_scan_host(const float* r_kinv, bool sph, int sw, int sh, std::vector<int>& cand_out, std::vector<float>& scratch, int isa, int* n_out) {
+    scratch.resize((size_t)4 * ((size_t)sw + (size_t)sh));
+    if (cand_out.size() < (size_t)2 * CAND_FIRST) cand_out.resize((size_t)2 * CAND_FIRST);
+    int n = isx_roi_border_host(r_kinv, sph ? 1 : 0, sw, sh, cand_out.data(), (int)(cand_out.size() / 2), scratch.data(), isa);
+    ISX_CHECK_ARG(n <= CAND_CAP, ISX_ERR_UNSUPPORTED, "detectResultRoi: %d extremum candidates exceed the refinement buffer (%d)", n, CAND_CAP);
+    if ((size_t)n > cand_out.size() / 2) {       // rare: more candidates than the list held
+        cand_out.resize((size_t)2 * n);
+        n = isx_roi_border_host(r_kinv, sph ? 1 : 0, sw, sh, cand_out.data(), n, scratch.data(), isa);
+    }
+    ISX_CHECK_ARG(n > 0, ISX_ERR_INVALID, "detectResultRoi: mapForward is not finite anywhere on the border of the %d x %d source (bad K / R / scale?)", sw, sh);
+    cand_out.resize((size_t)n * 2);
+    *n_out = n;
+    return ISX_OK;
+}
+
 int border_scan_sync(isx_warper* w, int sw, int sh, hipStream_t st, const char* label, int* n_out) {
+    static const bool host_scan = [] { const char* e = getenv("ISX_ROI_HOST"); return !(e && e[0] == '0'); }();
+    if (host_scan) return border_scan_host(w->proj.r_kinv, w->kind == ISX_WARP_SPHERICAL, sw, sh, w->host_cand, w->host_scratch, 0, n_out);
     static const bool poll = [] { const char* e = getenv("ISX_ROI_POLL"); return !(e && e[0] == '0'); }();
     unsigned* keys = (unsigned*)w->scan.p;
     int* count = (int*)(keys + 4);
@@ -1444,22 +1496,11 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         ISX_TRY(roi_stream_of(w, &st));
         int n = 0;
         ISX_TRY(border_scan_sync(w, sw, sh, st, "roi_border_sph", &n));
-        float tl_u = std::numeric_limits<float>::max(), tl_v = tl_u, br_u = -tl_u, br_v = -tl_u, u, v;
-        for (int i = 0; i < n; ++i) {
-            map_forward_host(w->proj, (float)w->host_cand[2 * i], (float)w->host_cand[2 * i + 1], u, v);
-            tl_u = (std::min)(tl_u, u); tl_v = (std::min)(tl_v, v); br_u = (std::max)(br_u, u); br_v = (std::max)(br_v, v);
-        }
-        tl_u = (float)f2i_host(tl_u); tl_v = (float)f2i_host(tl_v); br_u = (float)f2i_host(br_u); br_v = (float)f2i_host(br_v);
-        bool north, south;
-        sph_poles(w->k, w->rinv, sw, sh, &north, &south);
-        if (north) {
-            const float pv = (float)(3.1415926535897932384626433832795 * w->scale);
-            tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, pv); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, pv);
-        }
-        if (south) { tl_u = (std::min)(tl_u, 0.f); tl_v = (std::min)(tl_v, 0.f); br_u = (std::max)(br_u, 0.f); br_v = (std::max)(br_v, 0.f); }
-        if (mm) { mm[0] = tl_u; mm[1] = tl_v; mm[2] = br_u; mm[3] = br_v; }
-        roi[0] = f2i_host(tl_u); roi[1] = f2i_host(tl_v); roi[2] = f2i_host(br_u); roi[3] = f2i_host(br_v);
-        if (w->sph_memo.size() >= 1024) w->sph_memo.erase(w->sph_memo.begin());
+        float emm[4];
+        roi_from_candidates(w->proj, w->k, w->rinv, sw, sh, w->host_cand.data(), n, roi, emm);
+        if (mm) std::copy(emm, emm + 4, mm);
+        const float tl_u = emm[0], tl_v = emm[1], br_u = emm[2], br_v = emm[3];
+        if (w->sph_memo.size() >= (w->roi_cache_on ? (size_t)1024 : (size_t)64)) w->sph_memo.erase(w->sph_memo.begin());   // (1024 only with the fixed-rig hint: a miss scans the list)
         isx_warper::RoiEntry e;
         e.proj = w->proj; e.sw = sw; e.sh = sh;
         std::copy(w->k, w->k + 9, e.k); std::copy(w->rinv, w->rinv + 9, e.rinv);
@@ -1524,15 +1565,10 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
     if (n > CAND_FIRST)   // rare: more candidates than the first copy carried
         ISX_HIP(hipMemcpy(w->host_cand.data() + 2 * (size_t)CAND_FIRST, cand + 2 * (size_t)CAND_FIRST, (size_t)(n - CAND_FIRST) * 8, hipMemcpyDeviceToHost));
     }
-    float tl_uf = std::numeric_limits<float>::max(), tl_vf = tl_uf, br_uf = -tl_uf, br_vf = -tl_uf;     // W:66-69
-    for (int i = 0; i < n; ++i) {
-        float u, v;
-        map_forward_host(w->proj, (float)w->host_cand[2 * i], (float)w->host_cand[2 * i + 1], u, v);
-        tl_uf = (std::min)(tl_uf, u); tl_vf = (std::min)(tl_vf, v);                                    // W:77-78
-        br_uf = (std::max)(br_uf, u); br_vf = (std::max)(br_vf, v);
-    }
-    if (mm) { mm[0] = tl_uf; mm[1] = tl_vf; mm[2] = br_uf; mm[3] = br_vf; }
-    roi[0] = f2i_host(tl_uf); roi[1] = f2i_host(tl_vf); roi[2] = f2i_host(br_uf); roi[3] = f2i_host(br_vf);   // W:83-86
+    float emm[4];
+    roi_from_candidates(w->proj, w->k, w->rinv, sw, sh, w->host_cand.data(), n, roi, emm);
+    if (mm) std::copy(emm, emm + 4, mm);
+    const float tl_uf = emm[0], tl_vf = emm[1], br_uf = emm[2], br_vf = emm[3];
     {
         const size_t cap = w->roi_cache_on ? 1024 : 1;
         while (w->roi_cache.size() >= cap) w->roi_cache.erase(w->roi_cache.begin());
@@ -1551,22 +1587,43 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
     int mw = roi[2] - roi[0] + 1, mh = roi[3] - roi[1] + 1;
     const int mwp = (mw + 3) & ~3, mhp = (mh + 3) & ~3;   // segments padded to 16 bytes: the fused kernel loads float4
     size_t n = (size_t)2 * mwp + 2 * mhp;
-    constexpr size_t TAB_SLOTS = 1024;      // (~45 KB each for a 4K tile)
+    // A fixed rig (the reference, every BASELINE config) asks for the same few ROIs for ever: up to 1024 of them stay (a 64-tile panorama
+    // through one handle needs 64; with 16 every planned warp recomputed 7 000 sinf / cosf, DESIGN.md §3 "Round 5").  A caller whose camera
+    // changes with every frame never hits: for it the cache is bounded by BYTES (16 MiB of tables, ~350 ROIs of 4K tiles; ADVICE r5: 1024
+    // entries were 46 MB of device memory and as much of host copies per warper) and looked up through a hash, not scanned.
+    constexpr size_t TAB_SLOTS = 1024, TAB_BYTES = (size_t)16 << 20;
+    unsigned long long key = 1469598103934665603ull;
+    {
+        unsigned sbits; memcpy(&sbits, &w->scale, 4);
+        const unsigned words[6] = {(unsigned)w->kind, sbits, (unsigned)roi[0], (unsigned)roi[1], (unsigned)roi[2], (unsigned)roi[3]};
+        for (unsigned v : words) { key ^= v; key *= 1099511628211ull; }
+    }
     isx_warper::TabEntry* e = nullptr;
-    for (auto& c : w->tab_cache)
-        if (c.kind == w->kind && c.scale == w->scale && std::equal(roi, roi + 4, c.roi)) { e = &c; break; }
+    {
+        auto r = w->tab_index.equal_range(key);
+        for (auto it = r.first; it != r.second; ++it) {
+            isx_warper::TabEntry& c = w->tab_cache[it->second];
+            if (c.kind == w->kind && c.scale == w->scale && std::equal(roi, roi + 4, c.roi)) { e = &c; break; }
+        }
+    }
     if (!e) {
-        if (w->tab_cache.size() < TAB_SLOTS) {
+        if (w->tab_cache.size() < TAB_SLOTS && w->tab_bytes + n * sizeof(float) <= TAB_BYTES) {
             w->tab_cache.emplace_back();
             e = &w->tab_cache.back();
             e->buf.reset(new DevBuf());
-        } else {   // evict the least recently used entry (its buffers may still be read by enqueued kernels / its upload: drain first)
+            e->bytes = 0;
+        } else {   // reuse the least recently used entry (its buffers may still be read by enqueued kernels / its upload: drain first)
             e = &w->tab_cache[0];
             for (auto& c : w->tab_cache) if (c.stamp < e->stamp) e = &c;
             ISX_HIP(hipStreamSynchronize(w->stream));
+            auto r = w->tab_index.equal_range(e->key);
+            for (auto it = r.first; it != r.second; ++it)
+                if (&w->tab_cache[it->second] == e) { w->tab_index.erase(it); break; }
         }
-        e->host.assign(n, 0.f);
-        float* cs = e->host.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
+        e->kind = -1;      // not a valid entry until its table is up (an error below leaves it unreachable: it is not in the index)
+        e->key = key;
+        w->tab_host.assign(n, 0.f);
+        float* cs = w->tab_host.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
         for (int i = 0; i < mw; ++i) {
             float u = (float)(roi[0] + i);
             u /= w->scale;                                 // W:48
@@ -1583,12 +1640,14 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
         for (int i = mw; i < mwp; ++i) { cs[i] = cs[mw - 1]; cc[i] = cc[mw - 1]; }
         for (int i = mh; i < mhp; ++i) { ra[i] = ra[mh - 1]; rb[i] = rb[mh - 1]; }
         ISX_TRY(e->buf->reserve(n * sizeof(float)));
-        ISX_HIP(hipMemcpyAsync(e->buf->p, e->host.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
-        // A miss is a planning-time event (1024 entries): the upload is simply waited for.  (Tried without the wait in round 5, the entry keeping its
-        // host copy alive: the world-8 rehearsal of bench.py then delivered a wrong mosaic in 4 runs of 7 - on this runtime an asynchronous copy
+        w->tab_bytes += e->buf->cap - e->bytes; e->bytes = e->buf->cap;
+        ISX_HIP(hipMemcpyAsync(e->buf->p, w->tab_host.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
+        // A miss is a planning-time event: the upload is simply waited for (so one staging vector serves).  (Tried without the wait in round 5, every
+        // entry keeping a host copy alive: the world-8 rehearsal of bench.py then delivered a wrong mosaic in 4 runs of 7 - on this runtime an asynchronous copy
         // from PAGEABLE memory is not something a kernel launched right behind it on the same stream can rely on; 8 of 8 runs pass with the wait.)
         ISX_HIP(hipStreamSynchronize(w->stream));
         e->kind = w->kind; e->scale = w->scale; std::copy(roi, roi + 4, e->roi);
+        w->tab_index.emplace(key, (size_t)(e - w->tab_cache.data()));
     }
     e->stamp = ++w->tab_clock;
     const float* base = (const float*)e->buf->p;
@@ -1942,6 +2001,34 @@ int isx_warper_warp_with_mask_roi(isx_warper* w, const isx_mat* src_img, const i
     ISX_CHECK_ARG(roi != nullptr, ISX_ERR_INVALID, "warp_with_mask_roi: null roi");
     return warp_common(w, src_img, src_mask, K, R, ISX_INTER_LINEAR, ISX_BORDER_REFLECT, dst_img, dst_mask, nullptr, roi, true, false);
 } ISX_EXIT("isx_warper_warp_with_mask_roi")
+
+// detectResultRoi computed on the host alone, for the cameras whose ROI the synchronous path takes from the border (every spherical camera;
+// a cylindrical one where cyl_extrema_on_border holds): what isx_warper_roi returns there, without a device - the CPU test-suite compares it
+// with the oracle's scan of every source pixel.  isa: 0 = the code isx_warper_roi runs, 1 = the scalar form.  ISX_ERR_UNSUPPORTED: a
+// cylindrical camera whose extrema are not provably on the border (isx_warper_roi scans every pixel on the device there).
+int isx_selftest_roi_host(int kind, float scale, const float K[9], const float R[9], int src_w, int src_h, int isa, int roi[4], float minmax[4]) ISX_ENTRY {
+    clear_error();
+    ISX_CHECK_ARG(K != nullptr && R != nullptr && roi != nullptr, ISX_ERR_INVALID, "selftest_roi_host: null argument");
+    ISX_CHECK_ARG((kind == ISX_WARP_CYLINDRICAL || kind == ISX_WARP_SPHERICAL) && src_w > 0 && src_h > 0, ISX_ERR_INVALID, "selftest_roi_host: bad kind / size");
+    Proj p;
+    float k[9], rinv[9], kinv[9];
+    for (int i = 0; i < 9; ++i) k[i] = K[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) rinv[i * 3 + j] = R[j * 3 + i];
+    mat3_inv(K, kinv);
+    mat3_mul(R, kinv, p.r_kinv);
+    mat3_mul(K, rinv, p.k_rinv);
+    p.scale = scale; p.kind = kind;
+    ISX_CHECK_ARG(kind == ISX_WARP_SPHERICAL || cyl_extrema_on_border(p, k, rinv, src_w, src_h), ISX_ERR_UNSUPPORTED,
+                  "selftest_roi_host: the extrema of this cylindrical camera are not provably on the border");
+    std::vector<int> cand;
+    std::vector<float> scratch;
+    int n = 0;
+    ISX_TRY(border_scan_host(p.r_kinv, kind == ISX_WARP_SPHERICAL, src_w, src_h, cand, scratch, isa, &n));
+    float mm[4];
+    roi_from_candidates(p, k, rinv, src_w, src_h, cand.data(), n, roi, mm);
+    if (minmax) std::copy(mm, mm + 4, minmax);
+    return ISX_OK;
+} ISX_EXIT("isx_selftest_roi_host")
 
 int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches) ISX_ENTRY {
     clear_error();

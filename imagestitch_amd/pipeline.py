@@ -119,15 +119,24 @@ class PairStitcher:
                 raise ValueError("window %s needs tiles %s" % (self.window, self.active))
             # ... and of those tiles only the columns the strip depends on are warped in a step
             self.tile_cols = mosaic.tile_columns_for_window(self.corners, self.sizes, num_bands, *self.window)
+        # The buffers this object writes from `stream` are ALLOCATED on `stream`: torch's caching allocator ties a block to the
+        # stream it was allocated on and recycles it in that stream's order only - a buffer allocated on the caller's stream and written from
+        # `stream` could be handed out again on the caller's stream, once this object is dropped, while `stream` still has writes queued.
+        self._tstream = stream if isinstance(stream, torch.cuda.Stream) else None
+        def empty(n, dtype):
+            if isinstance(stream, torch.cuda.Stream):
+                with torch.cuda.stream(stream):
+                    return torch.empty((n,), dtype=dtype, device=dev)
+            return torch.empty((n,), dtype=dtype, device=dev)
         # cv::Mat-style pitched buffers (row pitch a multiple of 64 B) so that the warp kernel can store dwords
         def pitched(h, row_bytes, shape, strides):
             pitch = (row_bytes + 63) // 64 * 64
-            return torch.empty((h * pitch,), dtype=torch.uint8, device=dev).as_strided(shape, (pitch,) + strides)
+            return empty(h * pitch, torch.uint8).as_strided(shape, (pitch,) + strides)
         act = set(self.active)
         if tile_type == "s16":
             def pitched16(h, w):
                 pitch = (w * 6 + 63) // 64 * 64
-                return torch.empty((h * pitch // 2,), dtype=torch.int16, device=dev).as_strided((h, w, 3), (pitch // 2, 3, 1))
+                return empty(h * pitch // 2, torch.int16).as_strided((h, w, 3), (pitch // 2, 3, 1))
             self.warped = [pitched16(h, w) if i in act else None for i, (w, h) in enumerate(self.sizes)]
         else:
             self.warped = [pitched(h, w * 3, (h, w, 3), (3, 1)) if i in act else None for i, (w, h) in enumerate(self.sizes)]
@@ -136,6 +145,10 @@ class PairStitcher:
             self.warper.warp_with_mask(imgs[i], K, Rs[i], dst_img=self.warped[i], dst_mask=self.wmasks[i])
         seam = synth.seam_masks(self.corners, [None if m is None else m.cpu().numpy() for m in self.wmasks], self.sizes)
         self.seam = [None if s is None else torch.from_numpy(s).to(dev) for s in seam]
+        if isinstance(stream, torch.cuda.Stream):
+            for t in self.seam:
+                if t is not None:
+                    t.record_stream(stream)     # uploaded on the caller's stream, read from `stream` for as long as this object lives
         self.roi_pad, (fw, fh), self.L = prepare_geometry(self.corners, self.sizes, num_bands)
         self.mosaic_size = (fw, fh)
         if self.window is not None:
@@ -162,7 +175,7 @@ class PairStitcher:
         odt = {"int16": torch.int16, "float32": torch.float32, "uint8": torch.uint8}[out_dtype]
         es = {"int16": 2, "float32": 4, "uint8": 1}[out_dtype]
         opitch = (fw * 3 * es + 63) // 64 * 64
-        self.out = torch.empty((fh * opitch // es,), dtype=odt, device=dev).as_strided((fh, fw, 3), (opitch // es, 3, 1))
+        self.out = empty(fh * opitch // es, odt).as_strided((fh, fw, 3), (opitch // es, 3, 1))
         self.out_mask = pitched(fh, fw, (fh, fw), (1,))
 
     def _feed(self, i, corner):
@@ -341,13 +354,15 @@ class PairStitcher:
         if self.tile_type != "u8":
             raise ValueError("step_literal: the reference warps CV_8UC3 tiles (construct with tile_type='u8')")
         if not hasattr(self, "src_masks"):
-            # every mat as Mat::create makes it: continuous, rows back to back (a 3425-pixel CV_8UC3 row starts on an odd byte)
-            self.src_masks = [None if im is None else torch.full(im.shape[:2], 255, dtype=torch.uint8, device=im.device) for im in self.imgs]   # W:213-214
-            self.lit_warped = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.uint8, device=wi.device) for wi in self.warped]
-            self.lit_wmasks = [None if wm is None else torch.empty(tuple(wm.shape), dtype=torch.uint8, device=wm.device) for wm in self.wmasks]
-            self.warped16 = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.int16, device=wi.device) for wi in self.warped]
-            self.lit_out = torch.empty(tuple(self.out.shape), dtype=self.out.dtype, device=self.out.device)
-            self.lit_out_mask = torch.empty(tuple(self.out_mask.shape), dtype=torch.uint8, device=self.out.device)
+            import contextlib
+            with (torch.cuda.stream(self._tstream) if getattr(self, "_tstream", None) is not None else contextlib.nullcontext()):   # allocated on the stream that writes them
+                # every mat as Mat::create makes it: continuous, rows back to back (a 3425-pixel CV_8UC3 row starts on an odd byte)
+                self.src_masks = [None if im is None else torch.full(im.shape[:2], 255, dtype=torch.uint8, device=im.device) for im in self.imgs]   # W:213-214
+                self.lit_warped = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.uint8, device=wi.device) for wi in self.warped]
+                self.lit_wmasks = [None if wm is None else torch.empty(tuple(wm.shape), dtype=torch.uint8, device=wm.device) for wm in self.wmasks]
+                self.warped16 = [None if wi is None else torch.empty(tuple(wi.shape), dtype=torch.int16, device=wi.device) for wi in self.warped]
+                self.lit_out = torch.empty(tuple(self.out.shape), dtype=self.out.dtype, device=self.out.device)
+                self.lit_out_mask = torch.empty(tuple(self.out_mask.shape), dtype=torch.uint8, device=self.out.device)
         cs = list(self.corners)
         for i in self.active:
             im = self.imgs[i]

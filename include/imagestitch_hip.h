@@ -299,6 +299,16 @@ int isx_blender_table_uploads(isx_blender* b, long long* pieces);
  * answer from pinned memory after it has enqueued everything that does not depend on it - no stream synchronisation.  Either pointer
  * may be NULL.                                                                                                                    */
 int isx_blender_feed_path(isx_blender* b, int* fused_tiles, int* narrowed);
+/* Narrowed private copies (mode 2, CV_16SC3 device tiles) make blend() WAIT FOR THE GPU once: before it picks the last step's kernel the
+ * calling thread polls the pinned word that the first launch of blend()'s own chain publishes, i.e. it waits until the GPU has worked off
+ * whatever the stream held in front of that launch (no hipStreamSynchronize, but with a deep queue on the stream the host stalls for the
+ * backlog, and a stream gated behind something this thread would only release AFTER blend() returns - a host callback, a host-signalled
+ * event - would never reach the launch: the wait gives up into a stream synchronisation after 20 s).  on = 0 switches the narrowing off
+ * for this blender (what the environment variable ISX_FEED_NARROW=0 does for the process): private copies of CV_16SC3 tiles stay
+ * CV_16SC3, blend() enqueues and returns without looking at the device; same bits, 3 more bytes per pixel written and read (a 4K pair:
+ * the last step 50 -> 60 us).  on = 1 (default) allows it again.  Call it before the first feed of a cycle (ISX_ERR_STATE otherwise).
+ * hipGraph capture never narrows.                                                                                                    */
+int isx_blender_set_narrow_copies(isx_blender* b, int on);
 /* blender->blend(result, result_mask) (W:313).  dst: CV_16SC3 (I16: exact; F32: saturate_cast
  * round-half-even), CV_32FC3 (F32/F16ACC32 only) or CV_8UC3 (= blend to CV_16SC3 followed by
  * result.convertTo(CV_8U), what imwrite (W:315) does to the panorama); dst_mask: CV_8UC1.  Releases the pyramids:
@@ -451,6 +461,13 @@ int isx_gather_p2p_synchronize(isx_gather* g);
  * written out in packed FMAs (csrc/warp.hip, k_warp_tile).  This compares that recurrence with the compiler's IEEE division
  * on n pseudo-random operand pairs of the range the kernel admits to it; *mismatches must come back 0.              */
 int isx_selftest_division(int device, int n, unsigned long long seed, int* mismatches);
+/* detectResultRoi (W:64-88; SphericalWarper's border form) computed on the host alone - what isx_warper_roi returns for the cameras whose
+ * extrema provably lie on the source's border (every spherical camera; a cylindrical one with the image in front of the camera and no pole
+ * of the cylinder near it: every rig of the reference): the 2 (W + H) border pixels ranked on the caller's thread by two monotone stand-ins
+ * (csrc/roihost.cpp, AVX2), the pixels within a tolerance of the four extrema evaluated with mapForward (W:36-45) and the host's libm.
+ * Needs no device: the CPU test-suite compares it with the oracle's scan of every source pixel.  isa: 0 = the code isx_warper_roi runs,
+ * 1 = its scalar form.  ISX_ERR_UNSUPPORTED for a cylindrical camera outside that proof (isx_warper_roi scans every pixel on the GPU there). */
+int isx_selftest_roi_host(int kind, float scale, const float K[9], const float R[9], int src_w, int src_h, int isa, int roi[4], float minmax[4]);
 /* Every entry of this header is a function-try-block: a C++ exception raised underneath it (std::bad_alloc of a host container, a
  * std::length_error, anything a future change throws) is stopped there and comes back as a status - ISX_ERR_NOMEM for the two allocation
  * failures, ISX_ERR_INTERNAL otherwise, the text in isx_last_error() - never as an exception in the caller's frames (the

@@ -226,3 +226,33 @@ print("HASH", h.hexdigest())
         assert out.returncode == 0, out.stderr[-2000:]
         hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][0])
     assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
+@pytest.mark.parametrize("prec", [I16, F32])
+def test_narrowing_can_be_switched_off_per_blender(gpu, oracle, prec):
+    """isx_blender_set_narrow_copies(0): the private copies stay CV_16SC3, blend() never polls the device - same bits; switching it
+    on again narrows again; and switching it off inside a cycle that already holds narrowed tiles is refused."""
+    corners, sizes = LAYOUTS["pair"]
+    rng = np.random.default_rng(11)
+    mb = gpu.MultiBandBlender(False, 5, prec)
+    mb.set_deferred_level0("copy")
+    seen = []
+    for on in (False, True, False):
+        mb.set_narrow_copies(on)
+        tiles = _tiles(rng, sizes, "bytes")
+        od, om = _oracle_blend(oracle, 5, prec, corners, sizes, tiles)
+        d, m = _gpu_blend(gpu, mb, prec, corners, sizes, tiles)
+        assert np.array_equal(m, om) and np.array_equal(d, od), on
+        seen.append(mb.feed_path()["narrowed"])
+    assert seen == ["none", "confirmed", "none"], seen
+    import torch
+    mb.set_narrow_copies(True)
+    tiles = _tiles(rng, sizes, "bytes")
+    mb.prepare(corners, sizes)
+    mb.feed(torch.from_numpy(tiles[0][0]).cuda(), torch.from_numpy(tiles[0][1]).cuda(), corners[0])
+    with pytest.raises(Exception):
+        mb.set_narrow_copies(False)
+    mb.feed(torch.from_numpy(tiles[1][0]).cuda(), torch.from_numpy(tiles[1][1]).cuda(), corners[1])
+    od, om = _oracle_blend(oracle, 5, prec, corners, sizes, tiles)
+    d, m = mb.blend(out_f32=prec != I16)
+    assert np.array_equal(_np(m), om) and np.array_equal(_np(d), od)

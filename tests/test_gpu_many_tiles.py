@@ -251,4 +251,16 @@ def test_a_table_cycle_captured_as_a_hipgraph_survives_another_blend(gpu, oracle
     out, m = p.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref[0]) and torch.equal(m, ref[1])
+    # ... and the other order: the replay has just rewritten the device's tables behind the host's back - an eager blend of the moved
+    # tiles right after it must not trust its mirror of what the device held before the replay (it compared equal and skipped the upload)
+    with torch.cuda.stream(p.gstream):
+        p.blender.prepare(corners, p.sizes)
+        for i in range(24):
+            p.blender.feed_u8(p.warped[i], p.seam[i], corners[i])
+        d3, m3 = p.blender.blend(out_f32=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(d3.cpu().numpy(), od) and np.array_equal(m3.cpu().numpy(), om)
+    out, m = p.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref[0]) and torch.equal(m, ref[1])
     p.check_plan()
