@@ -436,8 +436,11 @@ def main():
                          "(isx_blender_set_window) and the all-gather of the strips is the panorama (strong scaling: the work per step is fixed)")
     ap.add_argument("--strip-of", default=None, metavar="R/W",
                     help="one GPU, no gather: run what rank R of W would run under --shard strips (its share of the compute, measurable here)")
-    ap.add_argument("--gather", default="chunk", choices=["chunk", "single"],
-                    help="N > 1: all-gather the rank's block pair by pair behind each blend (default), or as ONE collective per step")
+    ap.add_argument("--gather", default="chunk", choices=["chunk", "single", "root"],
+                    help="N > 1: all-gather the rank's block pair by pair behind each blend (default), or as ONE collective per step; root: pair by "
+                         "pair like chunk, but to rank 0 ONLY (1 / (N - 1) of the bytes on the links: tells 'the blend scales' from 'the links carry "
+                         "N - 1 times the bytes'; the default line reports it as a second leg, multi_gpu.root_gather_Mpix_s - the all-gather stays "
+                         "the graded schedule, north_star fixes it)")
     ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx", "p2p"],
                     help="N > 1: torch.distributed (RCCL), the library's own RCCL communicator (isx_gather_*), or the direct schedule "
                          "(isx_gather_p2p_*: every chunk copied straight into every rank's buffer, one stream per destination - tells RCCL's "
@@ -471,6 +474,8 @@ def main():
         print(json.dumps({"warp": tw, "blend": tb}))
         return
 
+    if args.gather == "root" and args.gather_backend != "torch":
+        raise SystemExit("bench.py: --gather root runs through torch.distributed (--gather-backend torch): the library's own gather entries are all-gathers")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -626,7 +631,11 @@ def main():
     def post_chunk(b, i):
         """all-gather of pair i's mosaic (chunk i of send[b]) on the communication stream, behind ev_pair[b][i]"""
         off, n = chunks[i]
-        if p2p:
+        if args.gather == "root":           # to rank 0 only (torch.distributed; the other backends have no such entry)
+            comm.wait_event(ev_pair[b][i])
+            with torch.cuda.stream(comm):
+                mosaic.gather_chunk_root(send[b], off, n, gather_buf, 0)
+        elif p2p:
             isx_g.p2p_chunk(send[b], off, n, ev_pair[b][i])
         elif isx_g is not None:
             isx_g.chunk(send[b], off, n, gather_buf, ev_pair[b][i])
@@ -647,7 +656,9 @@ def main():
 
     def gathers_done(b):
         """record `send[b] has been read by its gathers` for the step that reuses it"""
-        if p2p:
+        if args.gather == "root":
+            pass
+        elif p2p:
             isx_g.p2p_wait(comm)
         elif isx_g is not None:
             isx_g.wait(comm)
@@ -679,7 +690,7 @@ def main():
             if use_dist:
                 for i in range(len(pairs)):
                     ev_pair[b][i].record(pstreams[i % len(pstreams)] if pstreams[0] is not None else main)
-                    if args.gather == "chunk":
+                    if args.gather in ("chunk", "root"):
                         post_chunk(b, i)
                 if args.gather == "single":
                     post_block(b)
@@ -698,7 +709,7 @@ def main():
                     p.step()
             if use_dist:
                 ev_pair[b][i].record(p.gstream if args.graph else (ps if ps is not None else main))
-                if args.gather == "chunk":
+                if args.gather in ("chunk", "root"):
                     post_chunk(b, i)
         if use_dist:
             if args.gather == "single":
@@ -826,7 +837,10 @@ def main():
         dt_c = time.perf_counter() - t1
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            if p2p:
+            if args.gather == "root":
+                for off_, n_ in chunks:
+                    mosaic.gather_chunk_root(send[0], off_, n_, gather_buf, 0)
+            elif p2p:
                 isx_g.p2p_chunk(send[0], 0, n_out)
                 isx_g.p2p_wait()
             elif isx_g is not None:
@@ -835,10 +849,25 @@ def main():
                 mosaic.gather_mosaics(send[0], gather_buf)
         fence()
         dt_g = time.perf_counter() - t1
-        t = torch.tensor([dt, dt_c, dt_g], dtype=torch.float64, device=dev)
+        # ... and, as a second reported leg, the same K steps with every chunk gathered to rank 0 ONLY (what --gather root times as `value`): a
+        # rank's block crosses one link instead of N - 1, so this leg shows whether the blend scales when the links carry 1 / (N - 1) of the bytes
+        dt_r = 0.0
+        if args.gather != "root" and args.gather_backend == "torch" and not args.graph:
+            keep = args.gather
+            args.gather = "root"
+            fence()
+            step()                                       # (one untimed step: the first grouped send / recv sets its channels up)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            dt_r = time.perf_counter() - t1
+            args.gather = keep
+        t = torch.tensor([dt, dt_c, dt_g, dt_r], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_c, dt_g = (float(v) for v in t.tolist())
-        split = (dt_c, dt_g, int(send[0].numel()))
+        dt, dt_c, dt_g, dt_r = (float(v) for v in t.tolist())
+        split = (dt_c, dt_g, int(send[0].numel()), dt_r)
     gather_check = None
     if use_dist and args.check_gather:
         # One more step; then every chunk this rank RECEIVED (world x pairs of them) against the same mosaic stitched here, serially, from the
@@ -861,7 +890,9 @@ def main():
             for q in range(world):
                 # where rank q's chunk i lies: pair by pair, every chunk's copies are rank-major inside that chunk's own stretch of the buffer
                 # (mosaic.gather_chunk / isx_gather_chunk / p2p_chunk: world * offset + q * count); as one collective, rank-major blocks
-                at = world * off + q * n if args.gather == "chunk" else q * n_out + off
+                if args.gather == "root" and rank != 0:
+                    continue                                  # only rank 0 received anything
+                at = world * off + q * n if args.gather in ("chunk", "root") else q * n_out + off
                 got = gather_buf[at:at + n].as_strided(sh, (pt, sh[2], 1))
                 if strips:
                     w0, w1 = windows[q]
@@ -956,6 +987,7 @@ def main():
             "config": {"workload": ("ONE panorama per step cut into %d column strips, strip %d here: " % (strip_world, strip_rank) if strips else "") + "%s%d x (%d x %dx%d u8x3 tiles, %s warp f=%g, %d-band %s blend) per GPU per step%s" % (
                 ("%d x %dx%d tiles, %d tiles/GPU: " % (world * args.pairs * NT, W, H, args.pairs * NT)) if world > 1 else "",
                 args.pairs, NT, W, H, args.kind, F, args.bands, args.precision, (", u8x3 mosaics all-gathered pair by pair behind each blend (%s)" % args.gather_backend if args.gather == "chunk" else
+                 ", u8x3 mosaics gathered to rank 0 ONLY, pair by pair behind each blend (%s)" % args.gather_backend if args.gather == "root" else
                  ", ONE all-gather of the u8x3 mosaics per step, overlapped with the next step (%s)" % args.gather_backend) if use_dist else ""),
                 "tiles_per_mosaic": NT,
                 **({"shard": "strips", "strip": "%d/%d" % (strip_rank, strip_world), "window": list(window), "panorama_cols": fw_all,
@@ -978,7 +1010,7 @@ def main():
                                     "(profiles/round4_clock_ramp.txt); --preflight-ms 0 switches them off",
                             "after_idle_Mpix_s": round(mpix_step * args.steps / after_idle, 1) if after_idle else None}
         if split:
-            dt_c, dt_g, nsend = split
+            dt_c, dt_g, nsend, dt_r = split
             out["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "without_gather_Mpix_s": round(mpix_step * args.steps / dt_c, 1),
                                 # the N = 1 reference of THIS workload (config 4's per-GPU share: --pairs P on min(P, 4) streams, u8 mosaics, no gather) - the default N = 1
                                 # line is config 2 (one pair per step, CV_16SC3 result), so a ratio against it would mix two workloads: this is one
@@ -989,6 +1021,10 @@ def main():
                                 **({"gather_bus_GBs": round((world - 1) * nsend / (dt_g / args.steps) / 1e9, 1)} if world > 1 else
                                    {"local_copy_GBs": round(nsend / (dt_g / args.steps) / 1e9, 1)}),
                                 "gather": args.gather, "gather_backend": args.gather_backend,
+                                # the second leg: every chunk to rank 0 only (1 / (N - 1) of the all-gather's bytes on the links), same steps, timed after the region
+                                **({"root_gather_Mpix_s": round(mpix_step * args.steps / dt_r, 1),
+                                    "root_gather_what": "the same K steps with every pair's mosaic gathered to rank 0 ONLY (mosaic.gather_chunk_root, "
+                                                        "pair by pair behind each blend): a reported second leg - `value` stays the all-gather north_star fixes"} if dt_r > 0 else {}),
                                 **({"gather_check": gather_check} if gather_check is not None else {}),
                                 "note": "value = steps with the gathers overlapped with the blends that follow them; the two legs here are timed after "
                                         "it, each bracketed like the timed region; gather_bus_GBs = bytes every rank receives / gather time"}

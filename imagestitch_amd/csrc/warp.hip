@@ -378,6 +378,8 @@ struct TileDst {
     unsigned char* mask; unsigned mask_step;
     int w, h;
     int bx0;        // first 64-column block of this launch (isx_warper_set_dst_columns), 0 = the whole tile
+    int xg;         // > 0: runs of xg horizontally adjacent blocks go to ONE XCD (see k_warp_tile); xmagic = 2^32 / gridDim.x + 1
+    unsigned xmagic;
 };
 
 // The rows of a thread that did not qualify for the fast path (bit i of `slow`: the thread's four pixels of row row0 + i),
@@ -492,11 +494,28 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
     // left and right edge of the warped tile is a few dozen pixels wide, so with 256 x 1 waves every row's first and last wave crossed
     // it (tier 2); with 64 x 4 waves a quarter as many do.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int dx0 = ((blockIdx.x + d.bx0) * 16 + (lane & 15)) * 4;
+    // Which block of the tile this workgroup is.  The hardware deals the workgroups of a launch to the 8 XCDs round robin in dispatch order (x
+    // fastest), so horizontally adjacent blocks - whose 192-byte row segments of the source share the 128-byte lines at their common edge -
+    // always sit on different XCDs, and each XCD's L2 fetches the shared lines itself: 47.4 MB fetched per 4K tile for 24.9 MB of source
+    // (profiles/round5_traffic.json).  With d.xg > 0 the blocks are renumbered inside every aligned group of 8 xg consecutive ones so that XCD k
+    // receives the k-th run of xg ADJACENT blocks of the group, one after the other: neighbours meet in one L2, and every XCD still gets every
+    // eighth run of the tile (the plain round robin's even spread of cheap and dear blocks - round 2's band order lost on exactly that).
+    unsigned bxu = blockIdx.x, byu = blockIdx.y;
+    if (d.xg > 0) {
+        const unsigned gx = gridDim.x, total = gx * gridDim.y, L = blockIdx.y * gx + blockIdx.x, grp = 8u * (unsigned)d.xg;
+        unsigned lin = L;
+        if (L < total - total % grp) {
+            const unsigned base = L - L % grp, r = L - base, xcd = r & 7u, i = r >> 3;     // the i-th block this XCD receives from the group
+            lin = base + xcd * (unsigned)d.xg + i;
+        }
+        byu = __umulhi(lin, d.xmagic);          // lin / gx (exact: lin * gx < 2^32)
+        bxu = lin - byu * gx;
+    }
+    const int dx0 = (((int)bxu + d.bx0) * 16 + (lane & 15)) * 4;
     // Row blocks are taken alternately from the top and from the bottom of the tile: the rows near the tile's upper and lower edge are
     // where waves cross the image border (tier 2 below, the occasional generic pixel) and live several times longer than interior
     // waves - dispatched first they overlap with the rest of the launch, dispatched last they were its tail.
-    const int by = (blockIdx.y & 1) ? (int)gridDim.y - 1 - (int)(blockIdx.y >> 1) : (int)(blockIdx.y >> 1);
+    const int by = (byu & 1u) ? (int)gridDim.y - 1 - (int)(byu >> 1) : (int)(byu >> 1);
     const int dy = by * (4 * WARP_WAVES) + wv * 4 + (lane >> 4);
     if (dy >= d.h || dx0 >= d.w) return;
     const bool whole = VEC && dx0 + 4 <= d.w;       // four real columns and dword-aligned rows: vector stores
@@ -1221,12 +1240,15 @@ struct isx_warper {
     // (round 5: 1024 entries, each with its own host copy.  With 16 entries and one shared host buffer a panorama of more than 16 tiles through
     // one handle missed on EVERY warp - two stream synchronisations and 7 000 sinf / cosf per call: the 64-tile step was host-bound at 68 us per
     // 27 us warp kernel, 9.8 ms against a kernel sum of 7.3, profiles/round5_many_tiles_trace.txt)
-    struct TabEntry { int kind; float scale; int roi[4]; std::unique_ptr<DevBuf> buf; unsigned long long stamp; unsigned long long key; size_t bytes; };
-    std::vector<TabEntry> tab_cache;       // slots are reused, never erased: tab_index holds positions
-    std::unordered_multimap<unsigned long long, size_t> tab_index;   // hash of (kind, scale, roi) -> slot (no linear scan of 1024 entries per warp)
-    size_t tab_bytes = 0;                  // device bytes the entries' tables hold: bounded (TAB_BYTES), not only their number
+    struct TabEntry { int kind; float scale; int roi[4]; const float* dev; };
+    std::vector<TabEntry> tab_cache;
+    std::unordered_multimap<unsigned long long, size_t> tab_index;   // hash of (kind, scale, roi) -> entry (no linear scan of 1024 entries per warp)
+    // the tables live in a few 4 MiB chunks, bump-allocated (a DevBuf per entry was a megabyte per entry - reserve() rounds up - i.e. up to a
+    // gigabyte per warper at the old cap of 1024 entries): at most TAB_BYTES of them; a full arena is drained and started over
+    std::vector<std::unique_ptr<DevBuf>> tab_chunks;
+    size_t tab_chunk = 0, tab_used = 0;    // the chunk being filled and the bytes used in it
+    long long tab_resets = 0;
     std::vector<float> tab_host;           // staging of the one table being built (its upload is waited for)
-    unsigned long long tab_clock = 0;
     std::vector<int> host_cand;
     std::vector<float> host_scratch;      // the host border scan's stand-ins (roihost.cpp)
     float k[9], rinv[9];
@@ -1589,9 +1611,9 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
     size_t n = (size_t)2 * mwp + 2 * mhp;
     // A fixed rig (the reference, every BASELINE config) asks for the same few ROIs for ever: up to 1024 of them stay (a 64-tile panorama
     // through one handle needs 64; with 16 every planned warp recomputed 7 000 sinf / cosf, DESIGN.md §3 "Round 5").  A caller whose camera
-    // changes with every frame never hits: for it the cache is bounded by BYTES (16 MiB of tables, ~350 ROIs of 4K tiles; ADVICE r5: 1024
-    // entries were 46 MB of device memory and as much of host copies per warper) and looked up through a hash, not scanned.
-    constexpr size_t TAB_SLOTS = 1024, TAB_BYTES = (size_t)16 << 20;
+    // changes with every frame never hits: for it the cache is bounded by BYTES (TAB_BYTES of tables, ~350 ROIs of 4K tiles) and looked up
+    // through a hash, not scanned; when the arena or the entry list is full the stream is drained once and the cache starts over.
+    constexpr size_t TAB_SLOTS = 1024, TAB_BYTES = (size_t)16 << 20, TAB_CHUNK = (size_t)4 << 20;
     unsigned long long key = 1469598103934665603ull;
     {
         unsigned sbits; memcpy(&sbits, &w->scale, 4);
@@ -1607,21 +1629,23 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
         }
     }
     if (!e) {
-        if (w->tab_cache.size() < TAB_SLOTS && w->tab_bytes + n * sizeof(float) <= TAB_BYTES) {
-            w->tab_cache.emplace_back();
-            e = &w->tab_cache.back();
-            e->buf.reset(new DevBuf());
-            e->bytes = 0;
-        } else {   // reuse the least recently used entry (its buffers may still be read by enqueued kernels / its upload: drain first)
-            e = &w->tab_cache[0];
-            for (auto& c : w->tab_cache) if (c.stamp < e->stamp) e = &c;
+        const size_t need = (n * sizeof(float) + 255) & ~(size_t)255;
+        ISX_CHECK_ARG(need <= TAB_CHUNK, ISX_ERR_UNSUPPORTED, "warp: a %d x %d warped tile needs %zu bytes of column / row tables (limit %zu)", mw, mh, need, TAB_CHUNK);
+        auto start_over = [&]() -> int {      // enqueued kernels may still read the old tables: drain first
             ISX_HIP(hipStreamSynchronize(w->stream));
-            auto r = w->tab_index.equal_range(e->key);
-            for (auto it = r.first; it != r.second; ++it)
-                if (&w->tab_cache[it->second] == e) { w->tab_index.erase(it); break; }
+            w->tab_cache.clear(); w->tab_index.clear(); w->tab_chunk = 0; w->tab_used = 0; ++w->tab_resets;
+            return ISX_OK;
+        };
+        if (w->tab_cache.size() >= TAB_SLOTS) ISX_TRY(start_over());
+        if (!w->tab_chunks.empty() && w->tab_used + need > TAB_CHUNK) {
+            if ((w->tab_chunk + 2) * TAB_CHUNK > TAB_BYTES) ISX_TRY(start_over());
+            else { ++w->tab_chunk; w->tab_used = 0; }
         }
-        e->kind = -1;      // not a valid entry until its table is up (an error below leaves it unreachable: it is not in the index)
-        e->key = key;
+        if (w->tab_chunk >= w->tab_chunks.size()) {
+            w->tab_chunks.emplace_back(new DevBuf());
+            ISX_TRY(w->tab_chunks.back()->reserve(TAB_CHUNK));
+        }
+        float* dev = (float*)((char*)w->tab_chunks[w->tab_chunk]->p + w->tab_used);
         w->tab_host.assign(n, 0.f);
         float* cs = w->tab_host.data(); float* cc = cs + mwp; float* ra = cc + mwp; float* rb = ra + mhp;
         for (int i = 0; i < mw; ++i) {
@@ -1639,18 +1663,18 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
         // pixels in its unused lanes (zeros would make z = 0 there and send the whole group down the generic path, once per row)
         for (int i = mw; i < mwp; ++i) { cs[i] = cs[mw - 1]; cc[i] = cc[mw - 1]; }
         for (int i = mh; i < mhp; ++i) { ra[i] = ra[mh - 1]; rb[i] = rb[mh - 1]; }
-        ISX_TRY(e->buf->reserve(n * sizeof(float)));
-        w->tab_bytes += e->buf->cap - e->bytes; e->bytes = e->buf->cap;
-        ISX_HIP(hipMemcpyAsync(e->buf->p, w->tab_host.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
+        ISX_HIP(hipMemcpyAsync(dev, w->tab_host.data(), n * sizeof(float), hipMemcpyHostToDevice, w->stream));
         // A miss is a planning-time event: the upload is simply waited for (so one staging vector serves).  (Tried without the wait in round 5, every
         // entry keeping a host copy alive: the world-8 rehearsal of bench.py then delivered a wrong mosaic in 4 runs of 7 - on this runtime an asynchronous copy
         // from PAGEABLE memory is not something a kernel launched right behind it on the same stream can rely on; 8 of 8 runs pass with the wait.)
         ISX_HIP(hipStreamSynchronize(w->stream));
-        e->kind = w->kind; e->scale = w->scale; std::copy(roi, roi + 4, e->roi);
-        w->tab_index.emplace(key, (size_t)(e - w->tab_cache.data()));
+        w->tab_used += need;
+        w->tab_cache.emplace_back();
+        e = &w->tab_cache.back();
+        e->kind = w->kind; e->scale = w->scale; std::copy(roi, roi + 4, e->roi); e->dev = dev;
+        w->tab_index.emplace(key, w->tab_cache.size() - 1);
     }
-    e->stamp = ++w->tab_clock;
-    const float* base = (const float*)e->buf->p;
+    const float* base = e->dev;
     t->col_s = base; t->col_c = base + mwp; t->row_a = base + 2 * mwp; t->row_b = base + 2 * mwp + mhp;
     return ISX_OK;
 }
@@ -1736,7 +1760,9 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         const dim3 gridt(cdiv(wcrop, 64) - bx0, cdiv(dh, 4 * WARP_WAVES));
         const bool gained = w->gain != 1.0;
         ISX_CHECK_ARG(!(gained && src_mask), ISX_ERR_UNSUPPORTED, "warp_with_mask: isx_warper_set_gain applies to tiles warped with the all-255 mask (src_mask == NULL)");
-        WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0}, {}};
+        static const int warp_xg = [] { const char* e = getenv("ISX_WARP_XG"); return e ? atoi(e) : 0; }();
+        const int xg = (warp_xg > 0 && (unsigned long long)gridt.x * gridt.y * gridt.x < (1ull << 32)) ? warp_xg : 0;
+        WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0, xg, 0xFFFFFFFFu / gridt.x + 1u}, {}};
         if (gained) memcpy(wta.lut, w->gain_lut, 256);
 #define ISX_WARP_TILE(KD, O16, V)                                                                                                            \
     do {                                                                                                                                     \
@@ -1777,7 +1803,9 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         if (tile_path && small && src->type == ISX_8UC3 && interp == ISX_INTER_LINEAR && border == ISX_BORDER_REFLECT) {
             static const bool vec = [] { const char* e = getenv("ISX_WARP_VEC"); return !(e && e[0] == '0'); }();
             const dim3 gridt(cdiv(dw, 64), cdiv(dh, 4 * WARP_WAVES));
-            const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0}, {}};
+            static const int warp_xg = [] { const char* e = getenv("ISX_WARP_XG"); return e ? atoi(e) : 0; }();
+            const int xg = (warp_xg > 0 && (unsigned long long)gridt.x * gridt.y * gridt.x < (1ull << 32)) ? warp_xg : 0;
+            const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0, xg, 0xFFFFFFFFu / gridt.x + 1u}, {}};
 #define ISX_WARP_IMG(KD, V) ISX_LAUNCH("warp_tile_img", bytes, st, (k_warp_tile<KD, false, V, false>), gridt, dim3(64 * WARP_WAVES), 0, wta)
             if (w->kind == ISX_WARP_CYLINDRICAL) { if (vec) ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, true); else ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, false); }
             else { if (vec) ISX_WARP_IMG(ISX_WARP_SPHERICAL, true); else ISX_WARP_IMG(ISX_WARP_SPHERICAL, false); }

@@ -54,6 +54,29 @@ def gather_chunk(send, offset, count, out, group=None):
     return dst.view(world, count)
 
 
+def gather_chunk_root(send, offset, count, out, root=0, group=None):
+    """The same chunk to ONE rank only (bench.py --gather root): elements [offset, offset + count) of every rank's block land on `root` where
+    gather_chunk puts them (out[world * offset + r * count ...]); the other ranks' `out` is not touched (they may pass None).  A rank's block then
+    crosses ONE of its links instead of all N - 1: 1 / (N - 1) of the all-gather's bytes on the node.  north_star fixes the all-gather (every rank
+    holds every mosaic), so this is a reported second leg, not the graded one: it separates "the blend scales" from "the links carry N - 1 times
+    the bytes" (DESIGN.md §7).  RCCL: ncclSend / ncclRecv grouped (torch.distributed.gather); gloo moves host copies."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = send.view(-1).view(torch.uint8)[offset: offset + count]
+    dst = None
+    if rank == root:
+        dst = out.view(-1).view(torch.uint8)[world * offset: world * (offset + count)]
+    if dist.get_backend(group) == "gloo" and src.is_cuda:       # (the one-GPU rehearsal of the N-rank path: gloo gathers host tensors)
+        host = [torch.empty((count,), dtype=torch.uint8) for _ in range(world)] if rank == root else None
+        dist.gather(src.cpu(), host, dst=root, group=group)
+        if rank == root:
+            dst.view(world, count).copy_(torch.stack(host))
+    else:
+        dist.gather(src, [dst[r * count: (r + 1) * count] for r in range(world)] if rank == root else None, dst=root, group=group)
+    return None if dst is None else dst.view(world, count)
+
+
 def chunk_view(out, world, offset, count, rank):
     """Rank `rank`'s copy of the chunk at (offset, count) inside a buffer filled by gather_chunk / isx_gather_chunk."""
     return out.view(-1)[world * offset + rank * count: world * offset + (rank + 1) * count]

@@ -83,6 +83,17 @@ def _worker_chunks(rank, world, port, n_pairs, ret):
         for j, ((o, n), sh, pt) in enumerate(zip(chunks, shapes, pitches)):
             got = mosaic.chunk_view(gather_buf, world, o, n, q).as_strided(sh, (pt, sh[2], 1))     # chunk-major: world * offset + q * count
             ok = ok and bool(torch.all(got == q * 16 + j + 1))
+    # bench.py --gather root: the same chunks to rank 0 ONLY, in the same places; nobody else's buffer is touched
+    gather_buf.fill_(0x5a)
+    for (o, n) in chunks:
+        mosaic.gather_chunk_root(send, o, n, gather_buf if rank == 0 else None, 0)
+    if rank == 0:
+        for q in range(world):
+            for j, ((o, n), sh, pt) in enumerate(zip(chunks, shapes, pitches)):
+                got = mosaic.chunk_view(gather_buf, world, o, n, q).as_strided(sh, (pt, sh[2], 1))
+                ok = ok and bool(torch.all(got == q * 16 + j + 1))
+    else:
+        ok = ok and bool(torch.all(gather_buf == 0x5a))
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

@@ -332,7 +332,7 @@ def test_bench_walks_its_n2_path_on_one_gpu(gpu, tmp_path, backend, gather, shar
 
 
 @pytest.mark.parametrize("backend,gather,shard", [("p2p", "chunk", "pairs"), ("torch", "single", "pairs"), ("torch", "chunk", "pairs"), ("p2p", "single", "pairs"),
-                                                  ("p2p", "chunk", "strips"), ("torch", "single", "strips")])
+                                                  ("p2p", "chunk", "strips"), ("torch", "single", "strips"), ("torch", "root", "pairs")])
 def test_bench_walks_its_n8_path_on_one_gpu(gpu, tmp_path, backend, gather, shard):
     """The rehearsal of the first 8-GPU run: bench.py at WORLD SIZE 8 on one GPU (ISX_BENCH_ONE_GPU=1), BASELINE config 4's
     real shape - 32 pairs, 4 per rank (small tiles) - through the direct schedule (HIP IPC between 8 processes: every rank maps 7 peers'
@@ -363,6 +363,8 @@ def test_bench_walks_its_n8_path_on_one_gpu(gpu, tmp_path, backend, gather, shar
     assert mg["rccl_ranks"] == 8 and mg["gather_backend"] == backend and mg["gather"] == gather
     chk = mg["gather_check"]
     assert chk["chunks_per_rank"] == (32 if shard == "pairs" else 8) and chk["mismatched_over_all_ranks"] == 0, chk
+    # the second reported leg: every chunk to rank 0 only - present whenever the graded schedule is an all-gather over torch.distributed
+    assert ("root_gather_Mpix_s" in mg) == (backend == "torch" and gather != "root"), mg
     if shard == "pairs":
         assert d["config"]["pairs_per_gpu"] == 4 and d["config"]["tiles_per_mosaic"] == 2
         # the send block: 4 mosaics of CV_8UC3 rows padded to 4 bytes
