@@ -493,7 +493,9 @@ def main():
     if args.pairs is None:
         args.pairs = 1 if world == 1 else 4
     if args.batch and args.streams is None:
-        args.streams = 1
+        # --batch: one chain on one stream; --batch --graph: the ONE graph holds 4 parallel chains (PairStitcher.capture_batch(branches=4): a graph
+        # costs nothing to fork, and its single chain was level with the single eager chain but behind several eager chains - round 6)
+        args.streams = min(args.pairs, 4) if args.graph else 1
     if args.streams is None:
         args.streams = 1 if args.pairs == 1 else min(args.pairs, 4)
     rank = int(os.environ.get("RANK", "0"))
@@ -551,6 +553,7 @@ def main():
             raise SystemExit("--shard strips: %d ranks are more than this %d-column panorama has strips of %d columns" % (strip_world, fw_all, strip_cols))
         del wp
     pstreams = [None] if (args.streams <= 1 or args.graph) else [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+    graph_branches = args.streams if (args.graph and args.batch) else 1      # --batch --graph --streams S: S parallel chains inside the ONE graph
     def make_imgs(seed):
         """the NT tiles of one mosaic: the statistics of synth.make_tile (sinusoid + U{-32..31} noise), generated on the device from `seed`"""
         gen.manual_seed(seed)
@@ -622,7 +625,8 @@ def main():
             for p, v in zip(pairs, views[0]):
                 p.out = v
         if args.batch and not use_dist:
-            batch_graph, _ = PairStitcher.capture_batch(pairs)      # ONE graph: the batched launch chain of all pairs
+            # ONE graph: the batched launch chain of all pairs; --streams S > 1: S parallel chains inside that one graph
+            batch_graph, _ = PairStitcher.capture_batch(pairs, branches=graph_branches, batch_size=args.batch_size if graph_branches > 1 else 0)
         else:
             for p in pairs:
                 p.capture()
@@ -994,7 +998,7 @@ def main():
                     "tiles_this_rank": pairs[0].active} if strips else {}),
                 "pairs_per_gpu": args.pairs, "tile_type": args.tile_type,
                 # which side of the fast kernels' limits this run was on (isx_blender_last_path): deferred | eager cycle, the kernel of the last collapse step
-                "path": dict(pairs[0].blender.last_path(), level1=pairs[0].blender.level1_format()), "streams": len(pstreams), "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
+                "path": dict(pairs[0].blender.last_path(), level1=pairs[0].blender.level1_format()), "streams": len(pstreams), "graph_branches": graph_branches, "batched_blend": bool(args.batch), "host_enqueue_ms_per_pair": round(host_enqueue_ms / args.pairs, 4), "bands": args.bands, "precision": args.precision, "hipgraph": bool(args.graph), "cycle": args.cycle,
                 "tile_base_px": bm["tile_base_px"], "mosaic_px": bm["mosaic_px"], "warped_px": bm["warped_px"]},
             # SURVEY §8(d)'s work model of a pair (every pyramid level materialised once, destination pyramid read-modify-written): a
             # normalisation of the step time, NOT bytes this build moves - the deferred cycle never moves most of them

@@ -1761,7 +1761,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         const bool gained = w->gain != 1.0;
         ISX_CHECK_ARG(!(gained && src_mask), ISX_ERR_UNSUPPORTED, "warp_with_mask: isx_warper_set_gain applies to tiles warped with the all-255 mask (src_mask == NULL)");
         static const int warp_xg = [] { const char* e = getenv("ISX_WARP_XG"); return e ? atoi(e) : 0; }();
-        const int xg = (warp_xg > 0 && (unsigned long long)gridt.x * gridt.y * gridt.x < (1ull << 32)) ? warp_xg : 0;
+        const int xg = (warp_xg > 0 && gridt.x >= 2 && (unsigned long long)gridt.x * gridt.y * gridt.x < (1ull << 32)) ? warp_xg : 0;   // (one block column: nothing to pair, and the magic would overflow)
         WarpTileArgs wta{w->proj, t, sv, TileDst{(unsigned char*)dd.data, (unsigned)dd.step, (unsigned char*)dm.data, (unsigned)dm.step, wcrop, dh, bx0, xg, 0xFFFFFFFFu / gridt.x + 1u}, {}};
         if (gained) memcpy(wta.lut, w->gain_lut, 256);
 #define ISX_WARP_TILE(KD, O16, V)                                                                                                            \
@@ -1804,7 +1804,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             static const bool vec = [] { const char* e = getenv("ISX_WARP_VEC"); return !(e && e[0] == '0'); }();
             const dim3 gridt(cdiv(dw, 64), cdiv(dh, 4 * WARP_WAVES));
             static const int warp_xg = [] { const char* e = getenv("ISX_WARP_XG"); return e ? atoi(e) : 0; }();
-            const int xg = (warp_xg > 0 && (unsigned long long)gridt.x * gridt.y * gridt.x < (1ull << 32)) ? warp_xg : 0;
+            const int xg = (warp_xg > 0 && gridt.x >= 2 && (unsigned long long)gridt.x * gridt.y * gridt.x < (1ull << 32)) ? warp_xg : 0;
             const WarpTileArgs wta{w->proj, t, sv, TileDst{dp, (unsigned)ds, nullptr, 0u, dw, dh, 0, xg, 0xFFFFFFFFu / gridt.x + 1u}, {}};
 #define ISX_WARP_IMG(KD, V) ISX_LAUNCH("warp_tile_img", bytes, st, (k_warp_tile<KD, false, V, false>), gridt, dim3(64 * WARP_WAVES), 0, wta)
             if (w->kind == ISX_WARP_CYLINDRICAL) { if (vec) ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, true); else ISX_WARP_IMG(ISX_WARP_CYLINDRICAL, false); }

@@ -313,9 +313,11 @@ def test_batched_blend_equals_the_serial_blends(gpu, prec_name):
             assert torch.equal(res[p][0], serial[p][0]), (prec_name, rep, p)
 
 
-def test_batched_chain_captured_as_one_hipgraph(gpu):
+@pytest.mark.parametrize("branches,batch_size", [(1, 0), (3, 2)])
+def test_batched_chain_captured_as_one_hipgraph(gpu, branches, batch_size):
     """BASELINE config 3 as ONE hipGraph: the batched launch chain of several pairs (PairStitcher.capture_batch) replayed - every mosaic equal
-    to the pair's own serial step, the planned ROIs verified inside the graph (a stale plan raises the flag on replay)."""
+    to the pair's own serial step, the planned ROIs verified inside the graph (a stale plan raises the flag on replay).  branches = 3 (round 6):
+    the same pairs as three parallel chains inside the one graph (side streams forked from and joined to the capture stream)."""
     import torch
     from imagestitch_amd._lib import IsxError
     from imagestitch_amd.pipeline import PairStitcher
@@ -329,7 +331,7 @@ def test_batched_chain_captured_as_one_hipgraph(gpu):
         out, mask = ps.step()
         serial.append((out.clone(), mask.clone()))
         pairs.append(ps)
-    graph, gstream = PairStitcher.capture_batch(pairs)
+    graph, gstream = PairStitcher.capture_batch(pairs, branches=branches, batch_size=batch_size)
     for rep in range(3):
         for ps in pairs:
             ps.out.fill_(-3); ps.out_mask.fill_(9)
