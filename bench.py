@@ -974,6 +974,16 @@ def main():
         for name, v in per_kernel.items():
             if v["ms"] > 0 and v["alg_MB"] > 0:
                 v["frac"] = round(v["alg_MB"] * 1e6 / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+        # One launch, three figures - named here, in one place:
+        #   frac            = THE figure: this kernel bracketed by HIP events on its own dispatch inside the TIMED region (every `bracketed_every`-th launch)
+        #   frac_serialised = the same launch in the one fully bracketed, serialised warm-up step (`kernels_ms_one_step`): every launch of that step
+        #                     carries events, which costs each a little (0.51 against 0.55 in round 5's driver run)
+        #   the committed rocprofv3 --kernel-trace --stats average (profiles/roundN_bench_kernel_stats.csv) is the tracer's view of the same command
+        #                     and usually 1 - 2 us shorter than the event bracket (events bracket the dispatch, the tracer the kernel)
+        if roof is not None and per_kernel.get(dominant, {}).get("frac") is not None:
+            roof["frac_serialised"] = per_kernel[dominant]["frac"]
+            roof["frac_is"] = ("HIP events around this kernel's own dispatch in the timed region; frac_serialised = the same launch in the fully bracketed "
+                               "warm-up step (kernels_ms_one_step); profiles/ holds rocprofv3's average of the same command")
             per = (allk or {}).get(name) or (allk or {}).get("k_" + name)
             if per is not None and v["launches"]:
                 v["traffic_MB_per_launch"] = round(per / 1e6, 2)

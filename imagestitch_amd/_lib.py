@@ -57,6 +57,8 @@ _SIGS = {
     "isx_warper_warp_with_mask_roi": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],
     "isx_warper_warp_with_mask": [C.c_void_p, _MP, _MP, _F9, _F9, _MP, _MP, _IP],
     "isx_warper_warp_with_mask_planned": [C.c_void_p, _MP, _MP, _F9, _F9, _IP, _MP, _MP],
+    "isx_warper_begin_batch": [C.c_void_p],
+    "isx_warper_end_batch": [C.c_void_p],
     "isx_warper_plan_status": [C.c_void_p, _IP],
     "isx_warper_join": [C.c_void_p],
     "isx_warper_set_deferred_verify": [C.c_void_p, C.c_int],

@@ -2563,6 +2563,8 @@ int run_blend_deferred_t(isx_blender* b, const OutMat& out) {
         dim3 grid(cdiv(maxc, PD_OW), cdiv(maxr, PD_TY), n);
         if ((ISX_TAIL_ABL & 1) && k >= 2) grid = dim3(1, 1, n);
         if ((ISX_TAIL_ABL & 4) && k >= 2) continue;
+        if ((ISX_TAIL_ABL & 8) && k == 1) continue;                            // round 6 (tools/probes/level2_ablation.sh): the level 1 -> 2 launch not issued
+        if ((ISX_TAIL_ABL & 16) && k == 0) grid.y = (grid.y * 13 + 9) / 10;    // ... and the level-0 pyrDown doing 1.3 x its work (pyr_down0_body wraps the rows)
         if (use_top2 && k == L - 1) {       // level L is rebuilt inside k_collapse_top2
             if (k == b->mark_level && b->mark_event) ISX_HIP(hipEventRecord(b->mark_event, st));
             continue;

@@ -482,12 +482,14 @@ __device__ __forceinline__ int reflect_once(int p, int n2m1) {
 #endif
 // MASK = false: the image alone - RotationWarper::warp(img, K, R, INTER_LINEAR, BORDER_REFLECT) as the reference calls it (W:229), the
 // mask being a call of its own (W:232, k_warp_mask_tile); d.mask is then null
-template <int KIND, bool OUT16, bool VEC, bool MASK = true, bool GAIN = false>
-__global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu(WARP_WPE))) void k_warp_tile(WarpTileArgs a) {
-    const Proj& p = a.p; const MapTabs& t = a.t; const SrcView& img = a.img; const TileDst& d = a.d;
+// The tile's geometry without the gain table: what a BATCHED launch carries per tile (k_warp_tile_batch)
+struct WarpTileGeom { Proj p; MapTabs t; SrcView img; TileDst d; };
+// ka: the same four structs where they lie in the kernel-argument segment (the out-of-line fix-up takes pointers); klut: the gain table there
+template <int KIND, bool OUT16, bool VEC, bool MASK, bool GAIN>
+__device__ __forceinline__ void warp_tile_body(const Proj& p, const MapTabs& t, const SrcView& img, const TileDst& d, const WarpTileGeom* ka, const unsigned* klut) {
     __shared__ unsigned char s_lut[GAIN ? 256 : 4];
     if constexpr (GAIN) {      // the 256-entry gain table, once per workgroup (before any thread leaves: everyone reaches the barrier)
-        if (threadIdx.x < 64) ((unsigned*)s_lut)[threadIdx.x] = ((const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr())->lut[threadIdx.x];
+        if (threadIdx.x < 64) ((unsigned*)s_lut)[threadIdx.x] = klut[threadIdx.x];
         __syncthreads();
     }
     // A wave is 64 pixels wide and 4 rows tall (16 lanes x 4 pixels per row), a block 64 x 16: the band of border pixels along the
@@ -703,10 +705,26 @@ __global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu
     }
     // ---- the rare rest (z out of the guarded range incl. the z <= 0 sentinel, more than one reflection, sources too small for a
     // window, the last columns of the buffer's last row): the whole 4-pixel row of the thread again, by the generic code path
-    if (generic) {
-        const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1, GAIN ? (const unsigned char*)ka->lut : nullptr);
-    }
+    if (generic) warp_tile_fixup<OUT16>(&ka->p, &ka->t, &ka->img, &ka->d, dx0, dy, 1u, 1, GAIN ? (const unsigned char*)klut : nullptr);
+}
+static_assert(offsetof(WarpTileArgs, lut) == sizeof(WarpTileGeom), "WarpTileArgs = WarpTileGeom + the gain table");
+template <int KIND, bool OUT16, bool VEC, bool MASK = true, bool GAIN = false>
+__global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu(WARP_WPE))) void k_warp_tile(WarpTileArgs a) {
+    const WarpTileArgs* ka = (const WarpTileArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    warp_tile_body<KIND, OUT16, VEC, MASK, GAIN>(a.p, a.t, a.img, a.d, (const WarpTileGeom*)ka, ka->lut);
+}
+// Several tiles in ONE launch (blockIdx.z = tile; round 6, isx_warper_begin_batch): the planned warps of a step are independent of each other,
+// and as separate launches on one stream the second waited for the first one's last waves - the long-lived ones that cross the image border -
+// and paid a dispatch ramp of its own (~3 us of a 175 us step per extra launch).  The grid is the largest tile's; blocks past a smaller
+// tile's edge leave at once.  Same body, same bits.
+constexpr int WARP_BATCH_MAX = 8;
+struct WarpTileBatch { WarpTileGeom a[WARP_BATCH_MAX]; };
+static_assert(sizeof(WarpTileBatch) <= 4096, "kernel-argument limit");
+template <int KIND, bool OUT16, bool VEC>
+__global__ __launch_bounds__(64 * WARP_WAVES) __attribute__((amdgpu_waves_per_eu(WARP_WPE))) void k_warp_tile_batch(WarpTileBatch b) {
+    const WarpTileGeom& a = b.a[blockIdx.z];
+    const WarpTileGeom* ka = &((const WarpTileBatch*)__builtin_amdgcn_kernarg_segment_ptr())->a[blockIdx.z];
+    warp_tile_body<KIND, OUT16, VEC, true, false>(a.p, a.t, a.img, a.d, ka, nullptr);
 }
 
 
@@ -1251,6 +1269,10 @@ struct isx_warper {
     std::vector<float> tab_host;           // staging of the one table being built (its upload is waited for)
     std::vector<int> host_cand;
     std::vector<float> host_scratch;      // the host border scan's stand-ins (roihost.cpp)
+    // isx_warper_begin_batch .. isx_warper_end_batch: the fused tile warps in between are collected and leave as ONE launch (k_warp_tile_batch)
+    struct BatchItem { int variant; WarpTileGeom g; unsigned gx, gy; double bytes; };
+    bool batching = false;
+    std::vector<BatchItem> batch;
     float k[9], rinv[9];
     Proj proj;
     hipStream_t roi_stream = nullptr;  // the synchronous ROI scans' stream (roi_stream_of)
@@ -1287,9 +1309,57 @@ int set_camera(isx_warper* w, const float K[9], const float R[9]) {
     return ISX_OK;
 }
 
+// The collected tile warps of a batch (isx_warper_begin_batch): runs of the same kernel variant leave as one launch of up to WARP_BATCH_MAX tiles
+// (blockIdx.z = tile, the grid the largest tile's); a run of one takes the ordinary kernel.
+template <int KD, bool O16, bool V>
+int launch_warp_batch(hipStream_t st, const isx_warper::BatchItem* it, int n) {
+    if (n == 1) {
+        WarpTileArgs a{it[0].g.p, it[0].g.t, it[0].g.img, it[0].g.d, {}};
+        ISX_LAUNCH("warp_tile", it[0].bytes, st, (k_warp_tile<KD, O16, V>), dim3(it[0].gx, it[0].gy), dim3(64 * WARP_WAVES), 0, a);
+        return ISX_OK;
+    }
+    WarpTileBatch b;
+    memset(&b, 0, sizeof(b));
+    unsigned gx = 0, gy = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        b.a[i] = it[i].g;
+        b.a[i].d.xg = 0;          // (the XCD-run order is a function of the launch's own grid: off in a shared one)
+        gx = std::max(gx, it[i].gx); gy = std::max(gy, it[i].gy); bytes += it[i].bytes;
+    }
+    ISX_LAUNCH("warp_tile", bytes, st, (k_warp_tile_batch<KD, O16, V>), dim3(gx, gy, (unsigned)n), dim3(64 * WARP_WAVES), 0, b);
+    return ISX_OK;
+}
+int flush_warp_batch(isx_warper* w) {
+    if (w->batch.empty()) return ISX_OK;
+    std::vector<isx_warper::BatchItem> items;
+    items.swap(w->batch);
+    for (size_t i = 0; i < items.size();) {
+        size_t j = i + 1;
+        while (j < items.size() && j - i < (size_t)WARP_BATCH_MAX && items[j].variant == items[i].variant) ++j;
+        const isx_warper::BatchItem* it = &items[i];
+        const int n = (int)(j - i), v = items[i].variant;
+        int rc = ISX_OK;
+        switch (v) {
+            case 0: rc = launch_warp_batch<ISX_WARP_CYLINDRICAL, false, false>(w->stream, it, n); break;
+            case 1: rc = launch_warp_batch<ISX_WARP_CYLINDRICAL, false, true>(w->stream, it, n); break;
+            case 2: rc = launch_warp_batch<ISX_WARP_CYLINDRICAL, true, false>(w->stream, it, n); break;
+            case 3: rc = launch_warp_batch<ISX_WARP_CYLINDRICAL, true, true>(w->stream, it, n); break;
+            case 4: rc = launch_warp_batch<ISX_WARP_SPHERICAL, false, false>(w->stream, it, n); break;
+            case 5: rc = launch_warp_batch<ISX_WARP_SPHERICAL, false, true>(w->stream, it, n); break;
+            case 6: rc = launch_warp_batch<ISX_WARP_SPHERICAL, true, false>(w->stream, it, n); break;
+            default: rc = launch_warp_batch<ISX_WARP_SPHERICAL, true, true>(w->stream, it, n); break;
+        }
+        if (rc != ISX_OK) return rc;
+        i = j;
+    }
+    return ISX_OK;
+}
+
 // Enqueue the queued verification scans of planned warps on the side stream, behind the main stream's
 // current position.  The scan is VALU-bound like the warp kernel: it should run under memory-bound work.
 int flush_verify(isx_warper* w, hipEvent_t after = nullptr) {
+    ISX_TRY(flush_warp_batch(w));      // (the scans start behind the warps they verify)
     if (w->pending.empty()) return ISX_OK;
     // ISX_VERIFY_NEVER: a measurement aid (what the verification scans cost a step).  A run under it is not a verified run and cannot pass
     // for one: isx_warper_plan_status answers ISX_ERR_PLAN once a verification has been dropped here.
@@ -1631,7 +1701,8 @@ int make_tabs(isx_warper* w, const int roi[4], MapTabs* t) {
     if (!e) {
         const size_t need = (n * sizeof(float) + 255) & ~(size_t)255;
         ISX_CHECK_ARG(need <= TAB_CHUNK, ISX_ERR_UNSUPPORTED, "warp: a %d x %d warped tile needs %zu bytes of column / row tables (limit %zu)", mw, mh, need, TAB_CHUNK);
-        auto start_over = [&]() -> int {      // enqueued kernels may still read the old tables: drain first
+        auto start_over = [&]() -> int {      // enqueued kernels (and collected ones: isx_warper_begin_batch) may still read the old tables: drain first
+            ISX_TRY(flush_warp_batch(w));
             ISX_HIP(hipStreamSynchronize(w->stream));
             w->tab_cache.clear(); w->tab_index.clear(); w->tab_chunk = 0; w->tab_used = 0; ++w->tab_resets;
             return ISX_OK;
@@ -1770,7 +1841,15 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         else ISX_LAUNCH("warp_tile", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(64 * WARP_WAVES), 0, wta);                              \
     } while (0)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
-        if (!src_mask) {
+        if (!src_mask && w->batching && !gained && dst->device >= 0 && dst_mask->device >= 0 && src->device >= 0) {
+            // collected: leaves with the other tiles of the batch as one launch (flush_warp_batch)
+            isx_warper::BatchItem bi;
+            bi.variant = (w->kind == ISX_WARP_CYLINDRICAL ? 0 : 4) | (dst->type == ISX_16SC3 ? 2 : 0) | (vec ? 1 : 0);
+            bi.g = WarpTileGeom{wta.p, wta.t, wta.img, wta.d};
+            bi.gx = gridt.x; bi.gy = gridt.y; bi.bytes = bytes;
+            w->batch.push_back(bi);
+        } else if (!src_mask) {
+            ISX_TRY(flush_warp_batch(w));
             if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_TILE_K(true, true); else ISX_WARP_TILE_K(true, false); }
             else { if (vec) ISX_WARP_TILE_K(false, true); else ISX_WARP_TILE_K(false, false); }
         } else if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_FUSED(true, true); else ISX_WARP_FUSED(true, false); }
@@ -1863,8 +1942,26 @@ int isx_warper_destroy(isx_warper* w) ISX_ENTRY {
     return ISX_OK;
 } ISX_EXIT("isx_warper_destroy")
 
+int isx_warper_begin_batch(isx_warper* w) ISX_ENTRY {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_begin_batch: null warper");
+    ISX_HIP(hipSetDevice(w->device));
+    ISX_TRY(flush_warp_batch(w));
+    w->batching = true;
+    return ISX_OK;
+} ISX_EXIT("isx_warper_begin_batch")
+
+int isx_warper_end_batch(isx_warper* w) ISX_ENTRY {
+    clear_error();
+    ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_end_batch: null warper");
+    ISX_HIP(hipSetDevice(w->device));
+    w->batching = false;
+    return flush_warp_batch(w);
+} ISX_EXIT("isx_warper_end_batch")
+
 int isx_warper_set_stream(isx_warper* w, void* hip_stream) ISX_ENTRY {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_set_stream: null warper");
+    ISX_TRY(flush_warp_batch(w));      // collected warps leave on the stream they were issued for
     w->stream = (hipStream_t)hip_stream;
     return ISX_OK;
 } ISX_EXIT("isx_warper_set_stream")

@@ -194,12 +194,7 @@ class PairStitcher:
                 self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
                 self._feed(i, self.corners[i])
         else:
-            for i in self.active:
-                if self.tile_cols is not None:
-                    self.warper.set_dst_columns(*self.tile_cols[i])
-                self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
-            if self.tile_cols is not None:
-                self.warper.set_dst_columns(0, 0)
+            self._warps()
             if getattr(self, "_capturing_outside", False):
                 self.warper.discard_pending()   # a step being captured: the verification runs beside the graph (replay)
             elif self.mark is None:
@@ -212,14 +207,26 @@ class PairStitcher:
             self.warper.verify_after(self.mark)   # blend() recorded the mark behind its level-`verify_at` pyrDown
         return self.out, self.out_mask
 
+    def _warps(self):
+        """The planned warps of every active tile - collected and launched as ONE kernel (isx_warper_begin_batch: blockIdx.z = tile; round 6.
+        ISX_WARP_BATCH=0: one launch per tile, for A/B runs)."""
+        batch = os.environ.get("ISX_WARP_BATCH", "1") != "0"
+        if batch:
+            self.warper.begin_batch()
+        try:
+            for i in self.active:
+                if self.tile_cols is not None:
+                    self.warper.set_dst_columns(*self.tile_cols[i])
+                self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
+        finally:
+            if self.tile_cols is not None:
+                self.warper.set_dst_columns(0, 0)
+            if batch:
+                self.warper.end_batch()
+
     def step_until_blend(self):
         """The planned step up to (not including) blend(): warps, prepare, feeds - for step_batch."""
-        for i in self.active:
-            if self.tile_cols is not None:
-                self.warper.set_dst_columns(*self.tile_cols[i])
-            self.warper.warp_with_mask_planned(self.imgs[i], self.K, self.Rs[i], self.rois[i], self.warped[i], self.wmasks[i])
-        if self.tile_cols is not None:
-            self.warper.set_dst_columns(0, 0)
+        self._warps()
         if getattr(self, "_capturing_outside", False):
             self.warper.discard_pending()
         elif self.mark is None:

@@ -154,6 +154,13 @@ class RotationWarper:
         check(self._lib.isx_warper_warp_with_mask_planned(self._h, C.byref(mi), C.byref(mm) if mm is not None else None, kp, rp,
                                                           roi, C.byref(mdi), C.byref(mdm)))
 
+    def begin_batch(self):
+        """isx_warper_begin_batch: the fused tile warps that follow are collected; end_batch() launches them as ONE kernel (blockIdx.z = tile)."""
+        check(self._lib.isx_warper_begin_batch(self._h))
+
+    def end_batch(self):
+        check(self._lib.isx_warper_end_batch(self._h))
+
     def set_roi_cache(self, on=True):
         """Opt-in: remember detectResultRoi per (K, R, scale, source size); repeated calls skip the scan and its host sync."""
         check(self._lib.isx_warper_set_roi_cache(self._h, int(bool(on))))

@@ -163,6 +163,15 @@ int isx_warper_warp_with_mask_planned(isx_warper* w, const isx_mat* src_img,
                                       const isx_mat* src_mask, const float K[9],
                                       const float R[9], const int planned_roi[4],
                                       isx_mat* dst_img, isx_mat* dst_mask);
+/* Several tiles' warps in ONE launch.  Between begin and end the fused tile warps of this handle (isx_warper_warp_with_mask / _roi / _planned
+ * with src_mask == NULL, device mats, no gain) are collected instead of launched, and isx_warper_end_batch sends them off as one launch of up
+ * to 8 tiles per kernel variant (blockIdx.z = tile): the per-image loop of the reference (W:223-233) issues one warp after the other, and on
+ * a GPU each launch waits for the last - longest-lived - waves of the one before and pays its own dispatch ramp (~3 us of a 175 us step).
+ * Same kernel body, same bits.  The outputs are not written, nor even enqueued, before isx_warper_end_batch returns: use them (feed them)
+ * after it.  isx_warper_verify / _join / _plan_status / _set_stream end the collection's pending launches as well; anything that cannot be
+ * collected (a caller-supplied source mask, host mats, a gain) is launched at once, behind what was collected so far.                  */
+int isx_warper_begin_batch(isx_warper* w);
+int isx_warper_end_batch(isx_warper* w);
 int isx_warper_plan_status(isx_warper* w, int* mismatches /* synchronises the stream */);
 /* The verification scans of planned warps run on an internal side stream.  isx_warper_join makes the
  * handle's stream wait for them without blocking the host — required before hipStreamEndCapture when

@@ -329,3 +329,58 @@ def test_warp_dst_columns(gpu, kind, out16, dense):
     di, dm = fresh()                                         # (0, 0): the whole tile again
     wp.warp_with_mask(img, K, Rs[0], out16=out16, dst_img=di, dst_mask=dm)
     assert torch.equal(di, full) and torch.equal(dm, fmask)
+
+
+@pytest.mark.parametrize("kind", [CYL, SPH])
+def test_batched_tile_warps_are_one_launch_and_the_same_bits(gpu, oracle, kind):
+    """isx_warper_begin_batch .. end_batch (round 6): the fused warps of several tiles - different sources, cameras and sizes, CV_8UC3 and CV_16SC3
+    outputs, a column range - are collected and leave as one launch per kernel variant (blockIdx.z = tile; the grid is the largest tile's).  Every
+    tile equals the oracle's warp; nothing is written before end_batch; a call that cannot be collected (a caller-supplied source mask) goes out
+    at once, behind what was collected so far."""
+    import torch
+    sizes = [(480, 270), (333, 401), (640, 200), (97, 130)]
+    f = 420.0
+    mk = gpu.CylindricalWarper if kind == CYL else gpu.SphericalWarper
+    warper = mk().create(f)
+    jobs = []
+    for i, (w, h) in enumerate(sizes):
+        K, Rs = _cams(w, h, f, yaw=0.2 + 0.07 * i)
+        img = synth.make_tile(h, w, 40 + i, noise_only=(i % 2 == 1))
+        roi = warper.warpRoi((w, h), K, Rs[i % 2])
+        dw, dh = roi[2] - roi[0] + 1, roi[3] - roi[1] + 1
+        out16 = i == 2
+        d_img = torch.full((dh, dw, 3), 77, dtype=torch.int16 if out16 else torch.uint8, device="cuda")
+        d_msk = torch.full((dh, dw), 99, dtype=torch.uint8, device="cuda")
+        o_corner, o_img, _ = oracle.warp_u8(kind, f, K, Rs[i % 2], img, LINEAR, REFLECT)
+        _, o_mask, _ = oracle.warp_u8(kind, f, K, Rs[i % 2], np.full((h, w), 255, np.uint8), NEAREST, CONST)
+        assert o_corner == (roi[0], roi[1])
+        jobs.append((torch.from_numpy(img).cuda(), K, Rs[i % 2], roi, d_img, d_msk, o_img.astype(np.int16) if out16 else o_img, o_mask))
+    warper.begin_batch()
+    for t_img, K, R, roi, d_img, d_msk, _, _ in jobs:
+        warper.warp_with_mask_planned(t_img, K, R, roi, d_img, d_msk)
+    torch.cuda.synchronize()
+    assert all(bool((j[4] == 77).all()) and bool((j[5] == 99).all()) for j in jobs)      # collected, not launched
+    warper.end_batch()
+    torch.cuda.synchronize()
+    for t_img, K, R, roi, d_img, d_msk, o_img, o_mask in jobs:
+        assert np.array_equal(d_img.cpu().numpy(), o_img) and np.array_equal(d_msk.cpu().numpy(), o_mask)
+    warper.plan_status()
+    # a batch with a call in its middle that cannot be collected (caller-supplied source mask), and a column range on the last tile
+    for j in jobs:
+        j[4].fill_(77); j[5].fill_(99)
+    w0, h0 = sizes[0]
+    smask = (synth.make_tile(h0, w0, 9, noise_only=True)[:, :, 0] > 40).astype(np.uint8) * 255
+    _, o_mask_s, _ = oracle.warp_u8(kind, f, jobs[0][1], jobs[0][2], smask, NEAREST, CONST)
+    warper.begin_batch()
+    warper.warp_with_mask_planned(*jobs[1][:6])
+    warper.warp_with_mask_planned(*jobs[0][:6], mask=torch.from_numpy(smask).cuda())       # launched at once, behind tile 1
+    warper.set_dst_columns(64, 200)
+    warper.warp_with_mask_planned(*jobs[2][:6])
+    warper.set_dst_columns(0, 0)
+    warper.end_batch()
+    torch.cuda.synchronize()
+    assert np.array_equal(jobs[1][4].cpu().numpy(), jobs[1][6]) and np.array_equal(jobs[1][5].cpu().numpy(), jobs[1][7])
+    assert np.array_equal(jobs[0][4].cpu().numpy(), jobs[0][6]) and np.array_equal(jobs[0][5].cpu().numpy(), o_mask_s)
+    got, ref = jobs[2][4].cpu().numpy(), jobs[2][6]
+    assert np.array_equal(got[:, 64:200], ref[:, 64:200]) and bool((got[:, :64] == 77).all()) and bool((got[:, 200:] == 77).all())
+    warper.plan_status()
