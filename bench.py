@@ -39,7 +39,7 @@ def measured_traffic(kernel, args, live=True):
     """HBM (fabric) bytes per launch of `kernel` from rocprofv3's PMC counters, (2 x FETCH_SIZE + WRITE_SIZE) KiB with FETCH and WRITE in
     separate passes (tools/measure_traffic.py; the factor 2 is calibrated for the kernels' access shapes, profiles/round2_fetch_calib.txt).
     live: collected NOW, by two short child runs of this command under `rocprofv3 --kernel-trace --pmc X` (about 30 s); when rocprofv3 is
-    missing or a pass fails, the committed measurement of the same command (profiles/round5_traffic.json) is returned instead.
+    missing or a pass fails, the committed measurement of the same command (profiles/round6_traffic.json) is returned instead.
     Returns (bytes or None, source)."""
     import shutil
     import subprocess
@@ -60,11 +60,11 @@ def measured_traffic(kernel, args, live=True):
         except Exception:
             pass
     try:
-        path = os.path.join(ROOT, "profiles", "round5_traffic.json")
+        path = os.path.join(ROOT, "profiles", "round6_traffic.json")
         d = json.load(open(path))
         if d.get("bench_args", []) != [] or args.precision != "f32" or args.bands != 5 or args.tiles != 2 or args.width != 3840 or args.kind != "cylindrical" or args.tile_type != "u8":
             return None, "no PMC measurement of this command"
-        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round5_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
+        return d["kernels"][kernel]["traffic_bytes"], ("profiles/round6_traffic.json: the committed PMC measurement of this command (tools/measure_traffic.py; "
                                                       "rocprofv3 was not usable in this run)")
     except Exception:
         return None, "no PMC measurement of this command"

@@ -1616,7 +1616,7 @@ int detect_roi(isx_warper* w, int sw, int sh, int roi[4], float mm[4], bool sync
         std::copy(planned, planned + 4, pd.planned);
         std::copy(w->k, w->k + 9, pd.k); std::copy(w->rinv, w->rinv + 9, pd.rinv);
         w->pending.push_back(pd);
-        if (!w->defer_verify) return flush_verify(w);
+        if (!w->defer_verify && !w->batching) return flush_verify(w);      // (a collecting batch: its verifications start when it ends)
         return ISX_OK;
     }
     // cylindrical: min keys start at 0xffffffff, max keys and the candidate count at 0 (armed by the
@@ -1956,7 +1956,9 @@ int isx_warper_end_batch(isx_warper* w) ISX_ENTRY {
     ISX_CHECK_ARG(w != nullptr, ISX_ERR_INVALID, "isx_warper_end_batch: null warper");
     ISX_HIP(hipSetDevice(w->device));
     w->batching = false;
-    return flush_warp_batch(w);
+    ISX_TRY(flush_warp_batch(w));
+    if (!w->defer_verify) return flush_verify(w);        // the planned warps' verification scans, behind the launch they verify
+    return ISX_OK;
 } ISX_EXIT("isx_warper_end_batch")
 
 int isx_warper_set_stream(isx_warper* w, void* hip_stream) ISX_ENTRY {

@@ -68,6 +68,10 @@ public:
         isx::check(isx_warper_roi(w_.handle(), src_size.width, src_size.height, k, r, roi, nullptr));
         return cv::Rect(roi[0], roi[1], roi[2] - roi[0] + 1, roi[3] - roi[1] + 1);
     }
+    // warpPoint / warpBackward are NOT on the path this library replaces: the reference never calls them (W:229, 232 and B:105, 109 call warp();
+    // W:122 buildMaps) and the C-ABI has no entry for either.  They forward to the stock OpenCV warper this adapter is instantiated over (host
+    // code, OpenCV's own arithmetic) so that the class stays a complete cv::detail::RotationWarper - a pipeline that does call them gets stock
+    // behaviour, not an accelerated one, and needs the stock class to exist (the declarations-only test stub has just enough of it).
     cv::Point2f warpPoint(const cv::Point2f& pt, cv::InputArray K, cv::InputArray R) override { return stock_.warpPoint(pt, K, R); }
     void warpBackward(cv::InputArray src, cv::InputArray K, cv::InputArray R, int interp_mode, int border_mode, cv::Size dst_size,
                       cv::OutputArray dst) override {

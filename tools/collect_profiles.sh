@@ -2,13 +2,13 @@
 # Collects the measurement evidence of a round on the GPU box (run via gpurun from the repo root):
 #   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh round2 [fuzz_seconds]'
 # Everything lands under gpurun_out/<tag>/; copy what is to be judged into profiles/.
-TAG=${1:-round5}; FUZZ=${2:-600}
+TAG=${1:-round6}; FUZZ=${2:-600}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 line() { grep "^{" | tail -1; }
 # 1. HBM traffic per kernel (two PMC passes of their own), then the default line that reads it
 python tools/measure_traffic.py $O/${TAG}_traffic.json > $O/traffic.log 2>&1
-cp $O/${TAG}_traffic.json profiles/round5_traffic.json 2>/dev/null      # (bench.py's fallback when rocprofv3 is not usable in a run)
+cp $O/${TAG}_traffic.json profiles/round6_traffic.json 2>/dev/null      # (bench.py's fallback when rocprofv3 is not usable in a run)
 python bench.py --steps 20 --warmup 5 2>/dev/null | line > $O/${TAG}_bench_n1.json
 # 2. the same command under the kernel tracer
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -60,7 +60,6 @@ for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== pipeline_probe $m" 
 # round 5: A13 (the in-tree linear-ramp pair blend) on the record; the drop-in legs with the fused feed switched off / without narrowing; many tiles
 python bench.py --a13 --steps 50 2>/dev/null | line > $O/${TAG}_bench_a13.json
 for v in "ISX_FEED_FUSE=0" "ISX_FEED_NARROW=0" "ISX_FEED_STRIP=0" "ISX_FEED_FUSE=1"; do for m in "1 5 literal" "0 5 literal" "1 5 sync"; do echo "== [$v] pipeline_probe $m" >> $O/${TAG}_feed_variants.txt; env $v python tools/pipeline_probe.py $m 2>&1 | tail -14 >> $O/${TAG}_feed_variants.txt; done; done
-bash tools/probes/tail_ablation.sh run > $O/${TAG}_tail_ablation.txt 2>&1      # (needs tmp_ab/libtail*.so: bash tools/probes/tail_ablation.sh build, here)
 bash tools/trace_many_tiles.sh ${TAG}_t64 --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 > $O/${TAG}_many_tiles_trace.txt 2>&1
 ISX_TAB=0 python bench.py --no-cpu-baseline --no-dropin --tiles 64 --focal 24000 --yaw 0.046 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_64_ISX_TAB_0.json
 ISX_TAB=0 python bench.py --no-cpu-baseline --no-dropin --tiles 24 --focal 9000 --yaw 0.12 --steps 6 --warmup 2 2>/dev/null | line > $O/${TAG}_bench_many_tiles_24_ISX_TAB_0.json
@@ -84,6 +83,29 @@ for w in (2, 4, 8):
                             "compute_speedup_vs_one_gpu": round(whole["ms_per_step"] / max(r["ms_per_step"] for r in rs), 2)}
 json.dump(out, open("%s/%s_strips_config5.json" % (O, TAG), "w"), indent=1)
 PY
+# round 6: the warp kernel's XCD-run block order (traffic and time), the level-2 fusion's bound, next step's warps under this step's blend,
+# batched tile warps, config 3 as one graph with parallel chains, the host border scan against the device's
+VARS="ISX_WARP_XG=0|ISX_WARP_XG=4|ISX_WARP_XG=8" bash tools/ab_env.sh > $O/${TAG}_warp_xg_ab.txt 2>&1
+for g in 0 8; do ISX_WARP_XG=$g python tools/measure_traffic.py $O/${TAG}_traffic_warp_xg$g.json > /dev/null 2>&1; done
+python - "$O" "$TAG" >> $O/${TAG}_warp_xg_ab.txt <<'PY'
+import json, sys
+O, TAG = sys.argv[1], sys.argv[2]
+for g in (0, 8):
+    try:
+        d = json.load(open("%s/%s_traffic_warp_xg%d.json" % (O, TAG, g))); k = d.get("kernels", d)
+        print("ISX_WARP_XG=%d warp_tile per launch:" % g, k.get("warp_tile"))
+    except Exception as e:
+        print("ISX_WARP_XG=%d: no traffic figure (%r)" % (g, e))
+PY
+VARS="ISX_WARP_BATCH=0|ISX_WARP_BATCH=1" bash tools/ab_env.sh > $O/${TAG}_warp_batch_ab.txt 2>&1
+bash tools/probes/level2_ablation.sh run > $O/${TAG}_level2_ablation.txt 2>&1      # (needs tmp_ab/libl2_*.so: bash tools/probes/level2_ablation.sh build, here)
+python tools/probes/warp_under_blend_probe.py 200 2>&1 | grep -v amdgpu.ids > $O/${TAG}_warp_under_blend.txt
+b config3_16pairs_batch_graph_1chain --pairs 16 --batch --graph --streams 1
+b config3_16pairs_batch_graph_4chains --pairs 16 --batch --graph --streams 4
+b config3_16pairs_batch_4streams --pairs 16 --batch --streams 4
+python tools/probes/roi_latency_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_roi_latency.txt; ISX_ROI_HOST=0 python tools/probes/roi_latency_probe.py 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_roi_latency.txt
+ISX_ROI_HOST=0 python tools/probes/literal_host_probe.py 1 2>&1 | grep -v amdgpu.ids > $O/${TAG}_literal_host_time_device_roi.txt
+python tools/opencv_ab.py > $O/${TAG}_opencv_ab.json 2>&1
 # 5. fuzz soak
 python tools/fuzz_parity.py $FUZZ 11 $O/${TAG}_fuzz_${FUZZ}s_seed11.json > $O/fuzz.log 2>&1
 tail -3 $O/fuzz.log

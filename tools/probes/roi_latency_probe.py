@@ -15,11 +15,23 @@ def run(n=300):
     for i in range(n):
         w.warpRoi((W, H), K, Rs[i & 1])
     return (time.perf_counter() - t0) / n * 1e6
-print("idle GPU: %.1f us per call" % run())
+# the C call alone (arguments converted once: the wrapper's numpy -> ctypes conversions are the caller's, 4 - 5 us of the figure above)
+import ctypes as C
+from imagestitch_amd import _lib
+lib = _lib.load()
+_k, kp = _lib.f9(K)
+_rs = [_lib.f9(R) for R in Rs]
+roi4 = (C.c_int * 4)()
+def run_c(n=300):
+    t0 = time.perf_counter()
+    for i in range(n):
+        lib.isx_warper_roi(w._h, W, H, kp, _rs[i & 1][1], roi4, None)
+    return (time.perf_counter() - t0) / n * 1e6
+print("idle GPU: %.1f us per call (C call alone: %.1f)" % (run(), run_c()))
 a = torch.empty((1 << 28,), dtype=torch.uint8, device="cuda")
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
     for _ in range(400):
         a.add_(1)
-print("busy GPU: %.1f us per call" % run())
+print("busy GPU: %.1f us per call (C call alone: %.1f)" % (run(), run_c()))
 torch.cuda.synchronize()
