@@ -1841,7 +1841,9 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
         else ISX_LAUNCH("warp_tile", bytes, st, (k_warp_tile<KD, O16, V>), gridt, dim3(64 * WARP_WAVES), 0, wta);                              \
     } while (0)
 #define ISX_WARP_TILE_K(O16, V) do { if (w->kind == ISX_WARP_CYLINDRICAL) ISX_WARP_TILE(ISX_WARP_CYLINDRICAL, O16, V); else ISX_WARP_TILE(ISX_WARP_SPHERICAL, O16, V); } while (0)
-        if (!src_mask && w->batching && !gained && dst->device >= 0 && dst_mask->device >= 0 && src->device >= 0) {
+        const bool collect = !src_mask && w->batching && !gained && dst->device >= 0 && dst_mask->device >= 0 && src->device >= 0;
+        if (!collect) ISX_TRY(flush_warp_batch(w));      // whatever is launched here goes out BEHIND what was collected so far
+        if (collect) {
             // collected: leaves with the other tiles of the batch as one launch (flush_warp_batch)
             isx_warper::BatchItem bi;
             bi.variant = (w->kind == ISX_WARP_CYLINDRICAL ? 0 : 4) | (dst->type == ISX_16SC3 ? 2 : 0) | (vec ? 1 : 0);
@@ -1849,7 +1851,6 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             bi.gx = gridt.x; bi.gy = gridt.y; bi.bytes = bytes;
             w->batch.push_back(bi);
         } else if (!src_mask) {
-            ISX_TRY(flush_warp_batch(w));
             if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_TILE_K(true, true); else ISX_WARP_TILE_K(true, false); }
             else { if (vec) ISX_WARP_TILE_K(false, true); else ISX_WARP_TILE_K(false, false); }
         } else if (dst->type == ISX_16SC3) { if (vec) ISX_WARP_FUSED(true, true); else ISX_WARP_FUSED(true, false); }
@@ -1867,6 +1868,7 @@ int warp_common(isx_warper* w, const isx_mat* src, const isx_mat* src_mask, cons
             ISX_TRY(detect_roi(w, src->cols, src->rows, scratch, nullptr, true, planned));
         }
     } else {
+        ISX_TRY(flush_warp_batch(w));      // (a plain warp() inside a batch: behind the collected tile warps)
         ISX_CHECK_ARG(dst->type == src->type, ISX_ERR_TYPE, "warp: dst type %s differs from src type %s", type_name(dst->type), type_name(src->type));
         ISX_CHECK_ARG(interp == ISX_INTER_NEAREST || interp == ISX_INTER_LINEAR || interp == (ISX_INTER_LINEAR | ISX_INTER_TIES_EVEN), ISX_ERR_UNSUPPORTED,
                       "warp: interpolation %d (only NEAREST and LINEAR)", interp);

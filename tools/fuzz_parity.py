@@ -668,8 +668,66 @@ def case_fused_feed(rng):
             violated = violated or any_bad
 
 
+def case_round6_calls(rng):
+    """Round 6: (a) 1 - 9 tiles' fused warps collected by isx_warper_begin_batch and launched as one kernel per variant (blockIdx.z = tile; random
+    sizes, cameras, CV_8UC3 / CV_16SC3 outputs, dense / pitched rows, now and then a call in the middle that cannot be collected) - every tile
+    against the oracle's warp; (b) isx_warper_roi, which ranks the border on the caller's thread where the extrema provably lie there, against the
+    oracle's scan of every source pixel (ROI and float extrema), the host-only self-test entry included."""
+    import ctypes as C
+    import torch
+    kind = int(rng.integers(0, 2))
+    f = float(rng.uniform(150.0, 900.0))
+    wp = (G.CylindricalWarper() if kind == 0 else G.SphericalWarper()).create(f)
+    if rng.integers(0, 2):
+        wp.set_deferred_verify(True)
+    nt = int(rng.integers(1, 10))
+    jobs = []
+    for i in range(nt):
+        w, h = int(rng.integers(2, 420)), int(rng.integers(2, 300))
+        K = np.array([[f * rng.uniform(0.8, 1.2), 0, w / 2 + rng.uniform(-5, 5)], [0, f * rng.uniform(0.8, 1.2), h / 2 + rng.uniform(-5, 5)], [0, 0, 1]], np.float32)
+        R = rot(rng, float(rng.choice([0.2, 0.6, 1.2])))
+        oroi, omm = O.detect_roi(kind, f, K, R, w, h)
+        dw, dh = int(oroi[2]) - int(oroi[0]) + 1, int(oroi[3]) - int(oroi[1]) + 1
+        if dw < 1 or dh < 1 or dw > 60000 or dh > 60000 or dw * dh > 1_500_000:
+            continue
+        roi, mm = wp.warpRoi((w, h), K, R, with_minmax=True)
+        assert tuple(int(v) for v in roi) == tuple(int(v) for v in oroi), (roi, oroi)
+        assert np.array_equal(np.asarray(mm, np.float32), omm), (mm, omm)
+        # the host-only entry: the same answer wherever it answers at all
+        hr, hm = np.zeros(4, np.int32), np.zeros(4, np.float32)
+        fp = C.POINTER(C.c_float)
+        Kc, Rc = np.ascontiguousarray(K.reshape(9)), np.ascontiguousarray(R.reshape(9))
+        rc = G.load().isx_selftest_roi_host(kind, C.c_float(f), Kc.ctypes.data_as(fp), Rc.ctypes.data_as(fp), w, h, int(rng.integers(0, 2)),
+                                            hr.ctypes.data_as(C.POINTER(C.c_int)), hm.ctypes.data_as(fp))
+        if rc == 0:
+            assert np.array_equal(hr, oroi) and np.array_equal(hm, omm), (hr, oroi, hm, omm)
+        src = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        out16, pitched = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        es = 2 if out16 else 1
+        pit = (dw * 3 * es + 63) // 64 * 64 if pitched else dw * 3 * es
+        di = torch.full((dh * pit // es,), 77, dtype=torch.int16 if out16 else torch.uint8, device="cuda").as_strided((dh, dw, 3), (pit // es, 3, 1))
+        pm = (dw + 63) // 64 * 64 if pitched else dw
+        dm = torch.full((dh * pm,), 99, dtype=torch.uint8, device="cuda").as_strided((dh, dw), (pm, 1))
+        smask = None
+        if rng.random() < 0.15:          # a caller-supplied source mask: launched at once, not collected
+            smask = (rng.integers(0, 4, (h, w)) > 0).astype(np.uint8) * 255
+        jobs.append((torch.from_numpy(src).cuda(), K, R, [int(v) for v in oroi], di, dm, src, out16, smask, (w, h)))
+    if not jobs:
+        return "skip"
+    wp.begin_batch()
+    for (t, K, R, roi, di, dm, src, out16, smask, _) in jobs:
+        wp.warp_with_mask_planned(t, K, R, roi, di, dm, mask=None if smask is None else torch.from_numpy(smask).cuda())
+    wp.end_batch()
+    wp.plan_status()
+    for (t, K, R, roi, di, dm, src, out16, smask, (w, h)) in jobs:
+        _, oi, _ = O.warp_u8(kind, f, K, R, src, 1, 2)
+        _, om, _ = O.warp_u8(kind, f, K, R, np.full((h, w), 255, np.uint8) if smask is None else smask, 0, 0)
+        assert np.array_equal(di.cpu().numpy(), oi.astype(np.int16) if out16 else oi), np.argwhere(di.cpu().numpy() != oi)[:3]
+        assert np.array_equal(dm.cpu().numpy(), om)
+
+
 CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_float_and_many, case_pipeline, case_find, case_warp_fused,
-         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls, case_many_tiles, case_fused_feed]
+         case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls, case_many_tiles, case_fused_feed, case_round6_calls]
 
 
 def run(budget, seed0, verbose=True):
