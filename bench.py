@@ -441,6 +441,7 @@ def main():
                          "pair like chunk, but to rank 0 ONLY (1 / (N - 1) of the bytes on the links: tells 'the blend scales' from 'the links carry "
                          "N - 1 times the bytes'; the default line reports it as a second leg, multi_gpu.root_gather_Mpix_s - the all-gather stays "
                          "the graded schedule, north_star fixes it)")
+    ap.add_argument("--no-root-leg", action="store_true", help="N > 1: skip the second reported leg (the same steps with every chunk gathered to rank 0 only)")
     ap.add_argument("--gather-backend", default="torch", choices=["torch", "isx", "p2p"],
                     help="N > 1: torch.distributed (RCCL), the library's own RCCL communicator (isx_gather_*), or the direct schedule "
                          "(isx_gather_p2p_*: every chunk copied straight into every rank's buffer, one stream per destination - tells RCCL's "
@@ -856,7 +857,7 @@ def main():
         # ... and, as a second reported leg, the same K steps with every chunk gathered to rank 0 ONLY (what --gather root times as `value`): a
         # rank's block crosses one link instead of N - 1, so this leg shows whether the blend scales when the links carry 1 / (N - 1) of the bytes
         dt_r = 0.0
-        if args.gather != "root" and args.gather_backend == "torch" and not args.graph:
+        if args.gather != "root" and args.gather_backend == "torch" and not args.graph and not args.no_root_leg:
             keep = args.gather
             args.gather = "root"
             fence()
