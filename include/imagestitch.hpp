@@ -127,6 +127,10 @@ public:
         return Point(roi[0], roi[1]);
     }
     void setGain(double gain) { check(isx_warper_set_gain(h_, gain)); }
+    // Not in the reference: the fused tile warps issued between the two calls (planned or _roi forms on device mats) leave as ONE launch
+    // (isx_warper_begin_batch / isx_warper_end_batch); their outputs exist once endBatch() has returned and its launch has run
+    void beginBatch() { check(isx_warper_begin_batch(h_)); }
+    void endBatch() { check(isx_warper_end_batch(h_)); }
     isx_warper* handle() { return h_; }
 private:
     isx_warper* h_ = nullptr;
