@@ -150,3 +150,18 @@ def test_byte_model_matches_survey():
     assert abs(m["blend"] / 1e6 - 24.3) < 0.1 and abs(m["feed"] / 1e6 - (52.6 - 6.0)) < 0.1
     m = model_bytes([8294400], [7398000], [0], 0, _lib.PREC_F32, 5)
     assert m["warp"] == 3 * 8294400 + 4 * 7398000
+
+
+def test_the_opencv_ab_probe_never_raises_and_says_what_it_found():
+    """tools/opencv_ab.py is called from smoke() on every box: where no cv2 imports it must say so in one line and compare nothing; where one does, it
+    must return a verdict per check (strings / dicts), never raise (a probe, not a gate)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import opencv_ab
+    res = opencv_ab.run(verbose=False)
+    assert isinstance(res.get("opencv"), str) and isinstance(res.get("checks"), dict)
+    cv2, what = opencv_ab.probe()
+    if cv2 is None:
+        assert res["checks"] == {} and what.startswith("no cv2")
+    else:
+        assert res["checks"], res
