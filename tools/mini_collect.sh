@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG; mkdir -p $O
 line() { grep "^{" | tail -1; }
 timeout 400 python tools/measure_traffic.py $O/${TAG}_traffic.json > $O/traffic.log 2>&1
-cp $O/${TAG}_traffic.json profiles/round4_traffic.json 2>/dev/null
+cp $O/${TAG}_traffic.json profiles/round6_traffic.json 2>/dev/null
 timeout 600 python bench.py --steps 20 --warmup 5 2>/dev/null | line > $O/${TAG}_bench_n1.json
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin 2>/dev/null | line > $O/${TAG}_bench_under_rocprof.json
