@@ -384,3 +384,54 @@ def test_batched_tile_warps_are_one_launch_and_the_same_bits(gpu, oracle, kind):
     got, ref = jobs[2][4].cpu().numpy(), jobs[2][6]
     assert np.array_equal(got[:, 64:200], ref[:, 64:200]) and bool((got[:, :64] == 77).all()) and bool((got[:, 200:] == 77).all())
     warper.plan_status()
+
+
+def test_the_table_cache_starts_over_when_it_is_full(gpu, oracle):
+    """mapBackward's per-column / per-row tables are cached per ROI in a bounded arena (1024 entries, 16 MiB; round 6): a handle that sees more
+    distinct ROIs than that drains its stream once and starts the cache over.  1 300 cameras through one warper, with a batch of collected warps
+    straddling the reset: every checked tile equals the oracle's warp, before and after it, and an early camera asked again afterwards too."""
+    import torch
+    w, h, f = 96, 64, 120.0
+    img = synth.make_tile(h, w, 3, noise_only=True)
+    t_img = torch.from_numpy(img).cuda()
+    warper = gpu.CylindricalWarper().create(f)
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+
+    def cam(i):        # a 40 x 33 grid of yaw x pitch: steps of 5 and 4 pixels on the cylinder, so (nearly) every camera has an ROI of its own
+        a, b = -0.9 + 0.045 * (i % 40), -0.5 + 0.03 * (i // 40)
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        return (Ry @ Rx).astype(np.float32)
+
+    def check(i, wi, wm):
+        _, o_img, _ = oracle.warp_u8(CYL, f, K, cam(i), img, LINEAR, REFLECT)
+        _, o_mask, _ = oracle.warp_u8(CYL, f, K, cam(i), np.full((h, w), 255, np.uint8), NEAREST, CONST)
+        assert np.array_equal(wi.cpu().numpy(), o_img) and np.array_equal(wm.cpu().numpy(), o_mask), i
+
+    rois = set()
+    for i in range(1300):
+        if i in (1020, 1021, 1022, 1023, 1024, 1025, 1026):
+            continue        # these go through one collected batch below, across the 1024-entry boundary
+        c, wi, wm = warper.warp_with_mask(t_img, K, cam(i))
+        rois.add((c, tuple(wi.shape)))
+        if i in (0, 1, 511, 1019, 1027, 1299):
+            check(i, wi, wm)
+        if i == 1019:
+            outs = []
+            warper.begin_batch()
+            for j in range(1020, 1027):
+                roi = warper.warpRoi((w, h), K, cam(j))
+                dw, dh = roi[2] - roi[0] + 1, roi[3] - roi[1] + 1
+                di = torch.zeros((dh, dw, 3), dtype=torch.uint8, device="cuda")
+                dm = torch.zeros((dh, dw), dtype=torch.uint8, device="cuda")
+                warper.warp_with_mask_planned(t_img, K, cam(j), roi, di, dm)
+                outs.append((j, di, dm))
+            warper.end_batch()
+            torch.cuda.synchronize()
+            for j, di, dm in outs:
+                check(j, di, dm)
+    assert len(rois) > 1100, len(rois)         # (the cameras really asked for that many different tables)
+    for i in (0, 2, 700):                      # after the reset: entries of the first generation are rebuilt on demand
+        _, wi, wm = warper.warp_with_mask(t_img, K, cam(i))
+        check(i, wi, wm)
+    warper.plan_status()
