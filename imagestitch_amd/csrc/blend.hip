@@ -1445,14 +1445,17 @@ __device__ __forceinline__ void collapse_gather_body(const TS& ts, int tb, int t
 }
 
 
+#ifndef ISX_GATHER_LEVEL_WPE
+#define ISX_GATHER_LEVEL_WPE 3      // waves per SIMD the level steps of k_collapse_gather are compiled for (re-measured in round 6: tools/probes/retune_round6.sh)
+#endif
 // One mosaic per launch: its tiles are all of ts.
 template <int M, int SK, bool FINE0, bool TOP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : ISX_GATHER_LEVEL_WPE))) void k_collapse_gather(TileSet ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     collapse_gather_body<M, SK, FINE0, TOP>(ts, 0, ts.n, coarse_out, fine_out, out);
 }
 // ... its tiles in a device-resident table (more than DEF_MAX of them)
 template <int M, int SK, bool FINE0, bool TOP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather_tab(TileTab ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : ISX_GATHER_LEVEL_WPE))) void k_collapse_gather_tab(TileTab ts, LevelBuf coarse_out, LevelBuf fine_out, OutMat out) {
     collapse_gather_body<M, SK, FINE0, TOP>(ts, 0, ts.n, coarse_out, fine_out, out);
 }
 
@@ -1467,7 +1470,7 @@ struct BatchOut {
 };
 static_assert(sizeof(TileSet) + sizeof(BatchOut) <= 4096, "a batched collapse step's arguments exceed the kernel-argument limit");
 template <int M, int SK, bool FINE0, bool TOP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : 3))) void k_collapse_gather_batch(TileSet ts, BatchOut bo) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FINE0 ? (M == M_F16 ? 5 : 4) : ISX_GATHER_LEVEL_WPE))) void k_collapse_gather_batch(TileSet ts, BatchOut bo) {
     const int m = blockIdx.z;
     collapse_gather_body<M, SK, FINE0, TOP>(ts, bo.first[m], bo.first[m + 1], bo.coarse_out[m], bo.fine_out[m], bo.out[m]);
 }
