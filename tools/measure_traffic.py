@@ -31,9 +31,7 @@ def short(name):
 
 
 # kernel function name -> the launch name bench.py / the library's profiler reports
-# (round 6: a step's warps leave as ONE launch of k_warp_tile_batch under the launch name "warp_tile"; the single-tile kernel - planning, the
-# synchronous entries - is kept apart as "warp_tile_1" so that the step's figure is the batched launch's)
-ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_warp_tile_batch": "warp_tile", "k_warp_tile": "warp_tile_1", "k_roi_scan": "roi_scan",
+ALIAS = {"k_collapse_gather": None, "k_warp_img_mask": "warp_img_mask", "k_warp_tile": "warp_tile", "k_roi_scan": "roi_scan",
          "k_lap_acc_all": "lap_acc_all", "k_pyr_down": None, "k_pyr_down_multi": None, "k_collapse": None}
 
 
