@@ -1019,6 +1019,9 @@ def main():
             "roofline": roof,
             "step_hbm": step_hbm,
             "kernels_ms_one_step": per_kernel,
+            # that step is the SERIALISED one (the reference's own call sequence, a corner returned per warp): its two warps are two launches of the
+            # single-tile kernel; the timed steps issue both tiles' warps as ONE launch (isx_warper_begin_batch, round 6: 35 us against 2 x 22)
+            "kernels_ms_one_step_is": "the serialised, fully bracketed warm-up step (synchronous warps: one launch per tile); the timed steps launch all tiles' warps at once",
         }
         out["preflight"] = {"steps": preflight_steps, "ms": args.preflight_ms,
                             "what": "untimed steps before the W warm-up steps: the set-up leaves the GPU idle and its clock takes ~70 steps to settle "
