@@ -730,8 +730,10 @@ CASES = [case_warp, case_blend, case_feather, case_prep, case_seam, case_blend_f
          case_linear_pair, case_strip, case_strip_feather, case_batch, case_s16_tiles, case_round4_calls, case_many_tiles, case_fused_feed, case_round6_calls]
 
 
-def run(budget, seed0, verbose=True):
-    """Round-robin over the case families for `budget` seconds; case n uses seed seed0 * 1000003 + n.  Returns the summary dict."""
+def run(budget, seed0, verbose=True, progress_path=None):
+    """Round-robin over the case families for `budget` seconds; case n uses seed seed0 * 1000003 + n.  Returns the summary dict.
+    progress_path: the summary so far is written there every two minutes ("partial": true), so that a soak the GPU box's time limit cuts
+    short still leaves its count behind (round 6 lost an hour-long one that way)."""
     G.load()
     t0, n, bad, skipped = time.time(), 0, 0, 0
     only = os.environ.get("ISX_FUZZ_ONLY", "")       # a comma-separated subset of the families (a soak of what a round changed)
@@ -739,7 +741,19 @@ def run(budget, seed0, verbose=True):
     counts = {f.__name__: 0 for f in CASES}
     fails = {f.__name__: 0 for f in CASES}
     failing_seeds = []
+    def summary(partial):
+        d = {"cases": n, "seconds": round(time.time() - t0, 1), "seed": seed0, "mismatches": bad, "skipped_geometries": int(skipped),
+             "per_family": {k: {"cases": counts[k], "mismatches": fails[k]} for k in counts}, "failing_seeds": failing_seeds[:50]}
+        if partial:
+            d["partial"] = True
+        return d
+    last_dump = t0
     while time.time() - t0 < budget:
+        if progress_path and time.time() - last_dump > 120.0:
+            import json
+            with open(progress_path, "w") as f:
+                json.dump(summary(True), f, indent=1)
+            last_dump = time.time()
         fn = CASES[n % len(CASES)]
         seed = seed0 * 1000003 + n
         try:
@@ -760,14 +774,13 @@ def run(budget, seed0, verbose=True):
                 print("EXC ", fn.__name__, "seed", seed, type(e).__name__, code, str(e)[:120])
             bad += 1; fails[fn.__name__] += 1; failing_seeds.append([fn.__name__, seed])
         n += 1
-    return {"cases": n, "seconds": round(time.time() - t0, 1), "seed": seed0, "mismatches": bad, "skipped_geometries": int(skipped),
-            "per_family": {k: {"cases": counts[k], "mismatches": fails[k]} for k in counts}, "failing_seeds": failing_seeds[:50]}
+    return summary(False)
 
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    out = run(budget, seed0)
+    out = run(budget, seed0, progress_path=sys.argv[3] if len(sys.argv) > 3 else None)
     print("cases", out["cases"], {k: v["cases"] for k, v in out["per_family"].items()}, "skipped", out["skipped_geometries"],
           "failures", out["mismatches"], "in %.0f s" % out["seconds"])
     if len(sys.argv) > 3:
