@@ -860,14 +860,18 @@ def main():
         if args.gather != "root" and args.gather_backend == "torch" and not args.graph and not args.no_root_leg:
             keep = args.gather
             args.gather = "root"
-            fence()
-            step()                                       # (one untimed step: the first grouped send / recv sets its channels up)
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            fence()
-            dt_r = time.perf_counter() - t1
+            try:
+                fence()
+                step()                                       # (one untimed step: the first grouped send / recv sets its channels up)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                fence()
+                dt_r = time.perf_counter() - t1
+            except Exception as e:      # an optional leg: a backend without gather() must not cost the run its line (every rank raises alike)
+                print("bench.py: the gather-to-root leg did not run: %r" % (e,), file=sys.stderr)
+                dt_r = 0.0
             args.gather = keep
         t = torch.tensor([dt, dt_c, dt_g, dt_r], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
