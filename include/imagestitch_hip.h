@@ -474,8 +474,8 @@ int isx_selftest_division(int device, int n, unsigned long long seed, int* misma
  * extrema provably lie on the source's border (every spherical camera; a cylindrical one with the image in front of the camera and no pole
  * of the cylinder near it: every rig of the reference): the 2 (W + H) border pixels ranked on the caller's thread by two monotone stand-ins
  * (csrc/roihost.cpp, AVX2), the pixels within a tolerance of the four extrema evaluated with mapForward (W:36-45) and the host's libm.
- * Needs no device: the CPU test-suite compares it with the oracle's scan of every source pixel.  isa: 0 = the code isx_warper_roi runs,
- * 1 = its scalar form.  ISX_ERR_UNSUPPORTED for a cylindrical camera outside that proof (isx_warper_roi scans every pixel on the GPU there). */
+ * Needs no device: the CPU test-suite compares it with the oracle's scan of every source pixel.  isa: 0 = the code isx_warper_roi runs
+ * (AVX-512F where the CPU has it, else AVX2, else scalar), 1 = its scalar form, 2 = its AVX2 form.  ISX_ERR_UNSUPPORTED for a cylindrical camera outside that proof (isx_warper_roi scans every pixel on the GPU there). */
 int isx_selftest_roi_host(int kind, float scale, const float K[9], const float R[9], int src_w, int src_h, int isa, int roi[4], float minmax[4]);
 /* Every entry of this header is a function-try-block: a C++ exception raised underneath it (std::bad_alloc of a host container, a
  * std::length_error, anything a future change throws) is stopped there and comes back as a status - ISX_ERR_NOMEM for the two allocation

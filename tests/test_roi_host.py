@@ -1,7 +1,7 @@
 """detectResultRoi (W:64-88) on the caller's thread (csrc/roihost.cpp, round 6): where the extrema provably lie on the source's border
 `isx_warper_roi` ranks the 2 (W + H) border pixels on the host (AVX2) instead of launching a workgroup and waiting for it.  No device is
 needed for that path, so the CPU suite compares it - ROI and float extrema - with the oracle's scan of EVERY source pixel (cylindrical,
-W:72-81) / OpenCV's border form (spherical), for the vectorised and the scalar code."""
+W:72-81) / OpenCV's border form (spherical), for the vectorised (AVX-512F, AVX2) and the scalar code."""
 import ctypes as C
 
 import numpy as np
@@ -34,7 +34,7 @@ def _rot(yaw, pitch, roll):
 
 def _check(lib, oracle, kind, scale, K, R, w, h):
     oroi, omm = oracle.detect_roi(kind, scale, K, R, w, h)
-    for isa in (0, 1):
+    for isa in (0, 1, 2):       # the best vector form the CPU has (AVX-512F / AVX2), the scalar form, the AVX2 form
         rc, roi, mm = _host(lib, kind, scale, K, R, w, h, isa)
         assert rc == 0, lib.isx_last_error()
         assert np.array_equal(roi, oroi), (isa, roi, oroi)
